@@ -1,0 +1,179 @@
+/*
+ * unet_hip.h — C ABI of libunet_hip.so: the MI355X (gfx950) kernels behind the
+ * Our_UNet train step of Ulixes-8/UNet-Implementations.
+ *
+ * The reference has no FFI: its operator API for this path is the PyTorch module
+ * surface.  Every entry point below replaces the ATen op(s) the
+ * reference reaches through torch.nn at the cited file:line (paths relative to
+ * the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every function returns 0 on success or a negative UNET_E_* code;
+ *     unet_last_error() returns a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers owned by the caller (no ownership
+ *     transfer, no hidden allocation); workspaces are caller-provided and sized
+ *     by the matching *_workspace_bytes() query.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - activations are NHWC fp32 ("pixel-major": [N][H][W][C]); logits and the
+ *     input image cross the module boundary as NCHW, exactly like the reference.
+ *   - packed 3x3 weights: wf[tap][ci][co] (forward / B operand of the implicit
+ *     GEMM) and wd[tap][co][ci] (data gradient), tap = ky*3+kx.
+ */
+#ifndef UNET_HIP_H_
+#define UNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_ABI_VERSION 1
+
+#define UNET_OK 0
+#define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
+#define UNET_E_LAUNCH (-2)  /* HIP launch or runtime error */
+#define UNET_E_WORKSPACE (-3) /* workspace too small */
+
+typedef void* unet_stream_t; /* hipStream_t */
+
+const char* unet_last_error(void);
+int unet_abi_version(void);
+/* number of HIP devices visible to the library (0 without a GPU); never fails */
+int unet_device_count(void);
+
+/* ---- layout helpers ------------------------------------------------------ */
+
+/* NCHW -> NHWC (module boundary for the input image, Our_UNet/models/unet.py:399) */
+int unet_nchw_to_nhwc(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W,
+                      unet_stream_t stream);
+/* NHWC -> NCHW (test helper / hooks that want the reference layout) */
+int unet_nhwc_to_nchw(const float* x_nhwc, float* y_nchw, int N, int C, int H, int W,
+                      unet_stream_t stream);
+
+/* OIHW [Cout][Cin][3][3] (state_dict layout, Our_UNet/models/unet.py:106-115)
+ * -> wf[9][Cin][Cout] and wd[9][Cout][Cin]; either output may be NULL. */
+int unet_pack_conv3x3_weights(const float* w_oihw, float* wf, float* wd, int Cout, int Cin,
+                              unet_stream_t stream);
+
+/* ---- 3x3 convolution (pad 1, stride 1 or 2) ------------------------------ */
+
+/* y[N][Ho][Wo][Cout] = conv3x3(cat(x0[.., C0], x1[.., C1])) + bias.
+ * Replaces nn.Conv2d forward inside ConvBlock (Our_UNet/models/unet.py:106-115,
+ * stride rule :103) and the torch.cat of UpBlock (:228) via the two-source
+ * input (x1 may be NULL with C1 = 0).  H, W are the INPUT spatial sizes;
+ * Ho = (H-1)/stride+1.  C0 == 3 (RGB stem) or C0, C1 multiples of 32;
+ * Cout multiple of 32.
+ *
+ * Fused InstanceNorm statistics (optional): if stats_partial != NULL the
+ * epilogue also writes, per 32-pixel row group of each tile, the per-channel
+ * (mean, M2) pair consumed by unet_instnorm_finalize; see
+ * unet_conv3x3_fwd_stats_rows(). */
+int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1, const float* wf,
+                     const float* bias, float* y, int N, int H, int W, int Cout, int stride,
+                     unet_stream_t stream);
+
+/* dx[N][H][W][Ccols] (+)= conv3x3_transpose(dy[N][Ho][Wo][Cout], wd slice).
+ * Replaces the data-gradient half of aten::convolution_backward reached from
+ * loss.backward() (Our_UNet/src/train.py:663).  `wd` points at the first
+ * column of the slice inside wd[9][Cout][ldw]; Ccols is the slice width (the
+ * channel count of dx).  H, W are the spatial sizes of dx (the conv INPUT).
+ * accumulate != 0 adds into dx (skip tensors receive two gradients). */
+int unet_conv3x3_bwd_data(const float* dy, const float* wd, int ldw, float* dx, int N, int H,
+                          int W, int Cout, int Ccols, int stride, int accumulate,
+                          unet_stream_t stream);
+
+/* dw_oihw[Cout][Cin_total][3][3] (columns ci_offset .. ci_offset+Cx) =
+ *   sum over pixels of x[.., Cx] (x) dy[.., Cout]; db[Cout] = sum dy if db != NULL.
+ * Replaces the weight/bias-gradient half of aten::convolution_backward.
+ * H, W are the spatial sizes of x (the conv input). */
+size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, int Cx, int Cout, int stride);
+int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, float* dw_oihw,
+                            int ci_offset, int Cin_total, float* db, void* workspace,
+                            size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
+                            unet_stream_t stream);
+
+/* ---- InstanceNorm2d(eps, affine) + LeakyReLU + SpatialDropout2d ----------- */
+
+/* Per-(n,c) statistics of y[N][HW][C] and the folded affine coefficients
+ *   alpha[n][c] = gamma[c]*rstd, beta2[n][c] = beta[c] - mean*alpha.
+ * Replaces aten::native_batch_norm statistics as lowered from
+ * nn.InstanceNorm2d(eps=1e-5, affine=True) (Our_UNet/models/unet.py:118-119).
+ * mean, rstd, alpha, beta2 are [N][C]. */
+size_t unet_instnorm_workspace_bytes(int N, int HW, int C);
+int unet_instnorm_stats(const float* y, const float* gamma, const float* beta, float eps,
+                        float* mean, float* rstd, float* alpha, float* beta2, void* workspace,
+                        size_t workspace_bytes, int N, int HW, int C, unet_stream_t stream);
+
+/* a = leaky_relu(y*alpha + beta2, slope) * mask ; mask [N][C] may be NULL.
+ * Replaces InstanceNorm apply + nn.LeakyReLU (unet.py:122-123) +
+ * SpatialDropout2d.forward (unet.py:13-35; mask already scaled by 1/(1-p)). */
+int unet_instnorm_lrelu_drop_fwd(const float* y, const float* alpha, const float* beta2,
+                                 const float* mask, float slope, float* a, int N, int HW, int C,
+                                 unet_stream_t stream);
+
+/* Backward of the block above: from ga = dL/da produce dy = dL/dy (may alias ga),
+ * dgamma[C], dbeta[C] and dbias[C] = sum dy (the conv bias gradient; may be NULL). */
+int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta,
+                                 const float* mask, float slope, float* dy, float* dgamma,
+                                 float* dbeta, float* dbias, void* workspace,
+                                 size_t workspace_bytes, int N, int HW, int C,
+                                 unet_stream_t stream);
+
+/* ---- bilinear 2x upsample (align_corners=False) --------------------------- */
+
+/* y[N][2h][2w][C] from x[N][h][w][C]; replaces F.interpolate in UpBlock.forward
+ * (Our_UNet/models/unet.py:219-225) for the exact-2x case. */
+int unet_upsample2x_fwd(const float* x, float* y, int N, int h, int w, int C,
+                        unet_stream_t stream);
+/* gx[N][h][w][C] (+)= transpose-stencil of gy[N][2h][2w][C] (gather form, no atomics) */
+int unet_upsample2x_bwd(const float* gy, float* gx, int N, int h, int w, int C, int accumulate,
+                        unet_stream_t stream);
+
+/* ---- 1x1 segmentation head ------------------------------------------------ */
+
+/* logits_nchw[N][K][HW] = a[N][HW][C] . w[K][C] + b[K]; replaces
+ * segmentation_output = nn.Conv2d(32, 3, 1) (Our_UNet/models/unet.py:374-381,:430).
+ * C == 32, K <= 4. */
+int unet_head1x1_fwd(const float* a, const float* w, const float* b, float* logits_nchw, int N,
+                     int HW, int C, int K, unet_stream_t stream);
+size_t unet_head1x1_bwd_workspace_bytes(int N, int HW, int C, int K);
+int unet_head1x1_bwd(const float* a, const float* dlogits_nchw, const float* w, float* da,
+                     float* dw, float* db, void* workspace, size_t workspace_bytes, int N, int HW,
+                     int C, int K, unet_stream_t stream);
+
+/* ---- SimpleLoss: dynamic-weighted CE + soft Dice, forward and gradient ----- */
+
+/* loss_out[0] = w_ce*CE + w_dice*Dice, loss_out[1] = CE, loss_out[2] = Dice,
+ * loss_out[3..5] = the class weights used; dlogits (NCHW, may be NULL) = dL/dlogits.
+ * Replaces SimpleLoss.forward and its autograd backward
+ * (Our_UNet/models/losses.py:24-62 class weights, :73-76 CE, :84-121 Dice).
+ * class_weights: 3 floats on device used when dynamic_weights == 0 (NULL = unweighted).
+ * global_counts (optional, may be NULL): when non-NULL the kernel pair is split
+ * so the caller can all-reduce the 4 class/valid counts between the passes. */
+size_t unet_dice_wce_loss_workspace_bytes(int N, int H, int W);
+int unet_dice_wce_loss_fwd_bwd(const float* logits_nchw, const int64_t* target, float* loss_out,
+                               float* dlogits_nchw, void* workspace, size_t workspace_bytes,
+                               int N, int H, int W, float smooth, float w_dice, float w_ce,
+                               int ignore_index, int dynamic_weights, const float* class_weights,
+                               float grad_scale, unet_stream_t stream);
+
+/* ---- SGD with Nesterov momentum over a flat arena -------------------------- */
+
+/* g' = g*grad_scale + wd*p; buf = first_step ? g' : mu*buf + g'; p -= lr*(g' + mu*buf).
+ * Replaces optim.SGD(lr, momentum, nesterov=True, weight_decay).step()
+ * (Our_UNet/src/train.py:445-451,:664). */
+int unet_sgd_nesterov_step(float* params, const float* grads, float* momentum, int64_t n,
+                           float lr, float mu, float weight_decay, int first_step,
+                           float grad_scale, unet_stream_t stream);
+
+/* out[i] = a[i] + b[i] (gradient accumulation of skip tensors, test helper) */
+int unet_add_inplace(float* a, const float* b, int64_t n, unet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H_ */

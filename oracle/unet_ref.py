@@ -1,0 +1,222 @@
+"""ORACLE — test infrastructure only (never imported by the product path).
+
+CPU restatement of the reference's Our_UNet train step with stock torch fp32 ops:
+the same ATen operators the reference reaches through `torch.nn`, written
+functionally over a plain `state_dict`.  Each function cites the reference
+file:line it follows (paths relative to the reference checkout).
+
+Pinned: `tests/test_oracle_golden.py` checks this file against the fixtures in
+`tests/golden/`, which `tools/make_golden.py` generated in the build container by
+importing the reference's own `Our_UNet/models/unet.py` and `losses.py`.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg use it.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FEATURES = [32, 64, 128, 256, 512, 512]          # Our_UNet/src/train.py:780
+STRIDES = [1, 2, 2, 2, 2, 2]                      # Our_UNet/src/train.py:782
+ENC_DROPOUT = [0.0, 0.0, 0.1, 0.2, 0.3, 0.3]      # Our_UNet/src/train.py:791
+DEC_DROPOUT = [0.3, 0.2, 0.2, 0.1, 0.0]           # Our_UNet/src/train.py:793
+NEG_SLOPE = 0.01                                  # nn.LeakyReLU default, models/unet.py:122-123
+EPS = 1e-5                                        # models/unet.py:298-299
+
+
+# --------------------------------------------------------------------------- naming
+def block_indices(drop_rate):
+    """Indices of (conv, norm) pairs inside ConvBlock.block: a SpatialDropout2d module is
+    appended after each activation only when the rate is > 0 (models/unet.py:126-127)."""
+    step = 4 if drop_rate > 0 else 3
+    return [(0, 1), (step, step + 1)]
+
+
+def layer_table():
+    """Forward-order list of (prefix, conv_idx, norm_idx, cin, cout, stride, drop_rate, kind)."""
+    rows = []
+    cin = 3
+    for e, (f, s, p) in enumerate(zip(FEATURES, STRIDES, ENC_DROPOUT)):
+        for k, (ci, ni) in enumerate(block_indices(p)):
+            rows.append((f"encoder_stages.{e}.block", ci, ni, cin if k == 0 else f, f,
+                         s if k == 0 else 1, p, "enc"))
+        cin = f
+    for d, p in enumerate(DEC_DROPOUT):
+        lvl = len(FEATURES) - 2 - d
+        f = FEATURES[lvl]
+        for k, (ci, ni) in enumerate(block_indices(p)):
+            rows.append((f"decoder_stages.{d}.conv_block.block", ci, ni,
+                         FEATURES[lvl + 1] + f if k == 0 else f, f, 1, p,
+                         "dec_first" if k == 0 else "dec"))
+    return rows
+
+
+def dropout_layers():
+    """(channels, rate) of every SpatialDropout2d in forward order."""
+    return [(r[4], r[6]) for r in layer_table() if r[6] > 0]
+
+
+# --------------------------------------------------------------------------- weights
+def fill_state_dict(seed, trained_like=True):
+    """Deterministic weights shared by the reference, the oracle and the HIP model.
+
+    numpy PCG64 stream -> Kaiming-normal(fan_out, gain sqrt(2)) conv weights
+    (models/unet.py:386-392).  With trained_like=True biases and the InstanceNorm affine
+    parameters are perturbed so that every one of the 90 tensors influences the output.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        std = np.sqrt(2.0 / (cout * k * k))
+        sd[name + ".weight"] = torch.from_numpy(
+            (rng.standard_normal((cout, cin, k, k)) * std).astype(np.float32))
+        b = rng.standard_normal(cout) * 0.1 if trained_like else np.zeros(cout)
+        sd[name + ".bias"] = torch.from_numpy(b.astype(np.float32))
+
+    def norm(name, c):
+        g = 1.0 + 0.1 * rng.standard_normal(c) if trained_like else np.ones(c)
+        b = 0.1 * rng.standard_normal(c) if trained_like else np.zeros(c)
+        sd[name + ".weight"] = torch.from_numpy(g.astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy(b.astype(np.float32))
+
+    for prefix, ci, ni, cin, cout, _, _, _ in layer_table():
+        conv(f"{prefix}.{ci}", cout, cin, 3)
+        norm(f"{prefix}.{ni}", cout)
+    conv("segmentation_output", 3, FEATURES[0], 1)
+    return sd
+
+
+def synthetic_batch(seed, n, h, w):
+    """Images ~ N(0,1) (ImageNet-standardised pixels, src/train.py:303-308) and masks with one
+    foreground class per image, a 255 ring around the blob and background elsewhere."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = torch.from_numpy(rng.standard_normal((n, 3, h, w)).astype(np.float32))
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = np.zeros((n, h, w), dtype=np.int64)
+    for i in range(n):
+        cy, cx = h * (0.4 + 0.2 * rng.random()), w * (0.4 + 0.2 * rng.random())
+        ry, rx = h * (0.22 + 0.1 * rng.random()), w * (0.25 + 0.1 * rng.random())
+        d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+        cls = 1 + (i % 2)
+        mask[i][d < 1.0] = cls
+        ring = 1.0 + 4.0 * 2.0 / min(ry, rx)
+        mask[i][(d >= 1.0) & (d < ring)] = 255
+    return img, torch.from_numpy(mask)
+
+
+def draw_dropout_masks(seed, n):
+    """Replays the reference's draws: one `x.new_empty(N,C,1,1).bernoulli_(1-p)` then
+    `.div_(1-p)` per SpatialDropout2d in forward order (models/unet.py:30-31), from torch's
+    global CPU generator seeded with `seed`."""
+    torch.manual_seed(seed)
+    out = []
+    for c, p in dropout_layers():
+        m = torch.empty(n, c, 1, 1).bernoulli_(1 - p)
+        out.append(m.div_(1 - p).view(n, c))
+    return out
+
+
+# --------------------------------------------------------------------------- per-op
+def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None):
+    """Conv2d(3x3, pad 1) -> InstanceNorm2d(eps, affine) -> LeakyReLU(0.01) -> channel mask
+    (models/unet.py:101-134; SpatialDropout2d.forward :22-35)."""
+    y = F.conv2d(x, w, b, stride=stride, padding=1)
+    y = F.instance_norm(y, weight=gamma, bias=beta, eps=EPS)
+    y = F.leaky_relu(y, NEG_SLOPE)
+    if mask is not None:
+        y = y * mask.view(mask.shape[0], mask.shape[1], 1, 1)
+    return y
+
+
+def upsample_concat(x, skip):
+    """UpBlock.forward up-sampling + concat, up-sampled tensor first (models/unet.py:215-228)."""
+    if x.shape[2:] != skip.shape[2:]:
+        x = F.interpolate(x, size=skip.shape[2:], mode="bilinear", align_corners=False)
+    return torch.cat([x, skip], dim=1)
+
+
+# --------------------------------------------------------------------------- network
+def unet_forward(sd, x, masks=None):
+    """UNet.forward (models/unet.py:399-432).  `masks`: list from draw_dropout_masks (train
+    mode) or None (eval / rates 0)."""
+    mi = iter(masks) if masks is not None else None
+    skips = []
+    rows = layer_table()
+    cur = x
+    n_enc = 2 * len(FEATURES)
+    for li, (prefix, ci, ni, _, _, stride, p, kind) in enumerate(rows):
+        if kind == "dec_first":
+            cur = upsample_concat(cur, skips.pop())
+        m = next(mi) if (mi is not None and p > 0) else None
+        cur = conv_in_lrelu_drop(cur, sd[f"{prefix}.{ci}.weight"], sd[f"{prefix}.{ci}.bias"],
+                                 sd[f"{prefix}.{ni}.weight"], sd[f"{prefix}.{ni}.bias"], stride, m)
+        if kind == "enc" and li % 2 == 1 and li < n_enc - 1:
+            skips.append(cur)
+    return F.conv2d(cur, sd["segmentation_output.weight"], sd["segmentation_output.bias"])
+
+
+# --------------------------------------------------------------------------- loss
+def class_weights(target, ignore_index=255, num_classes=3):
+    """SimpleLoss._compute_class_weights (models/losses.py:24-62)."""
+    valid = target != ignore_index
+    total = valid.sum().float()
+    counts = torch.stack([((target == c) & valid).sum().float() for c in range(num_classes)])
+    counts = torch.where(counts == 0, torch.ones_like(counts), counts)
+    w = total / counts
+    return w * (num_classes / w.sum())
+
+
+def dice_loss(logits, target, ignore_index=255, smooth=1e-5):
+    """SimpleLoss._dice_loss (models/losses.py:84-121)."""
+    valid = (target != ignore_index).float()
+    prob = F.softmax(logits, dim=1)
+    n, k = logits.shape[:2]
+    total = 0
+    for c in range(k):
+        t = ((target == c).float() * valid).reshape(n, -1)
+        p = (prob[:, c] * valid).reshape(n, -1)
+        inter = (p * t).sum(dim=1)
+        union = p.sum(dim=1) + t.sum(dim=1)
+        total = total + (1.0 - ((2.0 * inter + smooth) / (union + smooth)).mean())
+    return total / k
+
+
+def simple_loss(logits, target, weight_dice=1.0, weight_ce=1.0, ignore_index=255, smooth=1e-5,
+                dynamic_weights=True, fixed_weights=None):
+    """SimpleLoss.forward (models/losses.py:64-82)."""
+    w = class_weights(target, ignore_index) if dynamic_weights else fixed_weights
+    ce = F.cross_entropy(logits, target, weight=w, ignore_index=ignore_index)
+    return weight_ce * ce + weight_dice * dice_loss(logits, target, ignore_index, smooth)
+
+
+# --------------------------------------------------------------------------- optimizer
+def sgd_nesterov_(params, grads, bufs, lr=0.005, momentum=0.99, weight_decay=1e-4):
+    """optim.SGD(nesterov=True, dampening=0) update (src/train.py:445-451); `bufs` entries are
+    None before the first step."""
+    with torch.no_grad():
+        for i, (p, g) in enumerate(zip(params, grads)):
+            g = g.add(p, alpha=weight_decay)
+            if bufs[i] is None:
+                bufs[i] = g.clone()
+            else:
+                bufs[i].mul_(momentum).add_(g)
+            g = g.add(bufs[i], alpha=momentum)
+            p.add_(g, alpha=-lr)
+
+
+def train_step(sd, bufs, images, target, masks=None, lr=0.005, momentum=0.99, weight_decay=1e-4):
+    """One step in the order of train_one_epoch (src/train.py:634-664).  `sd` values must be
+    leaf tensors with requires_grad=True; returns (loss, {name: grad})."""
+    names = list(sd.keys())
+    for v in sd.values():
+        v.grad = None
+    logits = unet_forward(sd, images, masks)
+    loss = simple_loss(logits, target)
+    loss.backward()
+    grads = {k: sd[k].grad.detach().clone() for k in names}
+    sgd_nesterov_([sd[k] for k in names], [grads[k] for k in names], bufs, lr, momentum,
+                  weight_decay)
+    return loss.detach(), logits.detach(), grads
+
+
+def leaf_state_dict(sd):
+    return {k: v.clone().requires_grad_(True) for k, v in sd.items()}

@@ -1,0 +1,405 @@
+"""Per-kernel parity (-m gpu): every C-ABI entry point against the oracle's stock-torch
+CPU ops on seeded inputs, and against the reference-generated fixtures in
+tests/golden/ops_small.npz.  Tolerances are relative to the tensor's max magnitude:
+fp32 with a different summation order, never looser than 5e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def to_nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def from_nhwc(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def check(a, b, tol, what=""):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# --------------------------------------------------------------------------- layout / pack
+def test_layout_roundtrip(ua):
+    x = rnd(2, 3, 10, 14, seed=1)
+    y = ua.ops.nchw_to_nhwc(x.to(DEV))
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    z = ua.ops.nhwc_to_nchw(y)
+    assert torch.equal(z.cpu(), x)
+
+
+def test_pack_weights(ua):
+    w = rnd(64, 32, 3, 3, seed=2)
+    wf, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    assert torch.equal(wf.cpu(), w.permute(2, 3, 1, 0).reshape(9, 32, 64))
+    assert torch.equal(wd.cpu(), w.permute(2, 3, 0, 1).reshape(9, 64, 32))
+
+
+# --------------------------------------------------------------------------- conv forward
+CONV_SHAPES = [
+    # N, H, W, C0, C1, Cout, stride
+    (2, 12, 20, 32, 0, 32, 1),
+    (2, 12, 20, 32, 0, 64, 2),
+    (1, 16, 16, 64, 32, 128, 1),
+    (2, 8, 8, 128, 0, 128, 1),
+    (1, 24, 40, 3, 0, 32, 1),
+    (3, 10, 6, 3, 0, 64, 1),
+    (2, 64, 64, 64, 0, 64, 1),
+    (1, 16, 16, 512, 0, 512, 1),
+    (2, 2, 2, 512, 0, 512, 1),
+    (1, 4, 4, 512, 512, 512, 1),
+    (2, 34, 18, 32, 0, 32, 2),
+    (1, 128, 128, 64, 32, 32, 1),
+    (1, 32, 32, 256, 128, 128, 1),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fwd(ua, shape):
+    N, H, W, C0, C1, Cout, s = shape
+    x = rnd(N, C0 + C1, H, W, seed=3)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=4, scale=0.1)
+    b = rnd(Cout, seed=5)
+    ref = F.conv2d(x, w, b, stride=s, padding=1)
+    wf, _ = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    x0 = to_nhwc(x[:, :C0])
+    x1 = to_nhwc(x[:, C0:]) if C1 else None
+    y = ua.ops.conv3x3_fwd(x0, x1, wf, b.to(DEV), s)
+    check(from_nhwc(y), ref, 2e-5, f"conv fwd {shape}")
+
+
+# --------------------------------------------------------------------------- conv dgrad
+DGRAD_SHAPES = [
+    # N, H, W, Cin, Cout, stride, (ci_offset, ccols)
+    (2, 12, 20, 32, 32, 1, (0, 32)),
+    (2, 12, 20, 64, 32, 1, (32, 32)),
+    (1, 16, 16, 96, 64, 1, (0, 64)),
+    (2, 16, 24, 32, 64, 2, (0, 32)),
+    (1, 8, 8, 128, 256, 2, (0, 128)),
+    (2, 4, 4, 512, 512, 2, (0, 512)),
+    (1, 32, 32, 384, 128, 1, (256, 128)),
+    (1, 64, 64, 64, 64, 1, (0, 64)),
+]
+
+
+@pytest.mark.parametrize("shape", DGRAD_SHAPES)
+def test_conv3x3_bwd_data(ua, shape):
+    N, H, W, Cin, Cout, s, (off, cc) = shape
+    x = rnd(N, Cin, H, W, seed=6).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=7, scale=0.1)
+    y = F.conv2d(x, w, None, stride=s, padding=1)
+    gy = rnd(*y.shape, seed=8)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    dx = ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, off, cc, H, W, s)
+    check(from_nhwc(dx), gx[:, off:off + cc], 2e-5, f"dgrad {shape}")
+    # accumulate flag adds into the existing tensor
+    base = rnd(N, cc, H, W, seed=9)
+    buf = to_nhwc(base)
+    ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, off, cc, H, W, s, out=buf, accumulate=True)
+    check(from_nhwc(buf), gx[:, off:off + cc] + base, 2e-5, f"dgrad acc {shape}")
+
+
+# --------------------------------------------------------------------------- conv wgrad
+WGRAD_SHAPES = [
+    # N, H, W, Cx, ci_offset, Cin_total, Cout, stride
+    (2, 12, 20, 32, 0, 32, 32, 1),
+    (2, 12, 40, 32, 0, 32, 32, 1),
+    (2, 16, 24, 32, 0, 32, 64, 2),
+    (1, 16, 16, 64, 0, 64, 64, 1),
+    (2, 8, 8, 128, 0, 128, 128, 1),
+    (2, 8, 8, 64, 0, 64, 128, 2),
+    (1, 32, 32, 64, 32, 96, 32, 1),
+    (1, 24, 40, 3, 0, 3, 32, 1),
+    (2, 2, 2, 512, 0, 512, 512, 1),
+    (2, 4, 4, 512, 0, 512, 512, 2),
+    (1, 64, 64, 64, 0, 64, 64, 1),
+    (3, 34, 70, 32, 0, 32, 32, 1),
+]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_conv3x3_bwd_weight(ua, shape):
+    N, H, W, Cx, off, Ct, Cout, s = shape
+    x = rnd(N, Ct, H, W, seed=10)
+    w = rnd(Cout, Ct, 3, 3, seed=11, scale=0.1).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=s, padding=1)
+    gy = rnd(*y.shape, seed=12)
+    gw, gb = torch.autograd.grad(y, (w, b), gy)
+    dw = torch.full((Cout, Ct, 3, 3), 7.0, device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    ua.ops.conv3x3_bwd_weight(to_nhwc(x[:, off:off + Cx]), to_nhwc(gy), dw, off, s, db=db)
+    check(dw[:, off:off + Cx].cpu(), gw[:, off:off + Cx], 3e-5, f"wgrad {shape}")
+    check(db.cpu(), gb, 3e-5, f"bias grad {shape}")
+    if off > 0:  # untouched columns keep their value
+        assert torch.all(dw[:, :off] == 7.0)
+
+
+# --------------------------------------------------------------------------- instance norm
+IN_SHAPES = [(2, 12, 20, 32), (2, 16, 16, 64), (1, 8, 8, 512), (2, 2, 2, 512), (1, 64, 64, 32),
+             (2, 33, 7, 128), (1, 128, 128, 32)]
+
+
+@pytest.mark.parametrize("shape", IN_SHAPES)
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_instnorm_lrelu_drop(ua, shape, with_mask):
+    N, H, W, C = shape
+    y = (rnd(N, C, H, W, seed=13) * 2.0 + 3.0).requires_grad_(True)   # large mean: cancellation test
+    gamma = (1 + 0.1 * rnd(C, seed=14)).requires_grad_(True)
+    beta = (0.1 * rnd(C, seed=15)).requires_grad_(True)
+    mask = None
+    if with_mask:
+        g = torch.Generator().manual_seed(16)
+        mask = torch.empty(N, C).bernoulli_(0.7, generator=g).div_(0.7)
+    z = F.leaky_relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    a_ref = z * mask.view(N, C, 1, 1) if with_mask else z
+    ga = rnd(N, C, H, W, seed=17)
+    gy_ref, gg_ref, gb_ref = torch.autograd.grad(a_ref, (y, gamma, beta), ga)
+
+    yd = to_nhwc(y.detach())
+    st = ua.ops.instnorm_stats(yd, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5)
+    mean_ref = y.detach().mean(dim=(2, 3))
+    var_ref = y.detach().var(dim=(2, 3), unbiased=False)
+    check(st[0].cpu(), mean_ref, 1e-6, "mean")
+    check(st[1].cpu(), 1.0 / torch.sqrt(var_ref + 1e-5), 2e-6, "rstd")
+    md = mask.to(DEV) if with_mask else None
+    a = ua.ops.instnorm_lrelu_drop_fwd(yd, st[2], st[3], md, 0.01)
+    check(from_nhwc(a), a_ref.detach(), 1e-5, "IN apply")
+    dg = torch.empty(C, device=DEV)
+    dbt = torch.empty(C, device=DEV)
+    dbias = torch.empty(C, device=DEV)
+    dy = ua.ops.instnorm_lrelu_drop_bwd(to_nhwc(ga), yd, st[0], st[1], gamma.detach().to(DEV),
+                                        beta.detach().to(DEV), md, 0.01, dg, dbt, dbias)
+    check(from_nhwc(dy), gy_ref, 5e-5, "IN bwd dy")
+    check(dg.cpu(), gg_ref, 5e-5, "dgamma")
+    check(dbt.cpu(), gb_ref, 5e-5, "dbeta")
+    # conv-bias gradient = sum of dy: mathematically 0, numerically tiny
+    assert dbias.abs().max().item() <= 1e-3 * max(1.0, gy_ref.abs().sum().item() / C)
+
+
+# --------------------------------------------------------------------------- upsample
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (1, 1, 1, 32), (2, 2, 2, 512), (1, 16, 16, 32),
+                                   (1, 5, 3, 128)])
+def test_upsample2x(ua, shape):
+    N, h, w, C = shape
+    x = rnd(N, C, h, w, seed=18).requires_grad_(True)
+    y = F.interpolate(x, size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
+    gy = rnd(*y.shape, seed=19)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    yd = ua.ops.upsample2x_fwd(to_nhwc(x.detach()))
+    check(from_nhwc(yd), y.detach(), 1e-6, "upsample fwd")
+    gxd = ua.ops.upsample2x_bwd(to_nhwc(gy))
+    check(from_nhwc(gxd), gx, 1e-6, "upsample bwd")
+    base = rnd(N, C, h, w, seed=20)
+    buf = to_nhwc(base)
+    ua.ops.upsample2x_bwd(to_nhwc(gy), out=buf, accumulate=True)
+    check(from_nhwc(buf), gx + base, 1e-6, "upsample bwd acc")
+
+
+# --------------------------------------------------------------------------- head
+@pytest.mark.parametrize("shape", [(2, 12, 20), (1, 64, 64), (3, 17, 9), (2, 128, 128)])
+def test_head1x1(ua, shape):
+    N, H, W = shape
+    a = rnd(N, 32, H, W, seed=21).requires_grad_(True)
+    w = rnd(3, 32, 1, 1, seed=22, scale=0.3).requires_grad_(True)
+    b = rnd(3, seed=23).requires_grad_(True)
+    y = F.conv2d(a, w, b)
+    gy = rnd(*y.shape, seed=24)
+    ga, gw, gb = torch.autograd.grad(y, (a, w, b), gy)
+    ad = to_nhwc(a.detach())
+    wd = w.detach().view(3, 32).to(DEV)
+    logits = ua.ops.head1x1_fwd(ad, wd, b.detach().to(DEV))
+    check(logits.cpu(), y.detach(), 1e-5, "head fwd")
+    dw = torch.empty(3, 32, device=DEV)
+    db = torch.empty(3, device=DEV)
+    da = ua.ops.head1x1_bwd(ad, gy.to(DEV), wd, dw, db)
+    check(from_nhwc(da), ga, 1e-5, "head da")
+    check(dw.cpu(), gw.view(3, 32), 2e-5, "head dw")
+    check(db.cpu(), gb, 2e-5, "head db")
+
+
+# --------------------------------------------------------------------------- loss
+def _loss_case(seed, N, H, W, drop_class=None):
+    g = torch.Generator().manual_seed(seed)
+    lg = torch.randn(N, 3, H, W, generator=g) * 2.0
+    tg = torch.randint(0, 3, (N, H, W), generator=g)
+    if drop_class is not None:
+        tg[tg == drop_class] = 0
+    tg[:, :2, :] = 255
+    tg[:, :, -1:] = 255
+    return lg, tg
+
+
+@pytest.mark.parametrize("case", [(1, 2, 24, 40, None), (2, 3, 16, 16, 2), (3, 1, 64, 64, 1),
+                                  (4, 2, 128, 128, None)])
+def test_loss_vs_oracle(ua, case):
+    seed, N, H, W, drop = case
+    lg, tg = _loss_case(seed, N, H, W, drop)
+    lgr = lg.clone().requires_grad_(True)
+    ref = O.simple_loss(lgr, tg)
+    ref.backward()
+    out, dl = ua.ops.dice_wce_loss_fwd_bwd(lg.to(DEV), tg.to(DEV), 1e-5, 1.0, 1.0, 255, True)
+    assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item())
+    check(out[3:6].cpu(), O.class_weights(tg), 1e-6, "class weights")
+    check(dl.cpu(), lgr.grad, 2e-5, "dlogits")
+
+
+def test_loss_all_ignored_image(ua):
+    """An image made only of 255 pixels contributes zero counts and dice = 1 (smooth/smooth)."""
+    lg, tg = _loss_case(7, 2, 16, 16, None)
+    tg[1] = 255
+    lgr = lg.clone().requires_grad_(True)
+    ref = O.simple_loss(lgr, tg)
+    ref.backward()
+    out, dl = ua.ops.dice_wce_loss_fwd_bwd(lg.to(DEV), tg.to(DEV), 1e-5, 1.0, 1.0, 255, True)
+    assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item())
+    check(dl.cpu(), lgr.grad, 2e-5, "dlogits")
+    assert torch.all(dl[1] == 0)
+
+
+def test_loss_golden(ua, golden):
+    g = golden("ops_small")
+    lg, tg = torch.from_numpy(g["loss_logits"]), torch.from_numpy(g["loss_target"])
+    out, dl = ua.ops.dice_wce_loss_fwd_bwd(lg.to(DEV), tg.to(DEV), 1e-5, 1.0, 1.0, 255, True)
+    assert abs(out[0].item() - float(g["loss_value"])) <= 2e-6 * abs(float(g["loss_value"]))
+    check(dl.cpu(), torch.from_numpy(g["loss_dlogits"]), 2e-5, "golden dlogits")
+    cw = torch.from_numpy(g["loss2_weights"]).to(DEV)
+    out2, dl2 = ua.ops.dice_wce_loss_fwd_bwd(lg.to(DEV), tg.to(DEV), 1e-5, 1.0, 1.0, 255, False,
+                                             class_weights=cw)
+    assert abs(out2[0].item() - float(g["loss2_value"])) <= 2e-6 * abs(float(g["loss2_value"]))
+    check(dl2.cpu(), torch.from_numpy(g["loss2_dlogits"]), 2e-5, "golden dlogits (static w)")
+
+
+def test_simple_loss_module(ua, golden):
+    g = golden("ops_small")
+    lg = torch.from_numpy(g["loss_logits"]).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(g["loss_target"]).to(DEV)
+    loss = ua.SimpleLoss()(lg, tg)
+    assert loss.dim() == 0 and loss.dtype == torch.float32
+    loss.backward()
+    assert abs(loss.item() - float(g["loss_value"])) <= 2e-6 * abs(float(g["loss_value"]))
+    check(lg.grad.cpu(), torch.from_numpy(g["loss_dlogits"]), 2e-5, "module dlogits")
+
+
+# --------------------------------------------------------------------------- SGD
+def test_sgd_golden(ua, golden):
+    g = golden("ops_small")
+    p = torch.from_numpy(g["sgd_p0"]).to(DEV)
+    buf = torch.zeros_like(p)
+    for s in range(3):
+        gr = torch.from_numpy(g["sgd_grads"][s]).to(DEV)
+        ua.ops.sgd_nesterov_step(p, gr, buf, 0.005, 0.99, 1e-4, s == 0)
+        check(p.cpu(), torch.from_numpy(g["sgd_traj"][s]), 1e-6, f"sgd step {s}")
+
+
+def test_sgd_odd_length(ua):
+    n = 1003
+    p0, g0 = rnd(n, seed=30), rnd(n, seed=31)
+    ps, bufs = [p0.clone()], [None]
+    O.sgd_nesterov_(ps, [g0], bufs)
+    O.sgd_nesterov_(ps, [g0 * 0.5], bufs)
+    pd = torch.zeros(1004, device=DEV)[:n]
+    pd.copy_(p0)
+    bd = torch.zeros(1004, device=DEV)[:n]
+    gd = torch.zeros(1004, device=DEV)[:n]
+    gd.copy_(g0)
+    ua.ops.sgd_nesterov_step(pd, gd, bd, 0.005, 0.99, 1e-4, True)
+    gd.mul_(0.5)
+    ua.ops.sgd_nesterov_step(pd, gd, bd, 0.005, 0.99, 1e-4, False)
+    check(pd.cpu(), ps[0], 1e-6, "sgd odd")
+
+
+# --------------------------------------------------------------------------- composed blocks (golden)
+def _run_block(ua, x0, x1, p, idx, stride, masks, grads_out=None):
+    """conv -> IN stats -> apply for the two convs of a reference ConvBlock state_dict `p`."""
+    recs = []
+    cur0, cur1 = x0, x1
+    for k, (ci, ni) in enumerate(idx):
+        w = p[f"block.{ci}.weight"].to(DEV)
+        wf, wd = ua.ops.pack_conv3x3_weights(w)
+        y = ua.ops.conv3x3_fwd(cur0, cur1, wf, p[f"block.{ci}.bias"].to(DEV), stride if k == 0 else 1)
+        gm, bt = p[f"block.{ni}.weight"].to(DEV), p[f"block.{ni}.bias"].to(DEV)
+        st = ua.ops.instnorm_stats(y, gm, bt, 1e-5)
+        m = masks[k].to(DEV) if masks is not None else None
+        a = ua.ops.instnorm_lrelu_drop_fwd(y, st[2], st[3], m, 0.01)
+        recs.append(dict(x0=cur0, x1=cur1, y=y, st=st, m=m, a=a, wd=wd, gm=gm, bt=bt, ci=ci, ni=ni,
+                         stride=stride if k == 0 else 1, w=w))
+        cur0, cur1 = a, None
+    return recs
+
+
+def _block_backward(ua, recs, g):
+    grads = {}
+    dx1 = None
+    for r in reversed(recs):
+        C = r["y"].shape[3]
+        dg, dbt, dbias = (torch.empty(C, device=DEV) for _ in range(3))
+        dy = ua.ops.instnorm_lrelu_drop_bwd(g, r["y"], r["st"][0], r["st"][1], r["gm"], r["bt"],
+                                            r["m"], 0.01, dg, dbt, dbias)
+        dw = torch.empty_like(r["w"])
+        ua.ops.conv3x3_bwd_weight(r["x0"], dy, dw, 0, r["stride"])
+        N, H, W, C0 = r["x0"].shape
+        if r["x1"] is not None:
+            ua.ops.conv3x3_bwd_weight(r["x1"], dy, dw, C0, r["stride"])
+            dx1 = ua.ops.conv3x3_bwd_data(dy, r["wd"], C0, r["x1"].shape[3], H, W, r["stride"])
+        g = ua.ops.conv3x3_bwd_data(dy, r["wd"], 0, C0, H, W, r["stride"])
+        grads[f"block.{r['ci']}.weight"] = dw
+        grads[f"block.{r['ci']}.bias"] = dbias
+        grads[f"block.{r['ni']}.weight"] = dg
+        grads[f"block.{r['ni']}.bias"] = dbt
+    return g, dx1, grads
+
+
+def test_convblock_golden(ua, golden):
+    """Reference ConvBlock(32->64, stride 2, dropout 0.2) in train mode, forward + backward."""
+    g = golden("ops_small")
+    p = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cb_p_")}
+    masks = [torch.from_numpy(g["cb_mask0"]), torch.from_numpy(g["cb_mask1"])]
+    recs = _run_block(ua, to_nhwc(torch.from_numpy(g["cb_x"])), None, p, [(0, 1), (4, 5)], 2, masks)
+    check(from_nhwc(recs[-1]["a"]), torch.from_numpy(g["cb_y"]), 2e-5, "ConvBlock fwd")
+    gx, _, grads = _block_backward(ua, recs, to_nhwc(torch.from_numpy(g["cb_gy"])))
+    check(from_nhwc(gx), torch.from_numpy(g["cb_gx"]), 5e-5, "ConvBlock gx")
+    for k, v in grads.items():
+        ref = torch.from_numpy(g["cb_g_" + k])
+        if k.endswith("bias") and ref.abs().max() < 1e-4:   # conv bias under IN: ~0 +- rounding
+            assert (v.cpu() - ref).abs().max() < 1e-4
+        else:
+            check(v.cpu(), ref, 5e-5, f"ConvBlock grad {k}")
+
+
+def test_upblock_golden(ua, golden):
+    """Reference UpBlock(64 up + 32 skip -> 32), eval mode, forward + backward."""
+    g = golden("ops_small")
+    p = {k[16:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ub_p_conv_block.")}
+    up = ua.ops.upsample2x_fwd(to_nhwc(torch.from_numpy(g["ub_x"])))
+    recs = _run_block(ua, up, to_nhwc(torch.from_numpy(g["ub_skip"])), p, [(0, 1), (3, 4)], 1, None)
+    check(from_nhwc(recs[-1]["a"]), torch.from_numpy(g["ub_y"]), 2e-5, "UpBlock fwd")
+    g_up, g_skip, grads = _block_backward(ua, recs, to_nhwc(torch.from_numpy(g["ub_gy"])))
+    gx = ua.ops.upsample2x_bwd(g_up)
+    check(from_nhwc(gx), torch.from_numpy(g["ub_gx"]), 5e-5, "UpBlock gx")
+    check(from_nhwc(g_skip), torch.from_numpy(g["ub_gskip"]), 5e-5, "UpBlock gskip")
+    for k, v in grads.items():
+        ref = torch.from_numpy(g["ub_g_conv_block." + k])
+        if k.endswith("bias") and ref.abs().max() < 1e-4:
+            assert (v.cpu() - ref).abs().max() < 1e-4
+        else:
+            check(v.cpu(), ref, 5e-5, f"UpBlock grad {k}")

@@ -1,0 +1,96 @@
+"""ctypes binding of libunet_hip.so (the C ABI declared in include/unet_hip.h).
+
+The library is built in-tree by `build()` (hipcc, --offload-arch=gfx950) and is
+the ONLY compute path of this package: there is no CPU or eager-PyTorch
+fallback.  `lib()` raises if the shared object is missing.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c = ctypes
+_p = _c.c_void_p
+_i = _c.c_int
+_f = _c.c_float
+_sz = _c.c_size_t
+_i64 = _c.c_int64
+
+# name -> (restype, argtypes); mirrors include/unet_hip.h one to one
+SIGNATURES = {
+    "unet_last_error": (_c.c_char_p, []),
+    "unet_abi_version": (_i, []),
+    "unet_device_count": (_i, []),
+    "unet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "unet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "unet_pack_conv3x3_weights": (_i, [_p, _p, _p, _i, _i, _p]),
+    "unet_conv3x3_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_bwd_data": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "unet_conv3x3_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),
+    "unet_instnorm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "unet_instnorm_stats": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _p]),
+    "unet_instnorm_lrelu_drop_fwd": (_i, [_p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),
+    "unet_instnorm_lrelu_drop_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _sz,
+                                          _i, _i, _i, _p]),
+    "unet_upsample2x_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "unet_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "unet_head1x1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "unet_head1x1_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "unet_head1x1_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_dice_wce_loss_workspace_bytes": (_sz, [_i, _i, _i]),
+    "unet_dice_wce_loss_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _f, _f, _f, _i, _i,
+                                        _p, _f, _p]),
+    "unet_sgd_nesterov_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
+    "unet_add_inplace": (_i, [_p, _p, _i64, _p]),
+}
+
+_lib = None
+
+
+class UNetHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libunet_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    proc = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout)
+        print(proc.stderr)
+    if proc.returncode != 0:
+        raise UNetHipError("building libunet_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UNetHipError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU / eager fallback for the HIP path)")
+    # torch must be imported first so its bundled libamdhip64.so.7 (same soname) is the
+    # one HIP runtime of the process: streams and device pointers are then shared.
+    import torch  # noqa: F401
+    handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if handle.unet_abi_version() != 1:
+        raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().unet_last_error()
+        raise UNetHipError(f"libunet_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,77 @@
+// common.h — shared device/host helpers for the gfx950 kernels of libunet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/unet_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error reporting -------------------------------------------------------
+void unet_set_error(const char* fmt, ...);
+
+#define UNET_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      unet_set_error(__VA_ARGS__);     \
+      return UNET_E_INVALID;           \
+    }                                  \
+  } while (0)
+
+#define UNET_CHECK_LAUNCH(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      unet_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return UNET_E_LAUNCH;                                                  \
+    }                                                                        \
+  } while (0)
+
+#define UNET_HIP_CALL(expr)                                                    \
+  do {                                                                         \
+    hipError_t e__ = (expr);                                                   \
+    if (e__ != hipSuccess) {                                                   \
+      unet_set_error("%s failed: %s", #expr, hipGetErrorString(e__));          \
+      return UNET_E_LAUNCH;                                                    \
+    }                                                                          \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }
+
+// ---- device helpers --------------------------------------------------------
+#ifdef __HIPCC__
+
+// Blocks b and b+8 share an XCD (round-robin dispatch over the 8 XCDs); remap so
+// each XCD walks a contiguous range of tile ids (private L2 reuse of halo rows
+// and weight panels).  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = orig & 7, idx = orig >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Chan/Welford merge of (count, mean, M2) pairs.
+__device__ __forceinline__ void wf_merge(float& n, float& mean, float& m2, float nb, float mb,
+                                         float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb;
+  const float d = mb - mean;
+  const float f = nb / nt;
+  mean += d * f;
+  m2 += m2b + d * d * n * f;
+  n = nt;
+}
+
+#endif  // __HIPCC__

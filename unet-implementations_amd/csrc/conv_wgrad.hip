@@ -1,0 +1,412 @@
+// conv_wgrad.hip — 3x3 convolution weight gradient on the fp32 matrix cores.
+//
+// dW[tap][ci][co] = sum over output pixels p of x[p @ tap][ci] * dy[p][co].
+// One workgroup = 9 waves, wave w owns tap w; the block owns a (CI_T x CO_T)
+// channel tile and a contiguous range of output-row segments of S pixels.  Per
+// segment the 3-row input halo patch [3][(S-1)*stride+3][CI_T] and the dy
+// segment [S][CO_T] are register-staged into double-buffered LDS once and
+// shared by all 9 taps (each input element is fetched ~1.1x instead of 9x).
+// MFMA operands: A = patch^T (rows = ci, k = pixel pair), B = dy (k = pixel
+// pair, cols = co); both are plain conflict-free ds_read_b32 (lanes run along
+// the contiguous channel axis).  Partial sums per pixel-range split are written
+// as slabs and reduced (fixed order => run-to-run deterministic) by
+// wgrad_reduce_kernel, which also scatters into the OIHW gradient.
+//
+// Replaces the weight-gradient half of aten::convolution_backward reached from
+// loss.backward() (Our_UNet/src/train.py:663).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+  const float* x;   // [N][H][W][Cx]
+  const float* dy;  // [N][Ho][Wo][Cout]
+  float* partial;   // [split][9][Cx][Cout]
+  int Cx, Cout;
+  int N, H, W, Ho, Wo;
+  int segs_per_row, total_segs, segs_per_block, split;
+  int ci_tiles, co_tiles;
+};
+
+template <int CI_T, int CO_T, int S, int STRIDE>
+__global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int PW = (S - 1) * STRIDE + 3;
+  constexpr int PATCH = 3 * PW * CI_T;
+  constexpr int DYT = S * CO_T;
+  constexpr int STAGE = PATCH + DYT;
+  constexpr int NP4 = PATCH / 4, ND4 = DYT / 4;
+  constexpr int NL = (NP4 + ND4 + 575) / 576;
+  constexpr int TI = CI_T / 32, TJ = CO_T / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tap_u = wave / 3, tap_v = wave - tap_u * 3;
+
+  int bid = blockIdx.x;
+  const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+  const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+  const int sp = bid;
+  const int ci0 = ci_t * CI_T, co0 = co_t * CO_T;
+  const int g_begin = sp * p.segs_per_block;
+  const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
+
+  // loader slots: LDS float offset == 4*idx for both regions
+  int s_kind[NL], s_a[NL], s_b[NL], s_c[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int idx = tid + 576 * k;
+    if (idx < NP4) {
+      const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
+      const int prow = pix / PW, pcol = pix - prow * PW;
+      s_kind[k] = 0; s_a[k] = prow - 1; s_b[k] = pcol - 1; s_c[k] = ci0 + seg * 4;
+    } else if (idx < NP4 + ND4) {
+      const int d = idx - NP4;
+      const int dpix = d / (CO_T / 4), seg = d - dpix * (CO_T / 4);
+      s_kind[k] = 1; s_a[k] = 0; s_b[k] = dpix; s_c[k] = co0 + seg * 4;
+    } else {
+      s_kind[k] = 2; s_a[k] = s_b[k] = s_c[k] = 0;
+    }
+  }
+
+  f32x4 rg[NL];
+  auto load_stage = [&](int g) {
+    const int xs = g % p.segs_per_row;
+    const int r = g / p.segs_per_row;
+    const int oy = r % p.Ho;
+    const int n = r / p.Ho;
+    const int x0 = xs * S;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (s_kind[k] == 0) {
+        const int iy = oy * STRIDE + s_a[k], ix = x0 * STRIDE + s_b[k];
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          v = *reinterpret_cast<const f32x4*>(
+              p.x + ((size_t)(n * p.H + iy) * p.W + ix) * p.Cx + s_c[k]);
+      } else if (s_kind[k] == 1) {
+        const int ox = x0 + s_b[k];
+        if (ox < p.Wo)
+          v = *reinterpret_cast<const f32x4*>(
+              p.dy + ((size_t)(n * p.Ho + oy) * p.Wo + ox) * p.Cout + s_c[k]);
+      }
+      rg[k] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* base = smem + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+      if (s_kind[k] != 2) *reinterpret_cast<f32x4*>(base + 4 * (tid + 576 * k)) = rg[k];
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (g_begin < g_end) {
+    load_stage(g_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int g = g_begin; g < g_end; ++g) {
+      const int buf = (g - g_begin) & 1;
+      const bool more = (g + 1 < g_end);
+      if (more) load_stage(g + 1);
+      const float* P = smem + buf * STAGE + (tap_u * PW + tap_v) * CI_T;
+      const float* D = smem + buf * STAGE + PATCH;
+#pragma unroll 4
+      for (int xx = 0; xx < S; xx += 2) {
+        float a[TI], b[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) a[i] = P[((xx + lh) * STRIDE) * CI_T + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) b[j] = D[(xx + lh) * CO_T + j * 32 + li];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  float* out = p.partial + ((size_t)(sp * 9 + wave) * p.Cx) * p.Cout;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = ci0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(size_t)row * p.Cout + co0 + j * 32 + li] = acc[i][j][r];
+      }
+}
+
+// dw_oihw[co][ci_off+ci][tap] = sum_s partial[s][tap][ci][co]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ dw, int split,
+                                                           int Cx, int Cout, int ci_off,
+                                                           int Cin_total) {
+  // tile: 32 co x 8 ci per block, all 9 taps; LDS transpose so both sides coalesce-ish
+  __shared__ float tile[9][8][33];
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 8;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;  // r in 0..7
+  const size_t slab = (size_t)9 * Cx * Cout;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* src = partial + ((size_t)t * Cx + ci0 + r) * Cout + co0 + c;
+    float s = 0.f;
+    for (int k = 0; k < split; ++k) s += src[(size_t)k * slab];
+    tile[t][r][c] = s;
+  }
+  __syncthreads();
+  // write: for each co (32) a run of 8 ci * 9 taps = 72 contiguous floats
+  for (int i = threadIdx.x; i < 32 * 72; i += 256) {
+    const int co = i / 72, rem = i - co * 72;
+    const int ci = rem / 9, t = rem - ci * 9;
+    dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[t][ci][co];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RGB stem weight gradient (Cx = 3): im2col rows (K = 27 -> 32) gathered into
+// LDS; out[k][co] accumulates over pixels; one 32x32 MFMA block per co tile.
+// ---------------------------------------------------------------------------
+constexpr int SW_PIX = 128;  // pixels per stage
+constexpr int SW_LDK = 32;
+
+__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ dy,
+                                                              float* __restrict__ partial, int N,
+                                                              int H, int W, int Cout,
+                                                              int stages_per_block,
+                                                              long long total_stages) {
+  __shared__ float A[SW_PIX * SW_LDK];  // [pix][k]
+  __shared__ float D[SW_PIX * 32];      // [pix][co]
+  __shared__ float R[4][32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int HW = H * W;
+  const long long M = (long long)N * HW;
+  const int co0 = blockIdx.y * 32;
+  const long long st_begin = (long long)blockIdx.x * stages_per_block;
+  const long long st_end = min(st_begin + (long long)stages_per_block, total_stages);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (long long st = st_begin; st < st_end; ++st) {
+    const long long m0 = st * SW_PIX;
+    for (int it = tid; it < SW_PIX * 9; it += 256) {
+      const int pix = it / 9, t = it - pix * 9;
+      const long long m = m0 + pix;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (m < M) {
+        const int n = (int)(m / HW);
+        const int r = (int)(m - (long long)n * HW);
+        const int yy = r / W + t / 3 - 1, xx = r % W + t % 3 - 1;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          const float* s = x + ((size_t)n * HW + (size_t)yy * W + xx) * 3;
+          v0 = s[0]; v1 = s[1]; v2 = s[2];
+        }
+      }
+      float* d = A + pix * SW_LDK + t * 3;
+      d[0] = v0; d[1] = v1; d[2] = v2;
+    }
+    for (int i = tid; i < SW_PIX * 5; i += 256) A[(i / 5) * SW_LDK + 27 + i % 5] = 0.f;
+    for (int i = tid; i < SW_PIX * 8; i += 256) {
+      const int pix = i >> 3, seg = i & 7;
+      const long long m = m0 + pix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)m * Cout + co0 + seg * 4);
+      *reinterpret_cast<f32x4*>(D + pix * 32 + seg * 4) = v;
+    }
+    __syncthreads();
+    // wave handles pixels [wave*32, wave*32+32)
+#pragma unroll 4
+    for (int q = 0; q < 32; q += 2) {
+      const int pix = wave * 32 + q + lh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[pix * SW_LDK + li], D[pix * 32 + li], acc, 0, 0,
+                                                 0);
+    }
+    __syncthreads();
+  }
+  // cross-wave reduce in fixed order
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    R[wave][row * 32 + li] = acc[r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 27 * 32; i += 256) {
+    const float s = (R[0][i] + R[1][i]) + (R[2][i] + R[3][i]);
+    const int k = i >> 5, c = i & 31;
+    partial[((size_t)blockIdx.x * 27 + k) * Cout + co0 + c] = s;
+  }
+}
+
+// stem reduce: dw_oihw[co][ci][tap] (Cin_total = 3) = sum_b partial[b][tap*3+ci][co]
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                         int nblocks, int Cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 27 * Cout) return;
+  const int k = i / Cout, co = i - k * Cout;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 27 + k) * Cout + co];
+  const int t = k / 3, ci = k - t * 3;
+  dw[((size_t)co * 3 + ci) * 9 + t] = s;
+}
+
+struct WgradPlan {
+  int ci_t, co_t, S, split, segs_per_row, total_segs, segs_per_block;
+  size_t ws_floats;
+  bool stem;
+  int stem_blocks, stem_spb;
+  long long stem_stages;
+};
+
+int stem_grid(long long stages) { return (int)(stages < 1024 ? stages : 1024); }
+
+WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
+  WgradPlan pl{};
+  if (Cx == 3) {
+    pl.stem = true;
+    const long long M = (long long)N * H * W;
+    pl.stem_stages = ceil_div64(M, SW_PIX);
+    pl.stem_blocks = stem_grid(pl.stem_stages);
+    pl.stem_spb = (int)ceil_div64(pl.stem_stages, pl.stem_blocks);
+    pl.stem_blocks = (int)ceil_div64(pl.stem_stages, pl.stem_spb);
+    pl.ws_floats = (size_t)pl.stem_blocks * 27 * Cout;
+    return pl;
+  }
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  pl.ci_t = (Cx % 64 == 0) ? 64 : 32;
+  pl.co_t = (Cout % 64 == 0) ? 64 : 32;
+  if (pl.ci_t == 64 && pl.co_t == 32) pl.ci_t = 32;  // instantiated: 32x32, 32x64, 64x64
+  pl.S = (stride == 2 || Wo <= 16) ? 16 : 32;
+  pl.segs_per_row = ceil_div(Wo, pl.S);
+  pl.total_segs = N * Ho * pl.segs_per_row;
+  const int tiles = (Cx / pl.ci_t) * (Cout / pl.co_t);
+  // aim for ~512 workgroups (2 per CU), at least 4 segments per block
+  int split = ceil_div(512, tiles);
+  const int max_split = ceil_div(pl.total_segs, 4);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  pl.segs_per_block = ceil_div(pl.total_segs, split);
+  pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
+  pl.ws_floats = (size_t)pl.split * 9 * Cx * Cout;
+  return pl;
+}
+
+template <int CI_T, int CO_T, int S, int STRIDE>
+int launch_wgrad(const WgradParams& p, hipStream_t stream) {
+  constexpr int PW = (S - 1) * STRIDE + 3;
+  constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
+  static bool attr_set = false;
+  auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(576), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_wgrad");
+  return UNET_OK;
+}
+
+__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, long long M,
+                                 int C) {
+  // one block per 32 channels; threads stride over pixels; fixed-order tree => deterministic
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int r = threadIdx.x >> 5;
+  float s = 0.f;
+  for (long long m = r; m < M; m += 8) s += dy[(size_t)m * C + c];
+  red[r][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (r == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    db[c] = t;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, int Cx, int Cout,
+                                                          int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cx <= 0 || Cout <= 0) return 0;
+  return make_plan(N, H, W, Cx, Cout, stride).ws_floats * sizeof(float);
+}
+
+extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, float* dw_oihw,
+                                       int ci_offset, int Cin_total, float* db, void* workspace,
+                                       size_t workspace_bytes, int N, int H, int W, int Cout,
+                                       int stride, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(x && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
+  UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
+  UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
+  UNET_REQUIRE(Cx == 3 || (Cx > 0 && Cx % 32 == 0), "conv3x3_bwd_weight: Cx %d unsupported", Cx);
+  UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_bwd_weight: bad ci slice");
+  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride);
+  if (workspace_bytes < pl.ws_floats * sizeof(float)) {
+    unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes,
+                   pl.ws_floats * sizeof(float));
+    return UNET_E_WORKSPACE;
+  }
+  float* ws = reinterpret_cast<float*>(workspace);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (pl.stem) {
+    UNET_REQUIRE(stride == 1 && Cin_total == 3 && ci_offset == 0, "conv3x3_bwd_weight: stem shape");
+    dim3 grid(pl.stem_blocks, Cout / 32);
+    hipLaunchKernelGGL(conv_stem_wgrad_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H, W,
+                       Cout, pl.stem_spb, pl.stem_stages);
+    UNET_CHECK_LAUNCH("conv_stem_wgrad");
+    const int n = 27 * Cout;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, ws,
+                       dw_oihw, pl.stem_blocks, Cout);
+    UNET_CHECK_LAUNCH("stem_wgrad_reduce");
+  } else {
+    WgradParams p{};
+    p.x = x; p.dy = dy; p.partial = ws; p.Cx = Cx; p.Cout = Cout;
+    p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+    p.segs_per_row = pl.segs_per_row; p.total_segs = pl.total_segs;
+    p.segs_per_block = pl.segs_per_block; p.split = pl.split;
+    p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
+    int rc;
+    if (pl.ci_t == 32 && pl.co_t == 32) {
+      if (stride == 1) rc = (pl.S == 32) ? launch_wgrad<32, 32, 32, 1>(p, stream)
+                                         : launch_wgrad<32, 32, 16, 1>(p, stream);
+      else rc = launch_wgrad<32, 32, 16, 2>(p, stream);
+    } else if (pl.ci_t == 32 && pl.co_t == 64) {
+      if (stride == 1) rc = (pl.S == 32) ? launch_wgrad<32, 64, 32, 1>(p, stream)
+                                         : launch_wgrad<32, 64, 16, 1>(p, stream);
+      else rc = launch_wgrad<32, 64, 16, 2>(p, stream);
+    } else {
+      if (stride == 1) rc = (pl.S == 32) ? launch_wgrad<64, 64, 32, 1>(p, stream)
+                                         : launch_wgrad<64, 64, 16, 1>(p, stream);
+      else rc = launch_wgrad<64, 64, 16, 2>(p, stream);
+    }
+    if (rc != UNET_OK) return rc;
+    dim3 rgrid(Cout / 32, Cx / 8);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, ws, dw_oihw, pl.split, Cx,
+                       Cout, ci_offset, Cin_total);
+    UNET_CHECK_LAUNCH("wgrad_reduce");
+  }
+  if (db) {
+    const long long M = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 32), dim3(256), 0, stream, dy, db, M, Cout);
+    UNET_CHECK_LAUNCH("bias_grad");
+  }
+  return UNET_OK;
+}

@@ -1,0 +1,405 @@
+// head_loss.hip — 1x1 segmentation head (NHWC activations -> NCHW logits) and
+// SimpleLoss (dynamic inverse-frequency weighted CE + soft Dice, ignore_index)
+// forward + closed-form gradient.  All HBM-bound; per-(n,class) reductions go
+// through per-block slabs and a single-block finalize in double (fixed order).
+//
+// Replaces segmentation_output (Our_UNet/models/unet.py:374-381,:430) and
+// SimpleLoss.forward + autograd (Our_UNet/models/losses.py:24-121).
+#include "common.h"
+
+namespace {
+
+constexpr int HT = 256;  // pixels per head tile
+constexpr int HLD = 33;
+
+// ------------------------------------------------------------------ head forward
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ b,
+                                                       float* __restrict__ logits, long long M,
+                                                       int HW, int K) {
+  __shared__ float sA[HT * HLD];
+  __shared__ float sW[4 * 32 + 4];
+  const int tid = threadIdx.x;
+  if (tid < K * 32) sW[tid] = w[tid];
+  if (tid < K) sW[128 + tid] = b ? b[tid] : 0.f;
+  const long long m0 = (long long)blockIdx.x * HT;
+  for (int i = tid; i < HT * 8; i += 256) {
+    const int pix = i >> 3, seg = i & 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m0 + pix < M) v = *reinterpret_cast<const f32x4*>(a + (size_t)(m0 + pix) * 32 + seg * 4);
+    float* d = sA + pix * HLD + seg * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  __syncthreads();
+  const long long m = m0 + tid;
+  if (m >= M) return;
+  float acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = sW[128 + k];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float x = sA[tid * HLD + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < K) acc[k] = fmaf(x, sW[k * 32 + c], acc[k]);
+  }
+  const long long n = m / HW, p = m - n * HW;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < K) logits[((size_t)n * K + k) * HW + p] = acc[k];
+}
+
+// ------------------------------------------------------------------ head backward
+// partial[block][K*32 + K]: dw then db
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ a,
+                                                       const float* __restrict__ dl,
+                                                       const float* __restrict__ w,
+                                                       float* __restrict__ da,
+                                                       float* __restrict__ partial, long long M,
+                                                       int HW, int K, long long tiles) {
+  __shared__ float sA[HT * HLD];
+  __shared__ float sD[4 * HT];
+  __shared__ float sW[4 * 32];
+  const int tid = threadIdx.x;
+  if (tid < K * 32) sW[tid] = w[tid];
+  float wacc = 0.f;  // threads < K*32: dw[k][c]; threads K*32..K*32+K-1: db[k]
+  const int wk = tid >> 5, wc = tid & 31;
+  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long long m0 = t * HT;
+    __syncthreads();  // previous tile fully consumed (also orders the sW fill)
+    for (int i = tid; i < HT * 8; i += 256) {
+      const int pix = i >> 3, seg = i & 7;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + pix < M) v = *reinterpret_cast<const f32x4*>(a + (size_t)(m0 + pix) * 32 + seg * 4);
+      float* d = sA + pix * HLD + seg * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    const long long m = m0 + tid;
+    float dv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const long long n = m / HW, p = m - n * HW;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < K) dv[k] = dl[((size_t)n * K + k) * HW + p];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sD[k * HT + tid] = dv[k];
+    __syncthreads();
+    if (m < M) {
+      float* o = da + (size_t)m * 32;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < K) x = fmaf(dv[k], sW[k * 32 + s * 4 + j], x);
+          v[j] = x;
+        }
+        *reinterpret_cast<f32x4*>(o + s * 4) = v;
+      }
+    }
+    if (tid < K * 32) {
+      float s = 0.f;
+      for (int pix = 0; pix < HT; ++pix) s = fmaf(sD[wk * HT + pix], sA[pix * HLD + wc], s);
+      wacc += s;
+    } else if (tid < K * 32 + K) {
+      const int k = tid - K * 32;
+      float s = 0.f;
+      for (int pix = 0; pix < HT; ++pix) s += sD[k * HT + pix];
+      wacc += s;
+    }
+  }
+  if (tid < K * 32 + K) partial[(size_t)blockIdx.x * (K * 32 + K) + tid] = wacc;
+}
+
+__global__ void head_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                         float* __restrict__ db, int nblocks, int K) {
+  const int i = threadIdx.x;
+  const int cols = K * 32 + K;
+  if (i >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * cols + i];
+  if (i < K * 32) {
+    if (dw) dw[i] = s;
+  } else if (db) {
+    db[i - K * 32] = s;
+  }
+}
+
+// ------------------------------------------------------------------ loss
+constexpr int LQ = 13;  // cnt[3], nll[3], I[3], P[3], valid
+constexpr int LOSS_BLOCKS = 128;  // per image
+
+struct LossCoef {  // written by finalize, read by the gradient kernel
+  float w[3];
+  float inv_wsum;   // w_ce / sum_i w[t_i]
+  float wdice;
+};
+
+__device__ __forceinline__ void softmax3(float z0, float z1, float z2, float& p0, float& p1,
+                                         float& p2, float& lse) {
+  const float m = fmaxf(z0, fmaxf(z1, z2));
+  const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
+  const float s = e0 + e1 + e2;
+  const float inv = 1.f / s;
+  p0 = e0 * inv; p1 = e1 * inv; p2 = e2 * inv;
+  lse = m + logf(s);
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ logits,
+                                                          const long long* __restrict__ target,
+                                                          float* __restrict__ partial, int HW,
+                                                          int ignore_index) {
+  __shared__ float red[4][LQ];
+  const int n = blockIdx.y;
+  const float* z = logits + (size_t)n * 3 * HW;
+  const long long* tg = target + (size_t)n * HW;
+  float q[LQ];
+#pragma unroll
+  for (int i = 0; i < LQ; ++i) q[i] = 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const long long t = tg[p];
+    const bool valid = (t != (long long)ignore_index);
+    float p0, p1, p2, lse;
+    const float z0 = z[p], z1 = z[HW + p], z2 = z[2 * HW + p];
+    softmax3(z0, z1, z2, p0, p1, p2, lse);
+    if (valid) {
+      q[12] += 1.f;
+      q[9] += p0; q[10] += p1; q[11] += p2;
+      if (t == 0) { q[0] += 1.f; q[3] += lse - z0; q[6] += p0; }
+      else if (t == 1) { q[1] += 1.f; q[4] += lse - z1; q[7] += p1; }
+      else if (t == 2) { q[2] += 1.f; q[5] += lse - z2; q[8] += p2; }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < LQ; ++i) {
+    const float s = wave_sum(q[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < LQ) {
+    const int i = threadIdx.x;
+    partial[((size_t)n * gridDim.x + blockIdx.x) * LQ + i] =
+        (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+// single block: thread i < N*LQ sums its column over the slabs (double), then thread 0
+// evaluates the loss and the gradient coefficients.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(
+    const float* __restrict__ partial, int N, int nblocks, float smooth, float w_dice, float w_ce,
+    int dynamic_weights, const float* __restrict__ class_weights, float grad_scale,
+    float* __restrict__ loss_out, LossCoef* __restrict__ coef, float* __restrict__ dice_ab) {
+  extern __shared__ double sums[];  // [N][LQ]
+  for (int i = threadIdx.x; i < N * LQ; i += blockDim.x) {
+    const int n = i / LQ, k = i - n * LQ;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[((size_t)n * nblocks + b) * LQ + k];
+    sums[i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double cnt[3] = {0, 0, 0}, nll[3] = {0, 0, 0}, total = 0;
+  for (int n = 0; n < N; ++n) {
+    for (int c = 0; c < 3; ++c) {
+      cnt[c] += sums[n * LQ + c];
+      nll[c] += sums[n * LQ + 3 + c];
+    }
+    total += sums[n * LQ + 12];
+  }
+  float w[3];
+  if (dynamic_weights) {
+    // Our_UNet/models/losses.py:44-60: count 0 -> 1, w = total/count, renormalised to sum 3
+    float cw[3], ws = 0.f;
+    for (int c = 0; c < 3; ++c) {
+      const float cp = cnt[c] == 0 ? 1.f : (float)cnt[c];
+      cw[c] = (float)total / cp;
+      ws += cw[c];
+    }
+    for (int c = 0; c < 3; ++c) w[c] = cw[c] * (3.f / ws);
+  } else {
+    for (int c = 0; c < 3; ++c) w[c] = class_weights ? class_weights[c] : 1.f;
+  }
+  double num = 0, den = 0;
+  for (int c = 0; c < 3; ++c) {
+    num += (double)w[c] * nll[c];
+    den += (double)w[c] * cnt[c];
+  }
+  const float ce = (float)(num / den);
+  double dice_sum = 0;
+  for (int c = 0; c < 3; ++c) {
+    double dmean = 0;
+    for (int n = 0; n < N; ++n) {
+      const double I = sums[n * LQ + 6 + c], P = sums[n * LQ + 9 + c], T = sums[n * LQ + c];
+      const double U = P + T;
+      dmean += (2.0 * I + smooth) / (U + smooth);
+      // d(dice loss)/dp_c at pixel i of image n = A*[t_i == c] + B (times valid mask)
+      const double k = 1.0 / (3.0 * N);
+      dice_ab[(n * 3 + c) * 2 + 0] = (float)(-2.0 * k / (U + smooth));
+      dice_ab[(n * 3 + c) * 2 + 1] = (float)((2.0 * I + smooth) * k / ((U + smooth) * (U + smooth)));
+    }
+    dice_sum += 1.0 - dmean / N;
+  }
+  const float dice = (float)(dice_sum / 3.0);
+  loss_out[0] = w_ce * ce + w_dice * dice;
+  loss_out[1] = ce;
+  loss_out[2] = dice;
+  for (int c = 0; c < 3; ++c) {
+    loss_out[3 + c] = w[c];
+    coef->w[c] = w[c];
+  }
+  coef->inv_wsum = (float)((double)w_ce * grad_scale / den);
+  coef->wdice = w_dice * grad_scale;
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ logits,
+                                                        const long long* __restrict__ target,
+                                                        const LossCoef* __restrict__ coef,
+                                                        const float* __restrict__ dice_ab,
+                                                        float* __restrict__ dlogits, int HW,
+                                                        int ignore_index) {
+  const int n = blockIdx.y;
+  const float* z = logits + (size_t)n * 3 * HW;
+  float* dz = dlogits + (size_t)n * 3 * HW;
+  const long long* tg = target + (size_t)n * HW;
+  const float w0 = coef->w[0], w1 = coef->w[1], w2 = coef->w[2];
+  const float iw = coef->inv_wsum, wd = coef->wdice;
+  float A[3], B[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    A[c] = dice_ab[(n * 3 + c) * 2 + 0];
+    B[c] = dice_ab[(n * 3 + c) * 2 + 1];
+  }
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const long long t = tg[p];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (t != (long long)ignore_index) {
+      float p0, p1, p2, lse;
+      softmax3(z[p], z[HW + p], z[2 * HW + p], p0, p1, p2, lse);
+      const float wt = (t == 0) ? w0 : (t == 1) ? w1 : (t == 2) ? w2 : 0.f;
+      const float k = wt * iw;
+      // weighted CE: w_t (p - onehot) / sum w
+      g0 = k * (p0 - (t == 0 ? 1.f : 0.f));
+      g1 = k * (p1 - (t == 1 ? 1.f : 0.f));
+      g2 = k * (p2 - (t == 2 ? 1.f : 0.f));
+      // dice through the softmax Jacobian: p_k (a_k - sum_c a_c p_c)
+      const float a0 = B[0] + (t == 0 ? A[0] : 0.f);
+      const float a1 = B[1] + (t == 1 ? A[1] : 0.f);
+      const float a2 = B[2] + (t == 2 ? A[2] : 0.f);
+      const float dot = a0 * p0 + a1 * p1 + a2 * p2;
+      g0 += wd * p0 * (a0 - dot);
+      g1 += wd * p1 * (a1 - dot);
+      g2 += wd * p2 * (a2 - dot);
+    }
+    dz[p] = g0; dz[HW + p] = g1; dz[2 * HW + p] = g2;
+  }
+}
+
+struct LossWs {
+  float* partial; LossCoef* coef; float* dice_ab;
+};
+size_t loss_ws_layout(int N, LossWs* out, char* base) {
+  size_t off = 0;
+  const size_t partial_b = align_up((size_t)N * LOSS_BLOCKS * LQ * sizeof(float), 256);
+  const size_t coef_b = align_up(sizeof(LossCoef), 256);
+  const size_t ab_b = align_up((size_t)N * 3 * 2 * sizeof(float), 256);
+  if (out) {
+    out->partial = reinterpret_cast<float*>(base + off);
+    out->coef = reinterpret_cast<LossCoef*>(base + off + partial_b);
+    out->dice_ab = reinterpret_cast<float*>(base + off + partial_b + coef_b);
+  }
+  off = partial_b + coef_b + ab_b;
+  return off;
+}
+
+int head_bwd_blocks(long long tiles) { return (int)(tiles < 1024 ? tiles : 1024); }
+
+}  // namespace
+
+extern "C" int unet_head1x1_fwd(const float* a, const float* w, const float* b, float* logits,
+                                int N, int HW, int C, int K, unet_stream_t stream) {
+  UNET_REQUIRE(a && w && logits, "head1x1_fwd: null pointer");
+  UNET_REQUIRE(C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0,
+               "head1x1_fwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
+  const long long M = (long long)N * HW;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
+                     (hipStream_t)stream, a, w, b, logits, M, HW, K);
+  UNET_CHECK_LAUNCH("head_fwd");
+  return UNET_OK;
+}
+
+extern "C" size_t unet_head1x1_bwd_workspace_bytes(int N, int HW, int C, int K) {
+  if (N <= 0 || HW <= 0) return 0;
+  const long long tiles = ceil_div64((long long)N * HW, HT);
+  return (size_t)head_bwd_blocks(tiles) * (K * 32 + K) * sizeof(float);
+}
+
+extern "C" int unet_head1x1_bwd(const float* a, const float* dlogits, const float* w, float* da,
+                                float* dw, float* db, void* workspace, size_t workspace_bytes,
+                                int N, int HW, int C, int K, unet_stream_t stream) {
+  UNET_REQUIRE(a && dlogits && w && da && workspace, "head1x1_bwd: null pointer");
+  UNET_REQUIRE(C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0,
+               "head1x1_bwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
+  if (workspace_bytes < unet_head1x1_bwd_workspace_bytes(N, HW, C, K)) {
+    unet_set_error("head1x1_bwd: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  const long long M = (long long)N * HW;
+  const long long tiles = ceil_div64(M, HT);
+  const int blocks = head_bwd_blocks(tiles);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dlogits,
+                     w, da, partial, M, HW, K, tiles);
+  UNET_CHECK_LAUNCH("head_bwd");
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial,
+                     dw, db, blocks, K);
+  UNET_CHECK_LAUNCH("head_bwd_finalize");
+  return UNET_OK;
+}
+
+extern "C" size_t unet_dice_wce_loss_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  return loss_ws_layout(N, nullptr, nullptr);
+}
+
+extern "C" int unet_dice_wce_loss_fwd_bwd(const float* logits, const int64_t* target,
+                                          float* loss_out, float* dlogits, void* workspace,
+                                          size_t workspace_bytes, int N, int H, int W,
+                                          float smooth, float w_dice, float w_ce, int ignore_index,
+                                          int dynamic_weights, const float* class_weights,
+                                          float grad_scale, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(logits && target && loss_out && workspace, "dice_wce_loss: null pointer");
+  UNET_REQUIRE(N > 0 && N <= 1024 && H > 0 && W > 0, "dice_wce_loss: bad shape");
+  if (workspace_bytes < loss_ws_layout(N, nullptr, nullptr)) {
+    unet_set_error("dice_wce_loss: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  LossWs ws;
+  loss_ws_layout(N, &ws, reinterpret_cast<char*>(workspace));
+  const int HW = H * W;
+  int blocks = ceil_div(HW, 256 * 8);
+  if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(blocks, N), dim3(256), 0, stream, logits,
+                     reinterpret_cast<const long long*>(target), ws.partial, HW, ignore_index);
+  UNET_CHECK_LAUNCH("loss_reduce");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), (size_t)N * LQ * sizeof(double),
+                     stream, ws.partial, N, blocks, smooth, w_dice, w_ce, dynamic_weights,
+                     class_weights, grad_scale, loss_out, ws.coef, ws.dice_ab);
+  UNET_CHECK_LAUNCH("loss_finalize");
+  if (dlogits) {
+    int gblocks = ceil_div(HW, 256 * 4);
+    if (gblocks < 1) gblocks = 1;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(gblocks, N), dim3(256), 0, stream, logits,
+                       reinterpret_cast<const long long*>(target), ws.coef, ws.dice_ab, dlogits, HW,
+                       ignore_index);
+    UNET_CHECK_LAUNCH("loss_grad");
+  }
+  return UNET_OK;
+}

@@ -1,0 +1,403 @@
+// instnorm.hip — InstanceNorm2d(eps, affine) + LeakyReLU + SpatialDropout2d,
+// forward and backward, on NHWC fp32 planes.  Pure HBM-bound streaming kernels:
+// float4 per lane along the contiguous channel axis, per-(n,c) reductions done
+// as per-thread register partials -> LDS -> per-block slabs -> a finalize
+// kernel that merges slabs in fixed order (deterministic run to run).
+//
+// Statistics use chunked Welford/Chan merging of (count, mean, M2) so the
+// variance does not suffer E[x^2]-E[x]^2 cancellation (the reference's CPU path
+// accumulates in double: aten::native_batch_norm as lowered from
+// nn.InstanceNorm2d, Our_UNet/models/unet.py:118-119).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__host__ __device__ inline int split_for(int N, int HW, int C) {
+  // enough blocks to fill the chip (~2048) but at least 64 pixels-iterations per block
+  int ppi = kThreads / (C / 4);
+  if (ppi < 1) ppi = 1;
+  int max_split = HW / (ppi * 8);
+  if (max_split < 1) max_split = 1;
+  int want = (2048 + N - 1) / N;
+  int s = want < max_split ? want : max_split;
+  return s < 1 ? 1 : s;
+}
+
+// ---------------------------------------------------------------- statistics
+// grid (split, N); partial[n][s][c] = (mean, M2), count implied by the pixel range.
+__global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restrict__ y,
+                                                            float2* __restrict__ partial, int HW,
+                                                            int C, int split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [groups][C][3]
+  const int lpp = C >> 2;
+  const int groups = kThreads / lpp;  // pixel groups per iteration
+  const int tid = threadIdx.x;
+  const int grp = tid / lpp, c4 = tid - grp * lpp;
+  const int n = blockIdx.y, s = blockIdx.x;
+  const int per = (HW + split - 1) / split;
+  const int p_begin = s * per;
+  const int p_end = min(p_begin + per, HW);
+  const float* base = y + (size_t)n * HW * C + c4 * 4;
+
+  float cnt = 0.f;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+  if (grp < groups) {
+    int pp = p_begin + grp;
+    while (pp < p_end) {
+      f32x4 v[8];
+      int k = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = pp + j * groups;
+        if (q < p_end) {
+          v[j] = *reinterpret_cast<const f32x4*>(base + (size_t)q * C);
+          ++k;
+        } else {
+          v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      const float kf = (float)k, inv = 1.f / kf;
+      f32x4 sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sm += v[j];
+      const f32x4 mu = sm * inv;
+      f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < k) {
+          const f32x4 d = v[j] - mu;
+          q2 += d * d;
+        }
+      // merge chunk (kf, mu, q2) into (cnt, mean, m2)
+      const float nt = cnt + kf;
+      const float f = kf / nt;
+      const f32x4 d = mu - mean;
+      mean += d * f;
+      m2 += q2 + d * d * (cnt * f);
+      cnt = nt;
+      pp += 8 * groups;
+    }
+  }
+  // block merge across pixel groups
+  float* sm_cnt = smem;                    // [groups][lpp]
+  float* sm_mean = smem + groups * lpp;    // [groups][C]
+  float* sm_m2 = sm_mean + groups * C;     // [groups][C]
+  if (grp < groups) {
+    sm_cnt[grp * lpp + c4] = cnt;
+    *reinterpret_cast<f32x4*>(sm_mean + grp * C + c4 * 4) = mean;
+    *reinterpret_cast<f32x4*>(sm_m2 + grp * C + c4 * 4) = m2;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    float n0 = 0.f, mu = 0.f, q = 0.f;
+    for (int g = 0; g < groups; ++g)
+      wf_merge(n0, mu, q, sm_cnt[g * lpp + (c >> 2)], sm_mean[g * C + c], sm_m2[g * C + c]);
+    partial[((size_t)n * split + s) * C + c] = float2{mu, q};
+  }
+}
+
+// one thread per (n, c): merge the slabs, emit mean / rstd / folded affine.
+__global__ void in_stats_finalize_kernel(const float2* __restrict__ partial,
+                                         const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                         float* __restrict__ alpha, float* __restrict__ beta2,
+                                         int N, int HW, int C, int split) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  const int per = (HW + split - 1) / split;
+  float cnt = 0.f, mu = 0.f, q = 0.f;
+  for (int s = 0; s < split; ++s) {
+    const int pb = s * per;
+    int pe = pb + per;
+    if (pe > HW) pe = HW;
+    const int k = pe - pb;
+    if (k <= 0) break;
+    const float2 v = partial[((size_t)n * split + s) * C + c];
+    wf_merge(cnt, mu, q, (float)k, v.x, v.y);
+  }
+  const float var = q / (float)HW;  // biased, like F.instance_norm
+  const float rs = 1.0f / sqrtf(var + eps);
+  mean[i] = mu;
+  rstd[i] = rs;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float a = g * rs;
+  if (alpha) alpha[i] = a;
+  if (beta2) beta2[i] = b - mu * a;
+}
+
+// ---------------------------------------------------------------- forward apply
+__global__ __launch_bounds__(kThreads) void in_apply_fwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ alpha, const float* __restrict__ beta2,
+    const float* __restrict__ mask, float slope, float* __restrict__ a, long long total4, int HW,
+    int C) {
+  const int lpp = C >> 2;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total4; i += stride) {
+    const long long pix = i / lpp;
+    const int c = (int)(i - pix * lpp) * 4;
+    const int n = (int)(pix / HW);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * C + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta2 + (size_t)n * C + c);
+    f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+    if (mask) mk = *reinterpret_cast<const f32x4*>(mask + (size_t)n * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = fmaf(v[k], al[k], be[k]);
+      o[k] = (z > 0.f ? z : z * slope) * mk[k];
+    }
+    *reinterpret_cast<f32x4*>(a + i * 4) = o;
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// pass 1: per (n,c) S1 = sum gz, S2 = sum gz*xhat, gz = ga*mask*lrelu'(z)
+__global__ __launch_bounds__(kThreads) void in_bwd_reduce_kernel(
+    const float* __restrict__ ga, const float* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mask, float slope,
+    float2* __restrict__ partial, int HW, int C, int split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [groups][C][2]
+  const int lpp = C >> 2;
+  const int groups = kThreads / lpp;
+  const int tid = threadIdx.x;
+  const int grp = tid / lpp, c4 = tid - grp * lpp;
+  const int n = blockIdx.y, s = blockIdx.x;
+  const int per = (HW + split - 1) / split;
+  const int p_begin = s * per;
+  const int p_end = min(p_begin + per, HW);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (grp < groups) {
+    const int c = c4 * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * C + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * C + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+    if (mask) mk = *reinterpret_cast<const f32x4*>(mask + (size_t)n * C + c);
+    const size_t base = (size_t)n * HW * C + c;
+    for (int pp = p_begin + grp; pp < p_end; pp += groups) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + (size_t)pp * C);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(ga + base + (size_t)pp * C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (yv[k] - mu[k]) * rs[k];
+        const float al = g[k] * rs[k];
+        const float z = fmaf(yv[k], al, b[k] - mu[k] * al);  // same expression as the forward
+        const float gz = gv[k] * mk[k] * (z > 0.f ? 1.f : slope);
+        s1[k] += gz;
+        s2[k] = fmaf(gz, xh, s2[k]);
+      }
+    }
+  }
+  float* sm1 = smem;               // [groups][C]
+  float* sm2 = smem + groups * C;  // [groups][C]
+  if (grp < groups) {
+    *reinterpret_cast<f32x4*>(sm1 + grp * C + c4 * 4) = s1;
+    *reinterpret_cast<f32x4*>(sm2 + grp * C + c4 * 4) = s2;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += kThreads) {
+    float a = 0.f, b = 0.f;
+    for (int g = 0; g < groups; ++g) {
+      a += sm1[g * C + c];
+      b += sm2[g * C + c];
+    }
+    partial[((size_t)n * split + s) * C + c] = float2{a, b};
+  }
+}
+
+// finalize: coef[n][c] = (S1/HW, S2/HW); dgamma[c] = sum_n S2; dbeta[c] = sum_n S1.
+// One thread per channel (loops over n and slabs; tiny).
+__global__ void in_bwd_finalize_kernel(const float2* __restrict__ partial,
+                                       float2* __restrict__ coef, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int N, int HW, int C, int split) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float dg = 0.f, db = 0.f;
+  const float inv = 1.f / (float)HW;
+  for (int n = 0; n < N; ++n) {
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < split; ++s) {
+      const float2 v = partial[((size_t)n * split + s) * C + c];
+      a += v.x;
+      b += v.y;
+    }
+    coef[(size_t)n * C + c] = float2{a * inv, b * inv};
+    db += a;
+    dg += b;
+  }
+  if (dgamma) dgamma[c] = dg;
+  if (dbeta) dbeta[c] = db;
+}
+
+// pass 2: dy = gamma*rstd*(gz - c1 - xhat*c2); per-block column sums of dy -> dbias slabs
+__global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
+    const float* ga /* may alias dy */, const float* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mask, float slope,
+    const float2* __restrict__ coef, float* dy, float* __restrict__ dbias_partial,
+    int HW, int C, int split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [groups][C]
+  const int lpp = C >> 2;
+  const int groups = kThreads / lpp;
+  const int tid = threadIdx.x;
+  const int grp = tid / lpp, c4 = tid - grp * lpp;
+  const int n = blockIdx.y, s = blockIdx.x;
+  const int per = (HW + split - 1) / split;
+  const int p_begin = s * per;
+  const int p_end = min(p_begin + per, HW);
+  f32x4 sd = {0.f, 0.f, 0.f, 0.f};
+  if (grp < groups) {
+    const int c = c4 * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)n * C + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * C + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+    if (mask) mk = *reinterpret_cast<const f32x4*>(mask + (size_t)n * C + c);
+    float c1[4], c2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float2 cf = coef[(size_t)n * C + c + k];
+      c1[k] = cf.x;
+      c2[k] = cf.y;
+    }
+    const size_t base = (size_t)n * HW * C + c;
+    for (int pp = p_begin + grp; pp < p_end; pp += groups) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + (size_t)pp * C);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(ga + base + (size_t)pp * C);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (yv[k] - mu[k]) * rs[k];
+        const float al = g[k] * rs[k];
+        const float z = fmaf(yv[k], al, b[k] - mu[k] * al);  // same expression as the forward
+        const float gz = gv[k] * mk[k] * (z > 0.f ? 1.f : slope);
+        o[k] = g[k] * rs[k] * (gz - c1[k] - xh * c2[k]);
+      }
+      sd += o;
+      *reinterpret_cast<f32x4*>(dy + base + (size_t)pp * C) = o;
+    }
+  }
+  if (dbias_partial) {
+    if (grp < groups) *reinterpret_cast<f32x4*>(smem + grp * C + c4 * 4) = sd;
+    __syncthreads();
+    for (int c = tid; c < C; c += kThreads) {
+      float a = 0.f;
+      for (int g = 0; g < groups; ++g) a += smem[g * C + c];
+      dbias_partial[((size_t)n * split + s) * C + c] = a;
+    }
+  }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int rows,
+                              int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r) a += partial[(size_t)r * C + c];
+  out[c] = a;
+}
+
+bool shape_ok(int N, int HW, int C) {
+  return N > 0 && HW > 0 && C >= 4 && C % 4 == 0 && C <= 1024 && (kThreads % (C / 4) == 0 || C / 4 > kThreads);
+}
+
+}  // namespace
+
+extern "C" size_t unet_instnorm_workspace_bytes(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  const int split = split_for(N, HW, C);
+  // slabs (float2) + bwd coef (float2 [N][C]) + dbias slabs (float)
+  return align_up((size_t)N * split * C * sizeof(float2), 256) +
+         align_up((size_t)N * C * sizeof(float2), 256) +
+         align_up((size_t)N * split * C * sizeof(float), 256);
+}
+
+extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const float* beta, float eps,
+                                   float* mean, float* rstd, float* alpha, float* beta2,
+                                   void* workspace, size_t workspace_bytes, int N, int HW, int C,
+                                   unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(y && mean && rstd && workspace, "instnorm_stats: null pointer");
+  UNET_REQUIRE(shape_ok(N, HW, C) && C <= 1024 && kThreads % (C / 4) == 0,
+               "instnorm_stats: unsupported shape N=%d HW=%d C=%d", N, HW, C);
+  if (workspace_bytes < unet_instnorm_workspace_bytes(N, HW, C)) {
+    unet_set_error("instnorm_stats: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  const int split = split_for(N, HW, C);
+  const int groups = kThreads / (C / 4);
+  float2* partial = reinterpret_cast<float2*>(workspace);
+  const size_t lds = (size_t)groups * (C / 4 + 2 * C) * sizeof(float);
+  hipLaunchKernelGGL(in_stats_kernel, dim3(split, N), dim3(kThreads), lds, stream, y, partial, HW,
+                     C, split);
+  UNET_CHECK_LAUNCH("in_stats");
+  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(N * C, 256)), dim3(256), 0, stream,
+                     partial, gamma, beta, eps, mean, rstd, alpha, beta2, N, HW, C, split);
+  UNET_CHECK_LAUNCH("in_stats_finalize");
+  return UNET_OK;
+}
+
+extern "C" int unet_instnorm_lrelu_drop_fwd(const float* y, const float* alpha, const float* beta2,
+                                            const float* mask, float slope, float* a, int N, int HW,
+                                            int C, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(y && alpha && beta2 && a, "instnorm_lrelu_drop_fwd: null pointer");
+  UNET_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0, "instnorm_lrelu_drop_fwd: bad shape");
+  const long long total4 = (long long)N * HW * (C / 4);
+  long long blocks = ceil_div64(total4, kThreads);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(in_apply_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, y,
+                     alpha, beta2, mask, slope, a, total4, HW, C);
+  UNET_CHECK_LAUNCH("in_apply_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, const float* mean,
+                                            const float* rstd, const float* gamma,
+                                            const float* beta, const float* mask, float slope,
+                                            float* dy, float* dgamma, float* dbeta, float* dbias,
+                                            void* workspace, size_t workspace_bytes, int N, int HW,
+                                            int C, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(ga && y && mean && rstd && gamma && beta && dy && workspace,
+               "instnorm_lrelu_drop_bwd: null pointer");
+  UNET_REQUIRE(shape_ok(N, HW, C) && kThreads % (C / 4) == 0,
+               "instnorm_lrelu_drop_bwd: unsupported shape N=%d HW=%d C=%d", N, HW, C);
+  if (workspace_bytes < unet_instnorm_workspace_bytes(N, HW, C)) {
+    unet_set_error("instnorm_lrelu_drop_bwd: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  const int split = split_for(N, HW, C);
+  const int groups = kThreads / (C / 4);
+  char* ws = reinterpret_cast<char*>(workspace);
+  float2* partial = reinterpret_cast<float2*>(ws);
+  ws += align_up((size_t)N * split * C * sizeof(float2), 256);
+  float2* coef = reinterpret_cast<float2*>(ws);
+  ws += align_up((size_t)N * C * sizeof(float2), 256);
+  float* dbp = reinterpret_cast<float*>(ws);
+  const size_t lds2 = (size_t)groups * 2 * C * sizeof(float);
+  hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(split, N), dim3(kThreads), lds2, stream, ga, y,
+                     mean, rstd, gamma, beta, mask, slope, partial, HW, C, split);
+  UNET_CHECK_LAUNCH("in_bwd_reduce");
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, partial,
+                     coef, dgamma, dbeta, N, HW, C, split);
+  UNET_CHECK_LAUNCH("in_bwd_finalize");
+  const size_t lds1 = (size_t)groups * C * sizeof(float);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(split, N), dim3(kThreads), lds1, stream, ga, y, mean,
+                     rstd, gamma, beta, mask, slope, coef, dy, dbias ? dbp : nullptr, HW, C, split);
+  UNET_CHECK_LAUNCH("in_bwd_apply");
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, dbp, dbias,
+                       N * split, C);
+    UNET_CHECK_LAUNCH("dbias_colsum");
+  }
+  return UNET_OK;
+}

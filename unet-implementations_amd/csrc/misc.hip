@@ -1,0 +1,277 @@
+// misc.hip — layout conversion, weight packing, bilinear 2x up-sampling,
+// SGD-Nesterov and the library-level entry points (error string, version).
+// All kernels here are HBM-bound streaming kernels (float4 per lane).
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void unet_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* unet_last_error(void) { return g_err; }
+extern "C" int unet_abi_version(void) { return UNET_ABI_VERSION; }
+extern "C" int unet_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+namespace {
+
+// ---- NCHW <-> NHWC (small C) ------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                    long long HW, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    // i indexes the NHWC output: ((n*HW + p)*C + c)
+    const int c = (int)(i % C);
+    const long long np = i / C;
+    const long long n = np / HW, p = np - n * HW;
+    y[i] = x[(n * C + c) * HW + p];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                    long long HW, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    // i indexes the NCHW output: ((n*C + c)*HW + p)
+    const long long p = i % HW;
+    const long long nc = i / HW;
+    const long long n = nc / C;
+    const int c = (int)(nc - n * C);
+    y[i] = x[(n * HW + p) * C + c];
+  }
+}
+
+// ---- weight packing -----------------------------------------------------------
+// wf[t][ci][co] and wd[t][co][ci] from w[co][ci][t]
+__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                              float* __restrict__ wd, int Cout, int Cin) {
+  const long long total = (long long)9 * Cin * Cout;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    if (wf) {  // i = (t*Cin + ci)*Cout + co
+      const int co = (int)(i % Cout);
+      const long long r = i / Cout;
+      const int ci = (int)(r % Cin), t = (int)(r / Cin);
+      wf[i] = w[((size_t)co * Cin + ci) * 9 + t];
+    }
+    if (wd) {  // i = (t*Cout + co)*Cin + ci
+      const int ci = (int)(i % Cin);
+      const long long r = i / Cin;
+      const int co = (int)(r % Cout), t = (int)(r / Cout);
+      wd[i] = w[((size_t)co * Cin + ci) * 9 + t];
+    }
+  }
+}
+
+// ---- bilinear 2x, align_corners=False ---------------------------------------------
+// out[2i]   = 0.25*in[i-1] + 0.75*in[i]   (i-1 clamped: out[0] = in[0])
+// out[2i+1] = 0.75*in[i]   + 0.25*in[i+1] (i+1 clamped)
+__device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float& w0, float& w1) {
+  // PyTorch area_pixel_compute_source_index: src = max((o+0.5)*0.5 - 0.5, 0)
+  float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+  w0 = 1.f - w1;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x,
+                                                             float* __restrict__ y, int h, int w,
+                                                             int C, long long total4) {
+  const int lpp = C >> 2;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const long long pix = i / lpp;
+    const int c = (int)(i - pix * lpp) * 4;
+    const int ox = (int)(pix % W2);
+    const long long r = pix / W2;
+    const int oy = (int)(r % H2);
+    const long long n = r / H2;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    up_taps(oy, h, y0, y1, wy0, wy1);
+    up_taps(ox, w, x0, x1, wx0, wx1);
+    const float* b = x + (size_t)n * h * w * C + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x0) * C);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x1) * C);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x0) * C);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x1) * C);
+    const f32x4 o = (v00 * wx0 + v01 * wx1) * wy0 + (v10 * wx0 + v11 * wx1) * wy1;
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+// gather form of the transpose: input row i receives
+//   out[2i] * a(2i), out[2i+1] * a(2i+1), out[2i-1] * 0.25 (i>=1), out[2i+2] * 0.25 (i<=L-1)
+// where the self-weights are 0.75 except at the clamped ends (1.0).
+__device__ __forceinline__ int bwd_taps(int i, int n_in, int idx[4], float wt[4]) {
+  const int L = n_in - 1;
+  int k = 0;
+  idx[k] = 2 * i;     wt[k] = (i == 0) ? 1.0f : 0.75f; ++k;
+  idx[k] = 2 * i + 1; wt[k] = (i == L) ? 1.0f : 0.75f; ++k;
+  if (i >= 1) { idx[k] = 2 * i - 1; wt[k] = 0.25f; ++k; }
+  if (i < L)  { idx[k] = 2 * i + 2; wt[k] = 0.25f; ++k; }
+  return k;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gy,
+                                                             float* gx, int h, int w, int C,
+                                                             long long total4, int accumulate) {
+  const int lpp = C >> 2;
+  const int W2 = 2 * w;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const long long pix = i / lpp;
+    const int c = (int)(i - pix * lpp) * 4;
+    const int ix = (int)(pix % w);
+    const long long r = pix / w;
+    const int iy = (int)(r % h);
+    const long long n = r / h;
+    int ys[4], xs[4];
+    float wy[4], wx[4];
+    const int ny = bwd_taps(iy, h, ys, wy), nx = bwd_taps(ix, w, xs, wx);
+    const float* b = gy + (size_t)n * (4 * (size_t)h * w) * C + c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a) {
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < nx; ++q)
+        row += *reinterpret_cast<const f32x4*>(b + ((size_t)ys[a] * W2 + xs[q]) * C) * wx[q];
+      acc += row * wy[a];
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(gx + i * 4);
+    if (accumulate) acc += *o;
+    *o = acc;
+  }
+}
+
+// ---- SGD with Nesterov momentum ------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p,
+                                                           const float* __restrict__ g,
+                                                           float* __restrict__ buf, long long n,
+                                                           float lr, float mu, float wd,
+                                                           int first_step, float gscale) {
+  const long long stride = (long long)gridDim.x * 256;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4) * gscale + pv * wd;
+    f32x4 bv;
+    if (first_step) bv = gv;
+    else bv = *reinterpret_cast<f32x4*>(buf + i * 4) * mu + gv;
+    *reinterpret_cast<f32x4*>(buf + i * 4) = bv;
+    gv += bv * mu;
+    pv -= gv * lr;
+    *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+  }
+  // tail
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    float pv = p[i];
+    float gv = g[i] * gscale + pv * wd;
+    float bv = first_step ? gv : buf[i] * mu + gv;
+    buf[i] = bv;
+    gv += bv * mu;
+    p[i] = pv - gv * lr;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
+                                                          const float* __restrict__ b,
+                                                          long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) a[i] += b[i];
+}
+
+unsigned stream_grid(long long items) {
+  long long b = ceil_div64(items, 256);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int unet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W,
+                                 unet_stream_t stream) {
+  UNET_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, C, (long long)H * W, total);
+  UNET_CHECK_LAUNCH("nchw_to_nhwc");
+  return UNET_OK;
+}
+
+extern "C" int unet_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W,
+                                 unet_stream_t stream) {
+  UNET_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad argument");
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, C, (long long)H * W, total);
+  UNET_CHECK_LAUNCH("nhwc_to_nchw");
+  return UNET_OK;
+}
+
+extern "C" int unet_pack_conv3x3_weights(const float* w, float* wf, float* wd, int Cout, int Cin,
+                                         unet_stream_t stream) {
+  UNET_REQUIRE(w && (wf || wd) && Cout > 0 && Cin > 0, "pack_conv3x3_weights: bad argument");
+  const long long total = (long long)9 * Cin * Cout;
+  hipLaunchKernelGGL(pack_w_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
+                     wf, wd, Cout, Cin);
+  UNET_CHECK_LAUNCH("pack_w");
+  return UNET_OK;
+}
+
+extern "C" int unet_upsample2x_fwd(const float* x, float* y, int N, int h, int w, int C,
+                                   unet_stream_t stream) {
+  UNET_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
+               "upsample2x_fwd: bad argument");
+  const long long total4 = (long long)N * 4 * h * w * (C / 4);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, h, w, C, total4);
+  UNET_CHECK_LAUNCH("upsample2x_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_upsample2x_bwd(const float* gy, float* gx, int N, int h, int w, int C,
+                                   int accumulate, unet_stream_t stream) {
+  UNET_REQUIRE(gy && gx && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
+               "upsample2x_bwd: bad argument");
+  const long long total4 = (long long)N * h * w * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+                     (hipStream_t)stream, gy, gx, h, w, C, total4, accumulate);
+  UNET_CHECK_LAUNCH("upsample2x_bwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_sgd_nesterov_step(float* params, const float* grads, float* momentum,
+                                      int64_t n, float lr, float mu, float weight_decay,
+                                      int first_step, float grad_scale, unet_stream_t stream) {
+  UNET_REQUIRE(params && grads && momentum && n > 0, "sgd_nesterov_step: bad argument");
+  UNET_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0) &&
+                   ((uintptr_t)momentum % 16 == 0),
+               "sgd_nesterov_step: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, params, grads, momentum, (long long)n, lr, mu,
+                     weight_decay, first_step, grad_scale);
+  UNET_CHECK_LAUNCH("sgd_nesterov");
+  return UNET_OK;
+}
+
+extern "C" int unet_add_inplace(float* a, const float* b, int64_t n, unet_stream_t stream) {
+  UNET_REQUIRE(a && b && n > 0, "add_inplace: bad argument");
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream,
+                     a, b, (long long)n);
+  UNET_CHECK_LAUNCH("add_inplace");
+  return UNET_OK;
+}

@@ -1,0 +1,198 @@
+"""Thin torch-tensor wrappers over the C ABI (one Python function per export).
+
+Tensors are plumbing only: device memory, the current HIP stream and nothing
+else.  Activations are NHWC fp32 (`[N, H, W, C]` contiguous).  Every function
+launches asynchronously on `torch.cuda.current_stream()`.
+"""
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("unet-implementations_amd: the HIP path needs CUDA/ROCm tensors "
+                           "(no CPU fallback exists)")
+    if t.dtype not in (torch.float32, torch.int64, torch.uint8):
+        raise TypeError(f"unsupported dtype {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _f32(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+# ---- layout -------------------------------------------------------------------
+def nchw_to_nhwc(x):
+    N, C, H, W = x.shape
+    y = _f32((N, H, W, C), x)
+    check(lib().unet_nchw_to_nhwc(_ptr(x), _ptr(y), N, C, H, W, _stream()))
+    return y
+
+
+def nhwc_to_nchw(x):
+    N, H, W, C = x.shape
+    y = _f32((N, C, H, W), x)
+    check(lib().unet_nhwc_to_nchw(_ptr(x), _ptr(y), N, C, H, W, _stream()))
+    return y
+
+
+def pack_conv3x3_weights(w_oihw, wf=None, wd=None, want_wd=True):
+    Cout, Cin, kh, kw = w_oihw.shape
+    assert kh == 3 and kw == 3
+    if wf is None:
+        wf = _f32((9, Cin, Cout), w_oihw)
+    if wd is None and want_wd:
+        wd = _f32((9, Cout, Cin), w_oihw)
+    check(lib().unet_pack_conv3x3_weights(_ptr(w_oihw), _ptr(wf), _ptr(wd), Cout, Cin, _stream()))
+    return wf, wd
+
+
+# ---- convolution ---------------------------------------------------------------
+def conv3x3_fwd(x0, x1, wf, bias, stride, out=None):
+    N, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    if x1 is not None:
+        assert x1.shape[:3] == x0.shape[:3]
+    Cout = wf.shape[2]
+    assert wf.shape[0] == 9 and wf.shape[1] == C0 + C1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = out if out is not None else _f32((N, Ho, Wo, Cout), x0)
+    check(lib().unet_conv3x3_fwd(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(bias), _ptr(y), N, H,
+                                 W, Cout, stride, _stream()))
+    return y
+
+
+def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False):
+    """dx[N,H,W,ccols] (+)= transpose-conv of dy with columns [ci_offset, ci_offset+ccols) of wd."""
+    N, Ho, Wo, Cout = dy.shape
+    cin_total = wd.shape[2]
+    assert wd.shape[0] == 9 and wd.shape[1] == Cout
+    dx = out if out is not None else _f32((N, H, W, ccols), dy)
+    assert dx.shape == (N, H, W, ccols)
+    wptr = _ptr(wd) + 4 * ci_offset
+    check(lib().unet_conv3x3_bwd_data(_ptr(dy), wptr, cin_total, _ptr(dx), N, H, W, Cout, ccols,
+                                      stride, 1 if accumulate else 0, _stream()))
+    return dx
+
+
+def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None):
+    N, H, W, Cx = x.shape
+    Cout = dy.shape[3]
+    cin_total = dw_oihw.shape[1]
+    assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
+    nbytes = lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride)
+    ws = _ws(nbytes, x)
+    check(lib().unet_conv3x3_bwd_weight(_ptr(x), Cx, _ptr(dy), _ptr(dw_oihw), ci_offset,
+                                        cin_total, _ptr(db), _ptr(ws), ws.numel(), N, H, W, Cout,
+                                        stride, _stream()))
+    return dw_oihw
+
+
+# ---- InstanceNorm + LeakyReLU + channel dropout -----------------------------------
+def instnorm_stats(y, gamma, beta, eps):
+    N, H, W, C = y.shape
+    st = _f32((4, N, C), y)  # mean, rstd, alpha, beta2
+    ws = _ws(lib().unet_instnorm_workspace_bytes(N, H * W, C), y)
+    check(lib().unet_instnorm_stats(_ptr(y), _ptr(gamma), _ptr(beta), eps, _ptr(st[0]),
+                                    _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), _ptr(ws), ws.numel(), N,
+                                    H * W, C, _stream()))
+    return st
+
+
+def instnorm_lrelu_drop_fwd(y, alpha, beta2, mask, slope, out=None):
+    N, H, W, C = y.shape
+    a = out if out is not None else torch.empty_like(y)
+    check(lib().unet_instnorm_lrelu_drop_fwd(_ptr(y), _ptr(alpha), _ptr(beta2), _ptr(mask), slope,
+                                             _ptr(a), N, H * W, C, _stream()))
+    return a
+
+
+def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma, dbeta, dbias,
+                            out=None):
+    """Returns dy (in place over `ga` unless `out` is given)."""
+    N, H, W, C = y.shape
+    dy = ga if out is None else out
+    ws = _ws(lib().unet_instnorm_workspace_bytes(N, H * W, C), y)
+    check(lib().unet_instnorm_lrelu_drop_bwd(_ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd),
+                                             _ptr(gamma), _ptr(beta), _ptr(mask), slope, _ptr(dy),
+                                             _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws),
+                                             ws.numel(), N, H * W, C, _stream()))
+    return dy
+
+
+# ---- bilinear 2x ---------------------------------------------------------------------
+def upsample2x_fwd(x):
+    N, h, w, C = x.shape
+    y = _f32((N, 2 * h, 2 * w, C), x)
+    check(lib().unet_upsample2x_fwd(_ptr(x), _ptr(y), N, h, w, C, _stream()))
+    return y
+
+
+def upsample2x_bwd(gy, out=None, accumulate=False):
+    N, H2, W2, C = gy.shape
+    h, w = H2 // 2, W2 // 2
+    gx = out if out is not None else _f32((N, h, w, C), gy)
+    check(lib().unet_upsample2x_bwd(_ptr(gy), _ptr(gx), N, h, w, C, 1 if accumulate else 0,
+                                    _stream()))
+    return gx
+
+
+# ---- head + loss ---------------------------------------------------------------------
+def head1x1_fwd(a, w, b):
+    N, H, W, C = a.shape
+    K = w.shape[0]
+    logits = _f32((N, K, H, W), a)
+    check(lib().unet_head1x1_fwd(_ptr(a), _ptr(w), _ptr(b), _ptr(logits), N, H * W, C, K,
+                                 _stream()))
+    return logits
+
+
+def head1x1_bwd(a, dlogits, w, dw, db):
+    N, H, W, C = a.shape
+    K = w.shape[0]
+    da = torch.empty_like(a)
+    ws = _ws(lib().unet_head1x1_bwd_workspace_bytes(N, H * W, C, K), a)
+    check(lib().unet_head1x1_bwd(_ptr(a), _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw), _ptr(db),
+                                 _ptr(ws), ws.numel(), N, H * W, C, K, _stream()))
+    return da
+
+
+def dice_wce_loss_fwd_bwd(logits, target, smooth, w_dice, w_ce, ignore_index, dynamic_weights,
+                          class_weights=None, grad_scale=1.0, want_grad=True):
+    N, K, H, W = logits.shape
+    if K != 3:
+        raise ValueError("the fused loss kernel handles exactly 3 classes")
+    out = _f32((8,), logits)
+    dl = torch.empty_like(logits) if want_grad else None
+    ws = _ws(lib().unet_dice_wce_loss_workspace_bytes(N, H, W), logits)
+    check(lib().unet_dice_wce_loss_fwd_bwd(_ptr(logits), _ptr(target), _ptr(out), _ptr(dl),
+                                           _ptr(ws), ws.numel(), N, H, W, smooth, w_dice, w_ce,
+                                           ignore_index, 1 if dynamic_weights else 0,
+                                           _ptr(class_weights), grad_scale, _stream()))
+    return out, dl
+
+
+# ---- optimizer -------------------------------------------------------------------------
+def sgd_nesterov_step(params, grads, momentum, lr, mu, weight_decay, first_step, grad_scale=1.0):
+    n = params.numel()
+    check(lib().unet_sgd_nesterov_step(_ptr(params), _ptr(grads), _ptr(momentum), n, lr, mu,
+                                       weight_decay, 1 if first_step else 0, grad_scale,
+                                       _stream()))
+
+
+def add_inplace(a, b):
+    check(lib().unet_add_inplace(_ptr(a), _ptr(b), a.numel(), _stream()))
+    return a

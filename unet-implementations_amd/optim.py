@@ -1,0 +1,87 @@
+"""Fused SGD with Nesterov momentum over the model's flat arenas.
+
+Counterpart of `optim.SGD(model.parameters(), lr, momentum, nesterov=True,
+weight_decay)` as configured in Our_UNet/src/train.py:445-451.  When every
+parameter and gradient is a view into the `UNet` arenas the whole step is ONE
+kernel launch over 19.66 M floats; otherwise each parameter gets its own launch
+of the same kernel.  `state_dict()` keeps torch's SGD layout
+(`state[i]['momentum_buffer']`, `param_groups`) so checkpoints interchange.
+"""
+import torch
+
+from . import ops
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0,
+                 nesterov=False, model=None):
+        if dampening != 0.0:
+            raise NotImplementedError("FusedSGD implements dampening == 0 (the reference setting)")
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum")
+        if not nesterov:
+            raise NotImplementedError("FusedSGD implements the Nesterov form used by the reference")
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                        nesterov=nesterov)
+        super().__init__(params, defaults)
+        self._model = model
+        self._flat_buf = None
+        self._steps = 0
+        self.grad_scale = 1.0
+
+    def _flat_ready(self):
+        """True when one launch over the arenas is equivalent to the per-parameter update."""
+        m = self._model
+        if m is None or len(self.param_groups) != 1:
+            return False
+        arena, garena = m.flat_parameters()
+        params = self.param_groups[0]["params"]
+        if len(params) != len(m._offsets):
+            return False
+        base, gbase = arena.data_ptr(), garena.data_ptr()
+        for p, off in zip(params, m._offsets):
+            if p.grad is None or p.data_ptr() != base + 4 * off or \
+                    p.grad.data_ptr() != gbase + 4 * off:
+                return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._flat_ready():
+            g = self.param_groups[0]
+            arena, garena = self._model.flat_parameters()
+            first = self._flat_buf is None
+            if first:
+                self._flat_buf = torch.zeros_like(arena)
+                for p, off in zip(g["params"], self._model._offsets):
+                    st = self.state[p]
+                    if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                        # resumed from a checkpoint: adopt the loaded buffers
+                        self._flat_buf[off:off + p.numel()].view_as(p).copy_(st["momentum_buffer"])
+                        first = False
+                    st["momentum_buffer"] = self._flat_buf[off:off + p.numel()].view_as(p)
+            ops.sgd_nesterov_step(arena, garena, self._flat_buf, g["lr"], g["momentum"],
+                                  g["weight_decay"], first, self.grad_scale)
+        else:
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.grad is None:
+                        continue
+                    st = self.state[p]
+                    first = "momentum_buffer" not in st or st["momentum_buffer"] is None
+                    if first:
+                        st["momentum_buffer"] = torch.zeros_like(p)
+                    n4 = p.numel()
+                    if p.data_ptr() % 16 or p.grad.data_ptr() % 16 or not p.is_contiguous() \
+                            or not p.grad.is_contiguous():
+                        raise RuntimeError("FusedSGD needs contiguous, 16-byte aligned tensors")
+                    ops.sgd_nesterov_step(p.data.view(-1), p.grad.view(-1),
+                                          st["momentum_buffer"].view(-1), g["lr"], g["momentum"],
+                                          g["weight_decay"], first, self.grad_scale)
+                    del n4
+        self._steps += 1
+        return loss

@@ -1,0 +1,75 @@
+"""The train step of Our_UNet/src/train.py:592-680 on the HIP path.
+
+`train_step` reproduces the reference's hot-loop order
+    optimizer.zero_grad() -> model(images) -> loss_function(outputs, masks)
+    -> loss.backward() -> optimizer.step()
+(src/train.py:634,:654,:658,:663,:664) without the per-step `loss.item()` sync
+(:670): the loss stays a device scalar.  `create_model` / `create_optimizer` /
+`create_lr_scheduler` mirror src/train.py:776-798, :431-453 and :456-477.
+"""
+import torch
+
+from .losses import SimpleLoss
+from .optim import FusedSGD
+from .unet import UNet
+
+
+def create_model(device="cuda"):
+    """The exact configuration built at Our_UNet/src/train.py:776-795."""
+    model = UNet(in_channels=3, num_classes=3, n_stages=6,
+                 features_per_stage=[32, 64, 128, 256, 512, 512], kernel_sizes=[[3, 3]] * 6,
+                 strides=[[1, 1], [2, 2], [2, 2], [2, 2], [2, 2], [2, 2]],
+                 n_conv_per_stage=[2] * 6, n_conv_per_stage_decoder=[2] * 5, conv_bias=True,
+                 norm_op=torch.nn.InstanceNorm2d, norm_op_kwargs={"eps": 1e-5, "affine": True},
+                 dropout_op=None, nonlin=torch.nn.LeakyReLU, nonlin_kwargs={"inplace": True},
+                 encoder_dropout_rates=[0.0, 0.0, 0.1, 0.2, 0.3, 0.3],
+                 decoder_dropout_rates=[0.3, 0.2, 0.2, 0.1, 0.0])
+    return model.to(device)
+
+
+def create_optimizer(model, lr=0.005, weight_decay=1e-4, momentum=0.99):
+    """SGD + Nesterov as at Our_UNet/src/train.py:445-451 (defaults from :66-99)."""
+    return FusedSGD(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=momentum,
+                    nesterov=True, model=model)
+
+
+def create_lr_scheduler(optimizer, max_epochs):
+    """Polynomial decay (1 - e/E)^0.9 stepped per epoch (Our_UNet/src/train.py:468-475)."""
+    return torch.optim.lr_scheduler.LambdaLR(
+        optimizer, lr_lambda=lambda epoch: (1 - epoch / max_epochs) ** 0.9)
+
+
+def get_loss_function():
+    """Default branch of Our_UNet/src/train.py:862-869."""
+    return SimpleLoss(weight_dice=1.0, weight_ce=1.0, ignore_index=255, dynamic_weights=True)
+
+
+def train_step(model, optimizer, loss_function, images, masks, grad_sync=None):
+    """One optimisation step; returns the loss as a 0-dim device tensor (no host sync).
+
+    `grad_sync` (optional) is called between backward and the optimizer step; the
+    data-parallel wrapper passes its gradient all-reduce finaliser here.
+    """
+    optimizer.zero_grad()
+    outputs = model(images)
+    loss = loss_function(outputs, masks)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    optimizer.step()
+    return loss.detach()
+
+
+def train_one_epoch(model, train_loader, optimizer, loss_function, device, scaler=None):
+    """Signature-compatible with the reference's train_one_epoch (src/train.py:592-680)."""
+    if scaler is not None:
+        raise NotImplementedError("fp16 GradScaler AMP is not part of the fp32 HIP path")
+    model.train()
+    total = torch.zeros((), device=device)
+    n = 0
+    for batch in train_loader:
+        images = batch["image"].to(device, non_blocking=True)
+        masks = batch["mask"].to(device, non_blocking=True)
+        total += train_step(model, optimizer, loss_function, images, masks)
+        n += 1
+    return (total / max(n, 1)).item()

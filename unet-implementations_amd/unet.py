@@ -1,0 +1,445 @@
+"""Drop-in `UNet` for the reference's Our_UNet (Our_UNet/models/unet.py:233-432).
+
+Same constructor keywords, same module tree (`encoder_stages[i].block[j]`,
+`decoder_stages[i].conv_block.block[j]`, `segmentation_output`) and therefore
+the same 90 `state_dict()` keys/shapes, same `forward(x) -> logits` contract
+(NCHW fp32 in, NCHW fp32 logits out).  The sub-modules only hold parameters:
+`forward` runs the whole network as ONE autograd node whose forward/backward
+launch the gfx950 kernels of libunet_hip.so through the C ABI.
+
+Internal layout: activations NHWC fp32; per 3x3 conv layer the raw output y,
+its per-(n,c) InstanceNorm statistics and the activated tensor
+a = dropout(leaky_relu(IN(y))) are kept for the backward pass.
+"""
+from typing import Dict, List, Optional, Tuple, Type, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class SpatialDropout2d(nn.Module):
+    """Channel dropout (reference: Our_UNet/models/unet.py:13-35).
+
+    Only carries `drop_prob`; the mask [N, C] (already divided by 1-p) is drawn by
+    `UNet.forward` with the same torch calls as the reference, so a given seed yields
+    the mask sequence the reference would draw on the same device.
+    """
+
+    def __init__(self, drop_prob):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob}"
+
+    def draw_mask(self, n, channels, device):
+        mask = torch.empty(n, channels, 1, 1, device=device).bernoulli_(1 - self.drop_prob)
+        return mask.div_(1 - self.drop_prob).view(n, channels)
+
+    def forward(self, x):  # NCHW tensor, stock torch semantics (not on the fused path)
+        if not self.training or self.drop_prob == 0:
+            return x
+        return x * self.draw_mask(x.size(0), x.size(1), x.device).view(x.size(0), x.size(1), 1, 1)
+
+
+def _same_padding(kernel_size):
+    if isinstance(kernel_size, int):
+        return kernel_size // 2
+    return (kernel_size[0] // 2, kernel_size[1] // 2)
+
+
+class ConvBlock(nn.Module):
+    """[Conv2d -> norm -> nonlin -> SpatialDropout2d?] x n_convs; stride on the first conv.
+
+    Mirrors Our_UNet/models/unet.py:37-141 (module order inside `.block` decides the
+    state_dict indices: 0/1 and 3/4, or 0/1 and 4/5 when dropout modules are present).
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, n_convs=2, padding=None,
+                 norm_op=nn.InstanceNorm2d, norm_op_kwargs=None, dropout_op=None,
+                 dropout_op_kwargs=None, nonlin=nn.LeakyReLU, nonlin_kwargs=None, conv_bias=True,
+                 spatial_dropout_rate=0.0):
+        super().__init__()
+        norm_op_kwargs = {"eps": 1e-5, "affine": True} if norm_op_kwargs is None else norm_op_kwargs
+        nonlin_kwargs = {"inplace": True} if nonlin_kwargs is None else nonlin_kwargs
+        dropout_op_kwargs = {} if dropout_op_kwargs is None else dropout_op_kwargs
+        if padding is None:
+            padding = _same_padding(kernel_size)
+        mods = []
+        cin = in_channels
+        for k in range(n_convs):
+            mods.append(nn.Conv2d(cin, out_channels, kernel_size, stride if k == 0 else 1, padding,
+                                  bias=conv_bias))
+            if norm_op is not None:
+                mods.append(norm_op(out_channels, **norm_op_kwargs))
+            if nonlin is not None:
+                mods.append(nonlin(**nonlin_kwargs))
+            if spatial_dropout_rate > 0:
+                mods.append(SpatialDropout2d(spatial_dropout_rate))
+            if dropout_op is not None:
+                mods.append(dropout_op(**dropout_op_kwargs))
+            cin = out_channels
+        self.block = nn.Sequential(*mods)
+
+    def forward(self, x):
+        raise NotImplementedError(
+            "ConvBlock only holds parameters here; call UNet.forward (the fused HIP path)")
+
+
+class UpBlock(nn.Module):
+    """Bilinear up-sample to the skip size, concat [up, skip], ConvBlock
+    (Our_UNet/models/unet.py:143-231)."""
+
+    def __init__(self, in_channels, skip_channels, out_channels, kernel_size, n_convs=2,
+                 norm_op=nn.InstanceNorm2d, norm_op_kwargs=None, dropout_op=None,
+                 dropout_op_kwargs=None, nonlin=nn.LeakyReLU, nonlin_kwargs=None, conv_bias=True,
+                 spatial_dropout_rate=0.0):
+        super().__init__()
+        self.conv_block = ConvBlock(in_channels + skip_channels, out_channels, kernel_size,
+                                    stride=1, n_convs=n_convs, padding=None, norm_op=norm_op,
+                                    norm_op_kwargs=norm_op_kwargs, dropout_op=dropout_op,
+                                    dropout_op_kwargs=dropout_op_kwargs, nonlin=nonlin,
+                                    nonlin_kwargs=nonlin_kwargs, conv_bias=conv_bias,
+                                    spatial_dropout_rate=spatial_dropout_rate)
+
+    def forward(self, x, skip):
+        raise NotImplementedError(
+            "UpBlock only holds parameters here; call UNet.forward (the fused HIP path)")
+
+
+class _Layer:
+    """One conv3x3 + InstanceNorm + LeakyReLU (+ dropout) unit of the fused plan."""
+
+    __slots__ = ("conv", "norm", "slope", "drop", "stride", "first_of_decoder", "name")
+
+    def __init__(self, conv, norm, slope, drop, stride, first_of_decoder, name):
+        self.conv, self.norm, self.slope, self.drop = conv, norm, slope, drop
+        self.stride, self.first_of_decoder, self.name = stride, first_of_decoder, name
+
+
+def _as_int(v):
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            return None
+        return int(v[0])
+    return int(v)
+
+
+class UNet(nn.Module):
+    """6-stage encoder/decoder UNet with the reference's constructor surface."""
+
+    def __init__(self, in_channels: int = 3, num_classes: int = 3, n_stages: int = 6,
+                 features_per_stage: List[int] = None,
+                 kernel_sizes: List[Tuple[int, int]] = None,
+                 strides: List[Tuple[int, int]] = None, n_conv_per_stage: List[int] = None,
+                 n_conv_per_stage_decoder: List[int] = None, conv_bias: bool = True,
+                 norm_op: Type[nn.Module] = nn.InstanceNorm2d, norm_op_kwargs: Dict = None,
+                 dropout_op: Optional[Type[nn.Module]] = None, dropout_op_kwargs: Dict = None,
+                 nonlin: Type[nn.Module] = nn.LeakyReLU, nonlin_kwargs: Dict = None,
+                 encoder_dropout_rates: List[float] = None,
+                 decoder_dropout_rates: List[float] = None):
+        super().__init__()
+        if features_per_stage is None:
+            features_per_stage = [32, 64, 128, 256, 512, 512]
+        if kernel_sizes is None:
+            kernel_sizes = [[3, 3]] * n_stages
+        if strides is None:
+            strides = [[1, 1]] + [[2, 2]] * (n_stages - 1)
+        if n_conv_per_stage is None:
+            n_conv_per_stage = [2] * n_stages
+        if n_conv_per_stage_decoder is None:
+            n_conv_per_stage_decoder = [2] * (n_stages - 1)
+        if norm_op_kwargs is None:
+            norm_op_kwargs = {"eps": 1e-5, "affine": True}
+        if nonlin_kwargs is None:
+            nonlin_kwargs = {"inplace": True}
+        if encoder_dropout_rates is None:
+            encoder_dropout_rates = [0.0, 0.0, 0.1, 0.2, 0.3, 0.3]
+        if decoder_dropout_rates is None:
+            decoder_dropout_rates = [0.3, 0.2, 0.2, 0.1, 0.0]
+
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.n_stages = n_stages
+        self.features_per_stage = features_per_stage
+
+        common = dict(norm_op=norm_op, norm_op_kwargs=norm_op_kwargs, dropout_op=dropout_op,
+                      dropout_op_kwargs=dropout_op_kwargs, nonlin=nonlin,
+                      nonlin_kwargs=nonlin_kwargs, conv_bias=conv_bias)
+        self.encoder_stages = nn.ModuleList()
+        cin = in_channels
+        for s in range(n_stages):
+            self.encoder_stages.append(
+                ConvBlock(cin, features_per_stage[s], kernel_sizes[s], strides[s],
+                          n_convs=n_conv_per_stage[s],
+                          spatial_dropout_rate=encoder_dropout_rates[s], **common))
+            cin = features_per_stage[s]
+        self.decoder_stages = nn.ModuleList()
+        for s in range(n_stages - 1):
+            lvl = n_stages - 2 - s
+            self.decoder_stages.append(
+                UpBlock(features_per_stage[lvl + 1], features_per_stage[lvl],
+                        features_per_stage[lvl], kernel_sizes[lvl],
+                        n_convs=n_conv_per_stage_decoder[lvl],
+                        spatial_dropout_rate=decoder_dropout_rates[s], **common))
+        self.segmentation_output = nn.Conv2d(features_per_stage[0], num_classes, kernel_size=1,
+                                             stride=1, padding=0, bias=True)
+        self.initialize_weights()
+        self._plan = None
+        self._arena = None       # flat fp32 parameter arena (parameters are views into it)
+        self._grad_arena = None  # flat fp32 gradient arena (p.grad are views into it)
+        self._offsets = None
+        self.dropout_mask_override = None  # test hook: list of [N, C] masks in forward order
+
+    # -- reference: Our_UNet/models/unet.py:386-397 --------------------------------------
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="leaky_relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.InstanceNorm2d):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # -- fused-plan construction -------------------------------------------------------------
+    def _block_layers(self, block, first_of_decoder, prefix):
+        mods = list(block.block)
+        layers, i = [], 0
+        while i < len(mods):
+            conv = mods[i]
+            if not isinstance(conv, nn.Conv2d):
+                raise NotImplementedError(f"{prefix}: unexpected module {type(conv).__name__}")
+            ks, st = _as_int(conv.kernel_size), _as_int(conv.stride)
+            if ks != 3 or st not in (1, 2) or _as_int(conv.padding) != 1 or conv.bias is None \
+                    or conv.groups != 1 or _as_int(conv.dilation) != 1:
+                raise NotImplementedError(
+                    f"{prefix}.block.{i}: the HIP path covers 3x3/pad 1/stride 1|2 convs with bias")
+            i += 1
+            norm = mods[i] if i < len(mods) else None
+            if not (isinstance(norm, nn.InstanceNorm2d) and norm.affine
+                    and not norm.track_running_stats):
+                raise NotImplementedError(
+                    f"{prefix}: the HIP path needs InstanceNorm2d(affine=True) after each conv")
+            i += 1
+            act = mods[i] if i < len(mods) else None
+            if not isinstance(act, nn.LeakyReLU):
+                raise NotImplementedError(f"{prefix}: the HIP path needs LeakyReLU after the norm")
+            i += 1
+            drop = None
+            if i < len(mods) and isinstance(mods[i], SpatialDropout2d):
+                drop = mods[i]
+                i += 1
+            if i < len(mods) and not isinstance(mods[i], nn.Conv2d):
+                raise NotImplementedError(
+                    f"{prefix}: dropout_op={type(mods[i]).__name__} is not on the HIP path")
+            layers.append(_Layer(conv, norm, float(act.negative_slope), drop, st,
+                                 first_of_decoder and not layers, f"{prefix}.block.{len(layers)}"))
+        return layers
+
+    def _build_plan(self):
+        enc = [self._block_layers(b, False, f"encoder_stages.{i}")
+               for i, b in enumerate(self.encoder_stages)]
+        dec = [self._block_layers(b.conv_block, True, f"decoder_stages.{i}.conv_block")
+               for i, b in enumerate(self.decoder_stages)]
+        head = self.segmentation_output
+        if _as_int(head.kernel_size) != 1 or head.in_channels != 32 or head.out_channels != 3:
+            raise NotImplementedError("the HIP head kernel is the 32 -> 3 1x1 convolution")
+        if enc[0][0].stride != 1:
+            raise NotImplementedError("first encoder conv must be stride 1")
+        self._plan = (enc, dec)
+        return self._plan
+
+    # -- flat parameter / gradient arenas -------------------------------------------------------
+    def _ensure_arena(self):
+        params = list(self.parameters())
+        dev = params[0].device
+        ok = self._arena is not None and self._arena.device == dev
+        if ok:
+            base = self._arena.data_ptr()
+            for p, off in zip(params, self._offsets):
+                if p.data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+        if ok:
+            return
+        offsets, total = [], 0
+        for p in params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("all UNet parameters must be fp32 on one device")
+            offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(params, offsets):
+                view = arena[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self._arena, self._offsets = arena, offsets
+        self._grad_arena = torch.zeros(total, dtype=torch.float32, device=dev)
+
+    def flat_parameters(self):
+        """(param_arena, grad_arena): flat fp32 views that alias every parameter / gradient."""
+        self._ensure_arena()
+        return self._arena, self._grad_arena
+
+    def _grad_view(self, p):
+        idx = self._param_index[id(p)]
+        off = self._offsets[idx]
+        return self._grad_arena[off:off + p.numel()].view(p.shape)
+
+    # -- forward ----------------------------------------------------------------------------------
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("unet-implementations_amd.UNet runs on MI355X only: move the model "
+                               "and the input to a ROCm device (no CPU fallback exists)")
+        if x.dim() != 4 or x.shape[1] != self.in_channels or self.in_channels != 3:
+            raise ValueError("expected an NCHW batch with 3 channels")
+        n_down = self.n_stages - 1
+        if x.shape[2] % (1 << n_down) or x.shape[3] % (1 << n_down) or \
+                min(x.shape[2], x.shape[3]) < (2 << n_down):
+            raise ValueError(f"H and W must be multiples of {1 << n_down} and >= {2 << n_down}")
+        if self._plan is None:
+            self._build_plan()
+        self._ensure_arena()
+        params = list(self.parameters())
+        self._param_index = {id(p): i for i, p in enumerate(params)}
+        x = x.contiguous().float()
+        return _UNetFunction.apply(self, x, *params)
+
+
+def _draw_masks(model, layers, n, device):
+    """Dropout masks in forward order; mirrors the reference's per-module draws."""
+    if model.dropout_mask_override is not None:
+        it = iter(model.dropout_mask_override)
+        return [next(it).to(device=device, dtype=torch.float32).contiguous()
+                if (l.drop is not None and l.drop.drop_prob > 0) else None for l in layers]
+    out = []
+    for l in layers:
+        if model.training and l.drop is not None and l.drop.drop_prob > 0:
+            out.append(l.drop.draw_mask(n, l.conv.out_channels, device))
+        else:
+            out.append(None)
+    return out
+
+
+class _UNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        enc, dec = model._plan
+        layers = [l for blk in enc for l in blk] + [l for blk in dec for l in blk]
+        need_grad = any(ctx.needs_input_grad)  # False under no_grad / frozen parameters
+        N = x.shape[0]
+        use_masks = model.training or model.dropout_mask_override is not None
+        masks = _draw_masks(model, layers, N, x.device) if use_masks else [None] * len(layers)
+        mask_of = {id(l): m for l, m in zip(layers, masks)}
+        saved = []  # per layer: dict(inputs, y, stats, mask, a)
+
+        def run_layer(l, x0, x1):
+            w = l.conv.weight
+            wf, wd = ops.pack_conv3x3_weights(w.detach(), want_wd=need_grad)
+            y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride)
+            st = ops.instnorm_stats(y, l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps)
+            m = mask_of[id(l)]
+            a = ops.instnorm_lrelu_drop_fwd(y, st[2], st[3], m, l.slope)
+            if need_grad:
+                saved.append(dict(layer=l, x0=x0, x1=x1, y=y, st=st, mask=m, a=a, wd=wd))
+            return a
+
+        cur = ops.nchw_to_nhwc(x)
+        skips = []
+        for bi, blk in enumerate(enc):
+            for l in blk:
+                cur = run_layer(l, cur, None)
+            if bi < len(enc) - 1:
+                skips.append(cur)
+        for di, blk in enumerate(dec):
+            skip = skips[len(skips) - 1 - di]
+            if cur.shape[1] * 2 != skip.shape[1] or cur.shape[2] * 2 != skip.shape[2]:
+                raise NotImplementedError("decoder up-sampling must be exactly 2x")
+            up = ops.upsample2x_fwd(cur)
+            for li, l in enumerate(blk):
+                cur = run_layer(l, up, skip) if li == 0 else run_layer(l, cur, None)
+        head = model.segmentation_output
+        logits = ops.head1x1_fwd(cur, head.weight.detach().view(head.out_channels, -1),
+                                 head.bias.detach())
+        if need_grad:
+            ctx.model = model
+            ctx.saved = saved
+            ctx.n_enc_blocks = len(enc)
+            ctx.params = params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, saved, params = ctx.model, ctx.saved, ctx.params
+        enc, dec = model._plan
+        gv = model._grad_view
+        dlogits = dlogits.contiguous()
+        head = model.segmentation_output
+        last = saved[-1]
+        g = ops.head1x1_bwd(last["a"], dlogits, head.weight.detach().view(head.out_channels, -1),
+                            gv(head.weight).view(head.out_channels, -1), gv(head.bias))
+
+        n_enc_layers = sum(len(b) for b in enc)
+        idx = len(saved) - 1
+        skip_grads = {}
+
+        def layer_bwd(rec, g_a, dx0_out=None, dx0_acc=False, need_dx=True):
+            l = rec["layer"]
+            st = rec["st"]
+            dy = ops.instnorm_lrelu_drop_bwd(g_a, rec["y"], st[0], st[1], l.norm.weight.detach(),
+                                             l.norm.bias.detach(), rec["mask"], l.slope,
+                                             gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias))
+            x0, x1 = rec["x0"], rec["x1"]
+            dw = gv(l.conv.weight)
+            ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride)
+            if x1 is not None:
+                ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride)
+            dx0 = dx1 = None
+            if need_dx:
+                N, H, W, C0 = x0.shape
+                dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
+                                           accumulate=dx0_acc)
+                if x1 is not None:
+                    dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride)
+            return dx0, dx1
+
+        # decoder stages, last to first
+        for di in range(len(dec) - 1, -1, -1):
+            blk = dec[di]
+            for li in range(len(blk) - 1, 0, -1):
+                g, _ = layer_bwd(saved[idx], g)
+                idx -= 1
+            g_up, g_skip = layer_bwd(saved[idx], g)
+            idx -= 1
+            skip_grads[len(enc) - 2 - di] = g_skip
+            g = ops.upsample2x_bwd(g_up)
+        # encoder stages, last to first
+        for bi in range(len(enc) - 1, -1, -1):
+            blk = enc[bi]
+            if bi < len(enc) - 1:
+                # g currently holds the gradient from encoder stage bi+1 accumulated into the
+                # decoder's skip gradient (see below)
+                pass
+            for li in range(len(blk) - 1, -1, -1):
+                rec = saved[idx]
+                idx -= 1
+                first_layer_of_net = (bi == 0 and li == 0)
+                if first_layer_of_net:
+                    layer_bwd(rec, g, need_dx=False)
+                    g = None
+                elif li == 0 and (bi - 1) in skip_grads:
+                    # input of this layer is the skip tensor of stage bi-1: accumulate into the
+                    # gradient the decoder already wrote for it
+                    g, _ = layer_bwd(rec, g, dx0_out=skip_grads.pop(bi - 1), dx0_acc=True)
+                else:
+                    g, _ = layer_bwd(rec, g)
+        assert idx == -1 and n_enc_layers > 0
+        ctx.saved = None
+        grads = [gv(p) if p.requires_grad else None for p in params]
+        return (None, None, *grads)
