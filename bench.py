@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Throughput of the Our_UNet train step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad -> UNet.forward -> SimpleLoss -> backward -> SGD-Nesterov step on one
+synthetic batch of 8 images 512x512 per GPU (inputs resident in HBM), train mode (dropout on).
+Rank 0 prints ONE JSON line; `value` is images/s over all GPUs (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = 385.188   # fwd + dgrad + wgrad, convolutions only
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def cpu_baseline(steps=3, hw=512, n=2):
+    """The oracle's train step (stock torch CPU ops, verified equal to the reference) timed on
+    this box's host cores: the reported CPU baseline, never the thing shipped."""
+    from oracle import unet_ref as O
+    # a 1-GPU box owns a 16-core share of the host (oversubscribing all 256 hardware threads
+    # makes torch's CPU kernels ~40x slower); use the affinity mask, capped at 16 threads
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    sd = O.leaf_state_dict(O.fill_state_dict(1, trained_like=False))
+    bufs = [None] * len(sd)
+    img, tgt = O.synthetic_batch(1234, n, hw, hw)
+    masks = O.draw_dropout_masks(0, n)
+    O.train_step(sd, bufs, img, tgt, masks)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(sd, bufs, img, tgt, masks)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} train steps of the oracle (torch CPU fp32) at bs={n}, {hw}x{hw}, "
+                      f"after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--hw", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    import unet_implementations_amd as ua
+    from oracle import unet_ref as O   # synthetic batch generator only (input data, not compute)
+    from unet_implementations_amd import ddp
+
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    torch.manual_seed(1234)          # same initial replica on every rank
+    model = ua.create_model(dev).train()
+    opt = ua.create_optimizer(model)
+    lossf = ua.get_loss_function()
+    sync = None
+    if world > 1:
+        ddp.broadcast_parameters(model)
+        sync = ddp.GradBucketAllReduce(model, opt)
+    img, tgt = O.synthetic_batch(1234 + rank, args.batch, args.hw, args.hw)
+    img, tgt = img.to(dev), tgt.to(dev)
+    torch.manual_seed(99 + rank)     # dropout stream differs per rank
+
+    def step():
+        return ua.train_step(model, opt, lossf, img, tgt, grad_sync=sync.finish if sync else None)
+
+    for _ in range(args.warmup):
+        loss = step()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ua.ops.KernelTimer()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    ua.ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ua.ops.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+    if not (final_loss == final_loss):
+        raise SystemExit("loss is NaN")
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / dt
+        result = {
+            "metric": "images/sec (512x512, bs/GPU=8) Our_UNet train step",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
+                                   "fp32 train step (fwd + Dice/wCE loss + bwd + SGD-Nesterov), "
+                                   "train mode, HIP conv/IN/upsample kernels",
+                       "global_batch": args.batch * world, "image": [args.hw, args.hw],
+                       "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "step_tflops": value / world * GFLOP_PER_IMAGE * 1e-3,
+            "step_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * 1e-3 / PEAK_F32_MFMA_TFLOPS,
+        }
+        if timer is not None:
+            summ = timer.summary()
+            k = summ.get("conv_igemm")
+            if k:
+                ach = k["flops"] / (k["ms"] * 1e-3) * 1e-12
+                result["roofline"] = {
+                    "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "kernel": "conv_igemm_kernel (3x3 conv forward + data gradient, all tile "
+                              "instantiations)",
+                    "launches_per_step": k["launches"] / args.steps,
+                    "avg_launch_us": 1e3 * k["ms"] / k["launches"],
+                    "flop_per_step": k["flops"] / args.steps,
+                }
+            result["kernel_groups"] = {
+                t: {"tflops": v["flops"] / (v["ms"] * 1e-3) * 1e-12, "ms_per_step": v["ms"] / args.steps,
+                    "launches_per_step": v["launches"] / args.steps}
+                for t, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

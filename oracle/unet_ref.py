@@ -116,10 +116,15 @@ def draw_dropout_masks(seed, n):
 
 
 # --------------------------------------------------------------------------- per-op
-def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None):
+def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None):
     """Conv2d(3x3, pad 1) -> InstanceNorm2d(eps, affine) -> LeakyReLU(0.01) -> channel mask
-    (models/unet.py:101-134; SpatialDropout2d.forward :22-35)."""
+    (models/unet.py:101-134; SpatialDropout2d.forward :22-35).  `record` (debug): list that
+    receives the raw conv output with retain_grad set."""
     y = F.conv2d(x, w, b, stride=stride, padding=1)
+    if record is not None:
+        if y.requires_grad:
+            y.retain_grad()
+        record.append(y)
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=EPS)
     y = F.leaky_relu(y, NEG_SLOPE)
     if mask is not None:
@@ -135,9 +140,9 @@ def upsample_concat(x, skip):
 
 
 # --------------------------------------------------------------------------- network
-def unet_forward(sd, x, masks=None):
+def unet_forward(sd, x, masks=None, record=None):
     """UNet.forward (models/unet.py:399-432).  `masks`: list from draw_dropout_masks (train
-    mode) or None (eval / rates 0)."""
+    mode) or None (eval / rates 0).  `record` (debug): collects each conv's raw output."""
     mi = iter(masks) if masks is not None else None
     skips = []
     rows = layer_table()
@@ -148,7 +153,8 @@ def unet_forward(sd, x, masks=None):
             cur = upsample_concat(cur, skips.pop())
         m = next(mi) if (mi is not None and p > 0) else None
         cur = conv_in_lrelu_drop(cur, sd[f"{prefix}.{ci}.weight"], sd[f"{prefix}.{ci}.bias"],
-                                 sd[f"{prefix}.{ni}.weight"], sd[f"{prefix}.{ni}.bias"], stride, m)
+                                 sd[f"{prefix}.{ni}.weight"], sd[f"{prefix}.{ni}.bias"], stride, m,
+                                 record)
         if kind == "enc" and li % 2 == 1 and li < n_enc - 1:
             skips.append(cur)
     return F.conv2d(cur, sd["segmentation_output.weight"], sd["segmentation_output.bias"])

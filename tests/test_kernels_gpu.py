@@ -97,6 +97,9 @@ DGRAD_SHAPES = [
     (2, 4, 4, 512, 512, 2, (0, 512)),
     (1, 32, 32, 384, 128, 1, (256, 128)),
     (1, 64, 64, 64, 64, 1, (0, 64)),
+    (2, 32, 32, 64, 128, 2, (0, 64)),
+    (2, 16, 16, 128, 128, 1, (0, 128)),
+    (2, 64, 64, 32, 64, 2, (0, 32)),
 ]
 
 
@@ -133,6 +136,10 @@ WGRAD_SHAPES = [
     (2, 4, 4, 512, 0, 512, 512, 2),
     (1, 64, 64, 64, 0, 64, 64, 1),
     (3, 34, 70, 32, 0, 32, 32, 1),
+    (2, 32, 32, 64, 0, 64, 128, 2),
+    (2, 64, 64, 32, 0, 32, 64, 2),
+    (2, 16, 16, 128, 0, 128, 256, 2),
+    (1, 64, 64, 64, 0, 64, 128, 2),
 ]
 
 
@@ -155,7 +162,7 @@ def test_conv3x3_bwd_weight(ua, shape):
 
 
 # --------------------------------------------------------------------------- instance norm
-IN_SHAPES = [(2, 12, 20, 32), (2, 16, 16, 64), (1, 8, 8, 512), (2, 2, 2, 512), (1, 64, 64, 32),
+IN_SHAPES = [(2, 16, 16, 128), (2, 12, 20, 32), (2, 16, 16, 64), (1, 8, 8, 512), (2, 2, 2, 512), (1, 64, 64, 32),
              (2, 33, 7, 128), (1, 128, 128, 32)]
 
 

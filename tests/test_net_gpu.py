@@ -1,0 +1,238 @@
+"""Whole-network parity (-m gpu): the drop-in UNet + SimpleLoss + FusedSGD through the C ABI
+against (a) the reference-generated fixtures tests/golden/net64.npz and net512.npz and
+(b) the oracle run on the same seeded inputs.
+
+Tolerance: 1e-4 relative on fp32 logits (north_star), stated per assertion; argmax masks are
+compared bit-exactly on every pixel whose reference top-2 logit margin is >= 1e-3 (pixels
+below that margin are ties at fp32 resolution: SURVEY.md §7.2).
+
+Gradients: LeakyReLU's derivative is discontinuous, so an element whose pre-activation is
+within fp32 rounding of 0 can take the other branch than in the reference run (measured on
+MI355X at 64x64: exactly 1 of 65,536 elements of encoder_stages.2.block.0, with the
+reference's own fp32 gradients deviating from an fp64 run by the same 4e-4..2e-3).  Gradient
+checks are therefore norm-wise (||g - ref|| / ||ref||) plus "all but a few sampled entries"."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def sample_idx(numel, k=64, seed=5):
+    rng = np.random.Generator(np.random.PCG64(seed + numel))
+    return np.sort(rng.choice(numel, size=min(k, numel), replace=False))
+
+
+def build(ua, g):
+    sd = O.fill_state_dict(int(g["seed_w"]))
+    model = ua.UNet()
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    img, tgt = O.synthetic_batch(int(g["seed_x"]), int(g["n"]), int(g["hw"]), int(g["hw"]))
+    return model, sd, img.to(DEV), tgt.to(DEV)
+
+
+def unpack_argmax(g, shape):
+    bits = np.unpackbits(g["eval_argmax"])[: 2 * int(np.prod(shape))].reshape(-1, 2)
+    return (bits[:, 0] * 2 + bits[:, 1]).reshape(shape).astype(np.uint8)
+
+
+def run_golden(ua, g, full):
+    model, sd0, img, tgt = build(ua, g)
+    n, hw = int(g["n"]), int(g["hw"])
+    names = [str(s) for s in g["param_names"]]
+    assert names == [k for k, _ in model.named_parameters()]
+
+    # ---- eval forward: logits within 1e-4 relative, argmax bit-exact off the tie pixels
+    model.eval()
+    with torch.no_grad():
+        le = model(img)
+    assert le.shape == (n, 3, hw, hw) and le.dtype == torch.float32
+    if full:
+        e = relerr(le, torch.from_numpy(g["eval_logits"]))
+    else:
+        e = relerr(le[:, :, ::16, ::16], torch.from_numpy(g["eval_logits_s16"]))
+    assert e <= 1e-4, f"eval logits rel err {e:.3e}"
+    am = le.argmax(dim=1).to(torch.uint8).cpu().numpy()
+    ref_am = unpack_argmax(g, am.shape)
+    assert hashlib.sha256(ref_am.tobytes()).hexdigest() == str(g["eval_argmax_sha256"])
+    low = np.unpackbits(g["eval_lowmargin"])[: am.size].reshape(am.shape).astype(bool)
+    assert low.mean() < 0.01
+    assert np.array_equal(am[~low], ref_am[~low]), "argmax differs on a non-tie pixel"
+
+    # ---- three train steps with injected dropout masks
+    model.train()
+    opt = ua.create_optimizer(model)
+    lossf = ua.get_loss_function()
+    steps = 3
+    for s in range(steps):
+        model.dropout_mask_override = O.draw_dropout_masks(int(g["seed_drop"]) + s, n)
+        if s == 0:
+            opt.zero_grad()
+            logits = model(img)
+            loss = lossf(logits, tgt)
+            loss.backward()
+            if full:
+                e = relerr(logits, torch.from_numpy(g["train_logits"]))
+            else:
+                e = relerr(logits[:, :, ::16, ::16], torch.from_numpy(g["train_logits_s16"]))
+            assert e <= 1e-4, f"train logits rel err {e:.3e}"
+            bad = []
+            for i, (k, p) in enumerate(model.named_parameters()):
+                gk = p.grad.reshape(-1)
+                ref_norm = float(g[f"gnorm_{i}"])
+                got = gk.double().norm().item()
+                if ref_norm < 1e-4:       # conv biases under InstanceNorm: exact 0 up to rounding
+                    if got >= 1e-3:
+                        bad.append(f"{k}: |grad| {got:.3e} should be ~0")
+                    continue
+                if abs(got - ref_norm) > 5e-3 * ref_norm:
+                    bad.append(f"{k}: grad norm {got} vs {ref_norm}")
+                idx = torch.from_numpy(sample_idx(gk.numel())).to(DEV)
+                ref_s = torch.from_numpy(g[f"gsamp_{i}"])
+                err = (gk[idx].cpu() - ref_s).abs()
+                # the reference's own fp32 run deviates from fp64 by 1e-3..1.5e-2 of max|g| at
+                # 512x512 (profiles/r01_grad_accuracy_vs_fp64_512.txt): LeakyReLU tie flips
+                tol = 1e-2 * max(ref_s.abs().max().item(), ref_norm / gk.numel() ** 0.5)
+                if (err > tol).sum().item() > 3 or err.max().item() > 20 * tol:
+                    bad.append(f"{k}: sampled grad err {err.max().item():.3e} (tol {tol:.3e})")
+            assert not bad, "\n".join(bad)
+            opt.step()
+        else:
+            loss = ua.train_step(model, opt, lossf, img, tgt)
+        ref_loss = float(g[f"loss_{s}"])
+        assert abs(loss.item() - ref_loss) <= 2e-4 * abs(ref_loss), \
+            f"step {s}: loss {loss.item()} vs {ref_loss}"
+        for i, (k, p) in enumerate(model.named_parameters()):
+            d = (p.detach().cpu() - sd0[k]).double().norm().item()
+            ref_d = float(g[f"dnorm_{s}_{i}"])
+            assert abs(d - ref_d) <= 5e-3 * ref_d + 1e-7, f"step {s} {k}: |dp| {d} vs {ref_d}"
+    for i, (k, p) in enumerate(model.named_parameters()):
+        flat = p.detach().reshape(-1)
+        idx = torch.from_numpy(sample_idx(flat.numel())).to(DEV)
+        ref_s = torch.from_numpy(g[f"psamp_{i}"])
+        assert (flat[idx].cpu() - ref_s).abs().max().item() <= 1e-5 + 2e-4 * ref_s.abs().max().item()
+
+
+def test_net64_golden(ua, golden):
+    run_golden(ua, golden("net64"), full=True)
+
+
+def test_net512_golden(ua, golden):
+    run_golden(ua, golden("net512"), full=False)
+
+
+def test_net_vs_oracle_random_init(ua):
+    """Reference-style random init (Kaiming weights, zero biases, unit gamma), 96x64 input,
+    train mode with oracle-drawn masks: logits, loss and every gradient against the oracle."""
+    sd0 = O.fill_state_dict(99, trained_like=False)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    img, tgt = O.synthetic_batch(5, 3, 96, 64)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(3, 3, 96, 64, generator=g)
+    tgt = tgt[:, :96, :64].contiguous()
+    masks = O.draw_dropout_masks(123, 3)
+    osd = O.leaf_state_dict(sd0)
+    ologits = O.unet_forward(osd, img, masks)
+    oloss = O.simple_loss(ologits, tgt)
+    oloss.backward()
+    model.dropout_mask_override = masks
+    logits = model(img.to(DEV))
+    loss = ua.SimpleLoss()(logits, tgt.to(DEV))
+    loss.backward()
+    assert relerr(logits, ologits.detach()) <= 1e-4
+    assert abs(loss.item() - oloss.item()) <= 1e-4 * abs(oloss.item())
+    bad = []
+    num = den = 0.0
+    for k, p in model.named_parameters():
+        ref = osd[k].grad.double()
+        got = p.grad.cpu().double()
+        if ref.abs().max() < 1e-4:
+            if got.abs().max().item() >= 1e-3:
+                bad.append(f"{k}: should be ~0")
+            continue
+        e = ((got - ref).norm() / ref.norm()).item()
+        num += ((got - ref) ** 2).sum().item()
+        den += (ref ** 2).sum().item()
+        if e > 3e-2:
+            bad.append(f"{k}: norm-wise grad rel err {e:.3e}")
+    assert not bad, "\n".join(bad)
+    assert (num / den) ** 0.5 <= 5e-3, f"whole-gradient rel err {(num / den) ** 0.5:.3e}"
+
+
+def test_gradient_accuracy_vs_fp64(ua):
+    """Principled accuracy check: the whole gradient of the HIP path must be as close to an
+    fp64 run of the oracle as the oracle's own fp32 run is (x3 slack, floor 5e-4)."""
+    sd0 = O.fill_state_dict(2024)
+    img, tgt = O.synthetic_batch(1234, 2, 64, 64)
+    masks = O.draw_dropout_masks(77, 2)
+
+    def run(dtype):
+        osd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd0.items()}
+        lg = O.unet_forward(osd, img.to(dtype), [m.to(dtype) for m in masks])
+        w = O.class_weights(tgt).to(dtype)
+        loss = torch.nn.functional.cross_entropy(lg, tgt, weight=w, ignore_index=255) \
+            + O.dice_loss(lg, tgt)
+        loss.backward()
+        return lg.detach(), torch.cat([v.grad.reshape(-1).double() for v in osd.values()])
+
+    l64, g64 = run(torch.float64)
+    l32, g32 = run(torch.float32)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    model.dropout_mask_override = masks
+    logits = model(img.to(DEV))
+    ua.SimpleLoss()(logits, tgt.to(DEV)).backward()
+    gh = torch.cat([p.grad.reshape(-1).double().cpu() for p in model.parameters()])
+    e_hip = ((gh - g64).norm() / g64.norm()).item()
+    e_ref = ((g32 - g64).norm() / g64.norm()).item()
+    assert e_hip <= max(3 * e_ref, 5e-4), f"gradient error vs fp64: hip {e_hip:.3e}, ref32 {e_ref:.3e}"
+    l_hip = relerr(logits, l64)
+    l_ref = relerr(l32, l64)
+    assert l_hip <= max(4 * l_ref, 2e-5), f"logits error vs fp64: hip {l_hip:.3e}, ref32 {l_ref:.3e}"
+
+
+def test_state_dict_roundtrip_and_eval_determinism(ua):
+    model = ua.UNet().to(DEV).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert len(sd) == 90
+    x = torch.randn(1, 3, 64, 64, device=DEV)
+    with torch.no_grad():
+        y1 = model(x)
+        y2 = model(x)
+    assert torch.equal(y1, y2)
+    other = ua.UNet().to(DEV).eval()
+    other.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(other(x), y1)
+
+
+def test_cpu_input_fails_loudly(ua):
+    model = ua.UNet()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.randn(1, 3, 64, 64))
+
+
+def test_train_step_drives_loss_down(ua):
+    torch.manual_seed(0)
+    model = ua.create_model(DEV).train()
+    opt = ua.create_optimizer(model)
+    lossf = ua.get_loss_function()
+    img, tgt = O.synthetic_batch(3, 2, 64, 64)
+    img, tgt = img.to(DEV), tgt.to(DEV)
+    losses = [ua.train_step(model, opt, lossf, img, tgt).item() for _ in range(12)]
+    assert all(np.isfinite(losses))
+    assert min(losses[-3:]) < losses[0]

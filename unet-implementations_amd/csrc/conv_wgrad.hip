@@ -148,6 +148,23 @@ __global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
       }
 }
 
+// Stage A of the slab reduction: out[c][e] = sum of slabs [16c, 16c+16) of in[.][e]
+// (fixed order).  Applied until <= 8 slabs remain so the final kernel stays shallow.
+constexpr int kSlabChunk = 16;
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ in,
+                                                          float* __restrict__ out, int split,
+                                                          long long E4) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E4) return;
+  const int c = blockIdx.y;
+  const int s0 = c * kSlabChunk;
+  const int s1 = min(s0 + kSlabChunk, split);
+  const f32x4* src = reinterpret_cast<const f32x4*>(in) + e;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = s0; k < s1; ++k) acc += src[(size_t)k * E4];
+  reinterpret_cast<f32x4*>(out)[(size_t)c * E4 + e] = acc;
+}
+
 // dw_oihw[co][ci_off+ci][tap] = sum_s partial[s][tap][ci][co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            float* __restrict__ dw, int split,
@@ -283,7 +300,8 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
     pl.stem_blocks = stem_grid(pl.stem_stages);
     pl.stem_spb = (int)ceil_div64(pl.stem_stages, pl.stem_blocks);
     pl.stem_blocks = (int)ceil_div64(pl.stem_stages, pl.stem_spb);
-    pl.ws_floats = (size_t)pl.stem_blocks * 27 * Cout;
+    pl.ws_floats = (size_t)pl.stem_blocks * 27 * Cout +
+                   2 * (size_t)ceil_div(pl.stem_blocks, kSlabChunk) * 27 * Cout;
     return pl;
   }
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -301,7 +319,9 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
   if (split < 1) split = 1;
   pl.segs_per_block = ceil_div(pl.total_segs, split);
   pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
-  pl.ws_floats = (size_t)pl.split * 9 * Cx * Cout;
+  // slabs + ping-pong room for the staged reduction (each stage shrinks 16x)
+  const size_t E = (size_t)9 * Cx * Cout;
+  pl.ws_floats = (size_t)pl.split * E + 2 * (size_t)ceil_div(pl.split, kSlabChunk) * E;
   return pl;
 }
 
@@ -373,8 +393,22 @@ extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, 
                        Cout, pl.stem_spb, pl.stem_stages);
     UNET_CHECK_LAUNCH("conv_stem_wgrad");
     const int n = 27 * Cout;
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, ws,
-                       dw_oihw, pl.stem_blocks, Cout);
+    const float* cur = ws;
+    int nslab = pl.stem_blocks;
+    float* ping = ws + (size_t)pl.stem_blocks * n;
+    float* pong = ping + (size_t)ceil_div(pl.stem_blocks, kSlabChunk) * n;
+    while (nslab > 8) {
+      const int chunks = ceil_div(nslab, kSlabChunk);
+      dim3 g((unsigned)ceil_div(n / 4, 256), chunks);
+      hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
+                         (long long)(n / 4));
+      UNET_CHECK_LAUNCH("slab_reduce(stem)");
+      cur = ping;
+      float* t = ping; ping = pong; pong = t;
+      nslab = chunks;
+    }
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, cur,
+                       dw_oihw, nslab, Cout);
     UNET_CHECK_LAUNCH("stem_wgrad_reduce");
   } else {
     WgradParams p{};
@@ -398,8 +432,23 @@ extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, 
       else rc = launch_wgrad<64, 64, 16, 2>(p, stream);
     }
     if (rc != UNET_OK) return rc;
+    const size_t E = (size_t)9 * Cx * Cout;
+    const float* cur = ws;
+    int nslab = pl.split;
+    float* ping = ws + (size_t)pl.split * E;
+    float* pong = ping + (size_t)ceil_div(pl.split, kSlabChunk) * E;
+    while (nslab > 8) {
+      const int chunks = ceil_div(nslab, kSlabChunk);
+      dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
+      hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
+                         (long long)(E / 4));
+      UNET_CHECK_LAUNCH("slab_reduce");
+      cur = ping;
+      float* t = ping; ping = pong; pong = t;
+      nslab = chunks;
+    }
     dim3 rgrid(Cout / 32, Cx / 8);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, ws, dw_oihw, pl.split, Cx,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
                        Cout, ci_offset, Cin_total);
     UNET_CHECK_LAUNCH("wgrad_reduce");
   }

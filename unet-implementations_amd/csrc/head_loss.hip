@@ -116,17 +116,29 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (tid < K * 32 + K) partial[(size_t)blockIdx.x * (K * 32 + K) + tid] = wacc;
 }
 
-__global__ void head_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                         float* __restrict__ db, int nblocks, int K) {
-  const int i = threadIdx.x;
+// one block per output column (K*32 weights then K biases): 256 threads stride the slabs,
+// fixed-order LDS tree
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                float* __restrict__ dw,
+                                                                float* __restrict__ db,
+                                                                int nblocks, int K) {
+  __shared__ float red[256];
+  const int i = blockIdx.x;
   const int cols = K * 32 + K;
-  if (i >= cols) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * cols + i];
-  if (i < K * 32) {
-    if (dw) dw[i] = s;
-  } else if (db) {
-    db[i - K * 32] = s;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(size_t)b * cols + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (i < K * 32) {
+      if (dw) dw[i] = red[0];
+    } else if (db) {
+      db[i - K * 32] = red[0];
+    }
   }
 }
 
@@ -356,8 +368,8 @@ extern "C" int unet_head1x1_bwd(const float* a, const float* dlogits, const floa
   hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dlogits,
                      w, da, partial, M, HW, K, tiles);
   UNET_CHECK_LAUNCH("head_bwd");
-  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial,
-                     dw, db, blocks, K);
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(K * 32 + K), dim3(256), 0, (hipStream_t)stream,
+                     partial, dw, db, blocks, K);
   UNET_CHECK_LAUNCH("head_bwd_finalize");
   return UNET_OK;
 }

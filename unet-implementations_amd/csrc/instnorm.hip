@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kColsumChunks = 32;
 
 __host__ __device__ inline int split_for(int N, int HW, int C) {
   // enough blocks to fill the chip (~2048) but at least 64 pixels-iterations per block
@@ -98,35 +99,44 @@ __global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restr
   }
 }
 
-// one thread per (n, c): merge the slabs, emit mean / rstd / folded affine.
-__global__ void in_stats_finalize_kernel(const float2* __restrict__ partial,
-                                         const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, float eps,
-                                         float* __restrict__ mean, float* __restrict__ rstd,
-                                         float* __restrict__ alpha, float* __restrict__ beta2,
-                                         int N, int HW, int C, int split) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i - n * C;
+// block = 32 channels x 8 lanes, grid (C/32, N): lane l merges slabs l, l+8, ... in order,
+// then the 8 lane results are merged in lane order (fixed order => deterministic).
+__global__ __launch_bounds__(256) void in_stats_finalize_kernel(
+    const float2* __restrict__ partial, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+    float* __restrict__ alpha, float* __restrict__ beta2, int N, int HW, int C, int split) {
+  __shared__ float sn[8][33], sm[8][33], sq[8][33];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
   const int per = (HW + split - 1) / split;
   float cnt = 0.f, mu = 0.f, q = 0.f;
-  for (int s = 0; s < split; ++s) {
-    const int pb = s * per;
-    int pe = pb + per;
-    if (pe > HW) pe = HW;
-    const int k = pe - pb;
-    if (k <= 0) break;
-    const float2 v = partial[((size_t)n * split + s) * C + c];
-    wf_merge(cnt, mu, q, (float)k, v.x, v.y);
+  if (c < C) {
+    for (int s = l; s < split; s += 8) {
+      const int pb = s * per;
+      int pe = pb + per;
+      if (pe > HW) pe = HW;
+      const int k = pe - pb;
+      if (k <= 0) break;
+      const float2 v = partial[((size_t)n * split + s) * C + c];
+      wf_merge(cnt, mu, q, (float)k, v.x, v.y);
+    }
   }
-  const float var = q / (float)HW;  // biased, like F.instance_norm
-  const float rs = 1.0f / sqrtf(var + eps);
-  mean[i] = mu;
-  rstd[i] = rs;
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  const float a = g * rs;
-  if (alpha) alpha[i] = a;
-  if (beta2) beta2[i] = b - mu * a;
+  sn[l][cl] = cnt; sm[l][cl] = mu; sq[l][cl] = q;
+  __syncthreads();
+  if (l == 0 && c < C) {
+    cnt = 0.f; mu = 0.f; q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wf_merge(cnt, mu, q, sn[k][cl], sm[k][cl], sq[k][cl]);
+    const int i = n * C + c;
+    const float var = q / (float)HW;  // biased, like F.instance_norm
+    const float rs = 1.0f / sqrtf(var + eps);
+    mean[i] = mu;
+    rstd[i] = rs;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float a = g * rs;
+    if (alpha) alpha[i] = a;
+    if (beta2) beta2[i] = b - mu * a;
+  }
 }
 
 // ---------------------------------------------------------------- forward apply
@@ -212,25 +222,44 @@ __global__ __launch_bounds__(kThreads) void in_bwd_reduce_kernel(
   }
 }
 
-// finalize: coef[n][c] = (S1/HW, S2/HW); dgamma[c] = sum_n S2; dbeta[c] = sum_n S1.
-// One thread per channel (loops over n and slabs; tiny).
-__global__ void in_bwd_finalize_kernel(const float2* __restrict__ partial,
-                                       float2* __restrict__ coef, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int N, int HW, int C, int split) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float dg = 0.f, db = 0.f;
-  const float inv = 1.f / (float)HW;
-  for (int n = 0; n < N; ++n) {
-    float a = 0.f, b = 0.f;
-    for (int s = 0; s < split; ++s) {
+// finalize 1: block = 32 channels x 8 lanes, grid (C/32, N): sums[n][c] = (S1, S2),
+// coef[n][c] = (S1/HW, S2/HW).
+__global__ __launch_bounds__(256) void in_bwd_finalize1_kernel(const float2* __restrict__ partial,
+                                                               float2* __restrict__ coef,
+                                                               float2* __restrict__ sums, int HW,
+                                                               int C, int split) {
+  __shared__ float sa[8][33], sb[8][33];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (int s = l; s < split; s += 8) {
       const float2 v = partial[((size_t)n * split + s) * C + c];
       a += v.x;
       b += v.y;
     }
+  sa[l][cl] = a; sb[l][cl] = b;
+  __syncthreads();
+  if (l == 0 && c < C) {
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+    const float inv = 1.f / (float)HW;
     coef[(size_t)n * C + c] = float2{a * inv, b * inv};
-    db += a;
-    dg += b;
+    sums[(size_t)n * C + c] = float2{a, b};
+  }
+}
+
+// finalize 2: dgamma[c] = sum_n S2[n][c]; dbeta[c] = sum_n S1[n][c]
+__global__ void in_bwd_finalize2_kernel(const float2* __restrict__ sums, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, int N, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float dg = 0.f, db = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float2 v = sums[(size_t)n * C + c];
+    db += v.x;
+    dg += v.y;
   }
   if (dgamma) dgamma[c] = dg;
   if (dbeta) dbeta[c] = db;
@@ -296,13 +325,26 @@ __global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
   }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int rows,
-                              int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[chunk][c] = sum of rows [chunk*rpc, (chunk+1)*rpc) of partial[.][c]; block = 32 c x 8 lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial,
+                                                     float* __restrict__ out, int rows, int C,
+                                                     int rows_per_chunk) {
+  __shared__ float sa[8][33];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(r0 + rows_per_chunk, rows);
   float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += partial[(size_t)r * C + c];
-  out[c] = a;
+  if (c < C)
+    for (int r = r0 + l; r < r1; r += 8) a += partial[(size_t)r * C + c];
+  sa[l][cl] = a;
+  __syncthreads();
+  if (l == 0 && c < C) {
+    a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += sa[k][cl];
+    out[(size_t)blockIdx.y * C + c] = a;
+  }
 }
 
 bool shape_ok(int N, int HW, int C) {
@@ -314,10 +356,12 @@ bool shape_ok(int N, int HW, int C) {
 extern "C" size_t unet_instnorm_workspace_bytes(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0) return 0;
   const int split = split_for(N, HW, C);
-  // slabs (float2) + bwd coef (float2 [N][C]) + dbias slabs (float)
+  // slabs (float2) + bwd coef and raw sums (float2 [N][C] each) + dbias slabs (float) +
+  // one row-chunk stage of the dbias column sum
   return align_up((size_t)N * split * C * sizeof(float2), 256) +
-         align_up((size_t)N * C * sizeof(float2), 256) +
-         align_up((size_t)N * split * C * sizeof(float), 256);
+         2 * align_up((size_t)N * C * sizeof(float2), 256) +
+         align_up((size_t)N * split * C * sizeof(float), 256) +
+         align_up((size_t)kColsumChunks * C * sizeof(float), 256);
 }
 
 extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const float* beta, float eps,
@@ -339,7 +383,7 @@ extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const flo
   hipLaunchKernelGGL(in_stats_kernel, dim3(split, N), dim3(kThreads), lds, stream, y, partial, HW,
                      C, split);
   UNET_CHECK_LAUNCH("in_stats");
-  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(N * C, 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(256), 0, stream,
                      partial, gamma, beta, eps, mean, rstd, alpha, beta2, N, HW, C, split);
   UNET_CHECK_LAUNCH("in_stats_finalize");
   return UNET_OK;
@@ -382,21 +426,39 @@ extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, con
   ws += align_up((size_t)N * split * C * sizeof(float2), 256);
   float2* coef = reinterpret_cast<float2*>(ws);
   ws += align_up((size_t)N * C * sizeof(float2), 256);
+  float2* sums = reinterpret_cast<float2*>(ws);
+  ws += align_up((size_t)N * C * sizeof(float2), 256);
   float* dbp = reinterpret_cast<float*>(ws);
+  ws += align_up((size_t)N * split * C * sizeof(float), 256);
+  float* dbstage = reinterpret_cast<float*>(ws);
   const size_t lds2 = (size_t)groups * 2 * C * sizeof(float);
   hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(split, N), dim3(kThreads), lds2, stream, ga, y,
                      mean, rstd, gamma, beta, mask, slope, partial, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_reduce");
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, partial,
-                     coef, dgamma, dbeta, N, HW, C, split);
-  UNET_CHECK_LAUNCH("in_bwd_finalize");
+  hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(256), 0, stream,
+                     partial, coef, sums, HW, C, split);
+  UNET_CHECK_LAUNCH("in_bwd_finalize1");
+  hipLaunchKernelGGL(in_bwd_finalize2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, sums,
+                     dgamma, dbeta, N, C);
+  UNET_CHECK_LAUNCH("in_bwd_finalize2");
   const size_t lds1 = (size_t)groups * C * sizeof(float);
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(split, N), dim3(kThreads), lds1, stream, ga, y, mean,
                      rstd, gamma, beta, mask, slope, coef, dy, dbias ? dbp : nullptr, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_apply");
   if (dbias) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, dbp, dbias,
-                       N * split, C);
+    const int rows = N * split;
+    if (rows <= 64) {
+      hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32), 1), dim3(256), 0, stream, dbp, dbias,
+                         rows, C, rows);
+    } else {
+      const int rpc = ceil_div(rows, kColsumChunks);
+      const int chunks = ceil_div(rows, rpc);
+      hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32), chunks), dim3(256), 0, stream, dbp,
+                         dbstage, rows, C, rpc);
+      UNET_CHECK_LAUNCH("dbias_colsum(stage)");
+      hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32), 1), dim3(256), 0, stream, dbstage,
+                         dbias, chunks, C, chunks);
+    }
     UNET_CHECK_LAUNCH("dbias_colsum");
   }
   return UNET_OK;

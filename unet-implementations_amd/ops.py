@@ -13,6 +13,44 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event timing of the matrix-core kernels, recorded on the stream the kernels are
+    launched on (torch's current stream).  bench.py installs one over its timed region to
+    report `roofline.achieved` = algorithmic FLOPs / measured kernel time."""
+
+    def __init__(self):
+        self.records = []  # (tag, flops, launches, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, tag, flops, launches, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((tag, flops, launches, start, ev))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, flops, launches, e0, e1 in self.records:
+            d = out.setdefault(tag, dict(flops=0.0, ms=0.0, launches=0, calls=0))
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += launches
+            d["calls"] += 1
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -70,8 +108,12 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None):
     assert wf.shape[0] == 9 and wf.shape[1] == C0 + C1
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = out if out is not None else _f32((N, Ho, Wo, Cout), x0)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_conv3x3_fwd(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(bias), _ptr(y), N, H,
                                  W, Cout, stride, _stream()))
+    if t0 is not None:
+        _timer.end("conv_stem_fwd" if C0 == 3 else "conv_igemm",
+                   2.0 * N * Ho * Wo * 9 * (C0 + C1) * Cout, 1, t0)
     return y
 
 
@@ -83,8 +125,11 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
     wptr = _ptr(wd) + 4 * ci_offset
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_conv3x3_bwd_data(_ptr(dy), wptr, cin_total, _ptr(dx), N, H, W, Cout, ccols,
                                       stride, 1 if accumulate else 0, _stream()))
+    if t0 is not None:  # stride 2 runs one launch per output parity class
+        _timer.end("conv_igemm", 2.0 * N * Ho * Wo * 9 * ccols * Cout, 4 if stride == 2 else 1, t0)
     return dx
 
 
@@ -95,9 +140,14 @@ def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None):
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     nbytes = lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride)
     ws = _ws(nbytes, x)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_conv3x3_bwd_weight(_ptr(x), Cx, _ptr(dy), _ptr(dw_oihw), ci_offset,
                                         cin_total, _ptr(db), _ptr(ws), ws.numel(), N, H, W, Cout,
                                         stride, _stream()))
+    if t0 is not None:  # wgrad kernel + slab reduce
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        _timer.end("conv_stem_wgrad" if Cx == 3 else "conv_wgrad",
+                   2.0 * N * Ho * Wo * 9 * Cx * Cout, 2, t0)
     return dw_oihw
 
 

@@ -192,6 +192,9 @@ class UNet(nn.Module):
         self._grad_arena = None  # flat fp32 gradient arena (p.grad are views into it)
         self._offsets = None
         self.dropout_mask_override = None  # test hook: list of [N, C] masks in forward order
+        # data-parallel hook: called during backward as `hook(lo)` once every gradient at arena
+        # offsets >= lo is final (backward completes the arena back to front)
+        self.grad_ready_hook = None
 
     # -- reference: Our_UNet/models/unet.py:386-397 --------------------------------------
     def initialize_weights(self):
@@ -388,13 +391,26 @@ class _UNetFunction(torch.autograd.Function):
         n_enc_layers = sum(len(b) for b in enc)
         idx = len(saved) - 1
         skip_grads = {}
+        hook = model.grad_ready_hook
+
+        def ready(module):
+            if hook is not None:
+                first = next(module.parameters())
+                hook(model._offsets[model._param_index[id(first)]])
+
+        ready(head)
 
         def layer_bwd(rec, g_a, dx0_out=None, dx0_acc=False, need_dx=True):
             l = rec["layer"]
             st = rec["st"]
+            dbg = getattr(model, "_debug_capture", None)
+            if dbg is not None:
+                dbg.append((l.name, "ga", g_a.clone()))
             dy = ops.instnorm_lrelu_drop_bwd(g_a, rec["y"], st[0], st[1], l.norm.weight.detach(),
                                              l.norm.bias.detach(), rec["mask"], l.slope,
                                              gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias))
+            if dbg is not None:
+                dbg.append((l.name, "dy", dy.clone()))
             x0, x1 = rec["x0"], rec["x1"]
             dw = gv(l.conv.weight)
             ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride)
@@ -419,13 +435,10 @@ class _UNetFunction(torch.autograd.Function):
             idx -= 1
             skip_grads[len(enc) - 2 - di] = g_skip
             g = ops.upsample2x_bwd(g_up)
+            ready(model.decoder_stages[di])
         # encoder stages, last to first
         for bi in range(len(enc) - 1, -1, -1):
             blk = enc[bi]
-            if bi < len(enc) - 1:
-                # g currently holds the gradient from encoder stage bi+1 accumulated into the
-                # decoder's skip gradient (see below)
-                pass
             for li in range(len(blk) - 1, -1, -1):
                 rec = saved[idx]
                 idx -= 1
@@ -439,6 +452,7 @@ class _UNetFunction(torch.autograd.Function):
                     g, _ = layer_bwd(rec, g, dx0_out=skip_grads.pop(bi - 1), dx0_acc=True)
                 else:
                     g, _ = layer_bwd(rec, g)
+            ready(model.encoder_stages[bi])
         assert idx == -1 and n_enc_layers > 0
         ctx.saved = None
         grads = [gv(p) if p.requires_grad else None for p in params]
