@@ -17,8 +17,8 @@
  *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*).
  *   - activations are NHWC fp32 ("pixel-major": [N][H][W][C]); logits and the
  *     input image cross the module boundary as NCHW, exactly like the reference.
- *   - packed 3x3 weights: wf[tap][ci][co] (forward / B operand of the implicit
- *     GEMM) and wd[tap][co][ci] (data gradient), tap = ky*3+kx.
+ *   - packed 3x3 weights, tap = ky*3+kx, the GEMM's reduction axis contiguous:
+ *     wf[tap][co][ci] (forward: K = ci) and wd[tap][ci][co] (data gradient: K = co).
  */
 #ifndef UNET_HIP_H_
 #define UNET_HIP_H_
@@ -54,7 +54,7 @@ int unet_nhwc_to_nchw(const float* x_nhwc, float* y_nchw, int N, int C, int H, i
                       unet_stream_t stream);
 
 /* OIHW [Cout][Cin][3][3] (state_dict layout, Our_UNet/models/unet.py:106-115)
- * -> wf[9][Cin][Cout] and wd[9][Cout][Cin]; either output may be NULL. */
+ * -> wf[9][Cout][Cin] and wd[9][Cin][Cout]; either output may be NULL. */
 int unet_pack_conv3x3_weights(const float* w_oihw, float* wf, float* wd, int Cout, int Cin,
                               unet_stream_t stream);
 
@@ -66,24 +66,22 @@ int unet_pack_conv3x3_weights(const float* w_oihw, float* wf, float* wd, int Cou
  * input (x1 may be NULL with C1 = 0).  H, W are the INPUT spatial sizes;
  * Ho = (H-1)/stride+1.  C0 == 3 (RGB stem) or C0, C1 multiples of 32;
  * Cout multiple of 32.
- *
- * Fused InstanceNorm statistics (optional): if stats_partial != NULL the
- * epilogue also writes, per 32-pixel row group of each tile, the per-channel
- * (mean, M2) pair consumed by unet_instnorm_finalize; see
- * unet_conv3x3_fwd_stats_rows(). */
+ */
 int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1, const float* wf,
                      const float* bias, float* y, int N, int H, int W, int Cout, int stride,
                      unet_stream_t stream);
 
 /* dx[N][H][W][Ccols] (+)= conv3x3_transpose(dy[N][Ho][Wo][Cout], wd slice).
  * Replaces the data-gradient half of aten::convolution_backward reached from
- * loss.backward() (Our_UNet/src/train.py:663).  `wd` points at the first
- * column of the slice inside wd[9][Cout][ldw]; Ccols is the slice width (the
- * channel count of dx).  H, W are the spatial sizes of dx (the conv INPUT).
- * accumulate != 0 adds into dx (skip tensors receive two gradients). */
-int unet_conv3x3_bwd_data(const float* dy, const float* wd, int ldw, float* dx, int N, int H,
-                          int W, int Cout, int Ccols, int stride, int accumulate,
-                          unet_stream_t stream);
+ * loss.backward() (Our_UNet/src/train.py:663).  wd is the whole
+ * wd[9][Cin_total][Cout]; the call produces input channels
+ * [ci_offset, ci_offset + Ccols) into dx, whose channel count is Ccols (the two
+ * halves of a concatenated input are two calls).  H, W are the spatial sizes of
+ * dx (the conv INPUT).  accumulate != 0 adds into dx (skip tensors receive two
+ * gradients). */
+int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_total, int ci_offset,
+                          float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
+                          int accumulate, unet_stream_t stream);
 
 /* dw_oihw[Cout][Cin_total][3][3] (columns ci_offset .. ci_offset+Cx) =
  *   sum over pixels of x[.., Cx] (x) dy[.., Cout]; db[Cout] = sum dy if db != NULL.

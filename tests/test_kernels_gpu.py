@@ -49,8 +49,8 @@ def test_layout_roundtrip(ua):
 def test_pack_weights(ua):
     w = rnd(64, 32, 3, 3, seed=2)
     wf, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
-    assert torch.equal(wf.cpu(), w.permute(2, 3, 1, 0).reshape(9, 32, 64))
-    assert torch.equal(wd.cpu(), w.permute(2, 3, 0, 1).reshape(9, 64, 32))
+    assert torch.equal(wf.cpu(), w.permute(2, 3, 0, 1).reshape(9, 64, 32))   # [tap][co][ci]
+    assert torch.equal(wd.cpu(), w.permute(2, 3, 1, 0).reshape(9, 32, 64))   # [tap][ci][co]
 
 
 # --------------------------------------------------------------------------- conv forward

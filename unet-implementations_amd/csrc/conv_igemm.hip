@@ -18,14 +18,14 @@
 
 namespace {
 
-constexpr int kMaxTaps = 9;
-
 struct IgemmParams {
   const float* src0;
   const float* src1;
   int C0, C1;        // channels of the two (virtually concatenated) sources
-  const float* w;    // packed weights, row (tap*Ktot + k), column stride 1, row stride ldw
-  int ldw;
+  const float* w;    // packed weights [tap][n][k]: w[tap*tap_stride + (n_off + n)*Ktot + k]
+  int tap_stride;
+  int n_off;
+  unsigned src0_bytes, src1_bytes, w_bytes;  // buffer-descriptor ranges (each < 2 GiB)
   const float* bias; // [Ncols] or nullptr
   float* out;
   int ldo;           // channel count of the output tensor
@@ -36,20 +36,27 @@ struct IgemmParams {
   int sin;           // input coordinate = a*sin + off
   int sout, py, px;  // output coordinate = a*sout + py
   int ntaps;
-  int offy[kMaxTaps], offx[kMaxTaps], wtap[kMaxTaps];
+  // tap table packed 8 bits per tap (4 taps per word): bits 0-1 = offy+1, 2-3 = offx+1,
+  // 4-7 = weight tap index.  Lives in SGPRs: no scalar-memory load per K step.
+  unsigned tapw[3];
   int Ncols;
 };
+
+inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
+  const unsigned e = (unsigned)(oy + 1) | ((unsigned)(ox + 1) << 2) | ((unsigned)wt << 4);
+  p.tapw[t >> 2] |= e << ((t & 3) * 8);
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int BK = 32;
-  constexpr int LDA = BK + 4;  // 144-B rows: conflict-free ds_read_b128 across 16 pixel rows
+  constexpr int LDA = BK + 4;  // 144-B rows: conflict-free ds_read_b128 across 16 rows
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
   constexpr int A_PASSES = BM / 32;
-  constexpr int B_PER_THREAD = (BK * BN / 4) / 256;
-  constexpr int A_TILE = BM * LDA, B_TILE = BK * BN;
+  constexpr int B_PASSES = BN / 32;
+  constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * A_TILE;
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   const int M = p.N * HlWl;
   const int Ktot = p.C0 + p.C1;
 
-  // ---- A loader: thread -> (row lrow + 32*i, 16-B segment lseg) ----
+  // ---- loaders: thread -> (row lrow + 32*i, 16-B segment lseg) for both tiles ----
   const int lrow = tid >> 3, lseg = tid & 7;
   int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
 #pragma unroll
@@ -86,16 +93,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
       a_ix[i] = 0;
     }
   }
-  // ---- B loader ----
-  int b_row[B_PER_THREAD], b_c4[B_PER_THREAD];
-#pragma unroll
-  for (int j = 0; j < B_PER_THREAD; ++j) {
-    const int idx = tid + 256 * j;
-    b_row[j] = idx / (BN / 4);
-    b_c4[j] = idx - b_row[j] * (BN / 4);
-  }
+  // Buffer descriptors: out-of-range lanes (zero padding, rows past M) get an offset beyond
+  // num_records and read 0 with no branch, so the K loop is one basic block.
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  // weight rows of this thread: ((n_off + n0 + lrow + 32*j) * Ktot + lseg*4) floats
+  const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
 
-  f32x4 ra[A_PASSES], rb[B_PER_THREAD];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[A_PASSES], rb[B_PASSES];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -107,80 +117,103 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   const int KS = p.ntaps * (Ktot / BK);
 
   auto load_tiles = [&](int t, int chunk) {
-    const int oy = p.offy[t], ox = p.offx[t];
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const int wt = (int)(e >> 4);
     const int c = chunk * BK;
-    const float* src;
-    int Cs, coff;
-    if (c < p.C0) {
-      src = p.src0; Cs = p.C0; coff = c;
-    } else {
-      src = p.src1; Cs = p.C1; coff = c - p.C0;
-    }
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
       const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok)
-        v = *reinterpret_cast<const f32x4*>(
-            src + (size_t)(a_nb[i] + iy * p.Win + ix) * Cs + coff + lseg * 4);
-      ra[i] = v;
+      // invalid lanes get bit 31 set: beyond num_records (< 2 GiB), the load returns 0
+      const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
     }
-    const float* wrow = p.w + ((size_t)p.wtap[t] * Ktot + c) * p.ldw + n0;
+    const unsigned woff = wrow_off + (unsigned)(wt * p.tap_stride + c) * 4u;
 #pragma unroll
-    for (int j = 0; j < B_PER_THREAD; ++j)
-      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)b_row[j] * p.ldw + b_c4[j] * 4);
+    for (int j = 0; j < B_PASSES; ++j) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (unsigned)(32 * j * Ktot) * 4u, 0, 0);
+      rb[j] = __builtin_bit_cast(f32x4, v);
+    }
   };
   auto store_tiles = [&](int buf) {
-    float* Ab = As + buf * A_TILE;
-    float* Bb = Bs + buf * B_TILE;
+    float* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
+    float* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i)
-      *reinterpret_cast<f32x4*>(Ab + (lrow + 32 * i) * LDA + lseg * 4) = ra[i];
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + 32 * i * LDA) = ra[i];
 #pragma unroll
-    for (int j = 0; j < B_PER_THREAD; ++j)
-      *reinterpret_cast<f32x4*>(Bb + b_row[j] * BN + b_c4[j] * 4) = rb[j];
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + 32 * j * LDA) = rb[j];
   };
 
   int t_next = 0, chunk_next = 0;
-  auto advance = [&]() {
-    if (++t_next == p.ntaps) { t_next = 0; ++chunk_next; }
+  auto advance = [&](bool on) {  // branch-free: keeps the K step a single basic block
+    const int tn = t_next + 1;
+    const bool wrap = tn == p.ntaps;
+    t_next = on ? (wrap ? 0 : tn) : t_next;
+    chunk_next = on ? chunk_next + (wrap ? 1 : 0) : chunk_next;
   };
 
   load_tiles(t_next, chunk_next);
-  advance();
+  advance(KS > 1);
   store_tiles(0);
   __syncthreads();
 
+  // fragment addresses: lane (li, lh) reads 4 consecutive k at row li, k offset 4*lh.
+  // MFMA r of a k-group of 8 then multiplies k = kb + 4*lh + r on both operands.
+  const int frag_off = li * LDA + 4 * lh;
   for (int ks = 0; ks < KS; ++ks) {
     const int buf = ks & 1;
-    const bool more = (ks + 1 < KS);
-    if (more) {
-      load_tiles(t_next, chunk_next);
-      advance();
-    }
-    const float* Ab = As + buf * A_TILE + wm0 * LDA;
-    const float* Bb = Bs + buf * B_TILE + wn0;
+    // Always stage a tile (the last iteration re-stages the final one into the idle buffer):
+    // no branch, so the whole K step is one scheduling region.
+    load_tiles(t_next, chunk_next);
+    advance(ks + 2 < KS);
+    const float* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
+    const float* Bb = Bs + buf * B_TILE + wn0 * LDA + frag_off;
+    f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-    for (int kb = 0; kb < BK; kb += 8) {
-      f32x4 a[TM];
-      float b[TN][4];
+    for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDA);
 #pragma unroll
-      for (int m = 0; m < TM; ++m)
-        a[m] = *reinterpret_cast<const f32x4*>(Ab + (m * 32 + li) * LDA + kb + 4 * lh);
+    for (int n = 0; n < TN; ++n) b[0][n] = *reinterpret_cast<const f32x4*>(Bb + n * 32 * LDA);
 #pragma unroll
-      for (int n = 0; n < TN; ++n)
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[n][r] = Bb[(kb + 4 * lh + r) * BN + n * 32 + li];
+        for (int m = 0; m < TM; ++m)
+          a[nxt][m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDA + (kk + 1) * 8);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          b[nxt][n] = *reinterpret_cast<const f32x4*>(Bb + n * 32 * LDA + (kk + 1) * 8);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][r], b[n][r], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][n][r], acc[m][n],
+                                                             0, 0, 0);
     }
-    if (more) store_tiles(buf ^ 1);
+    store_tiles(buf ^ 1);
+    // Pin the software pipeline (hipcc otherwise sinks every read to just before its first
+    // use): fragment reads run one k-group ahead of the MFMAs, the next tile's buffer loads
+    // issue behind the first MFMA group, the LDS writes of the staged tile come last.
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
+#pragma unroll
+    for (int kk = 1; kk < BK / 8; ++kk) {
+      if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
     __syncthreads();
   }
 
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   constexpr int BK = 32, LDA = BK + 4;
-  constexpr size_t lds = 2 * (size_t)(BM * LDA + BK * BN) * sizeof(float);
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDA * sizeof(float);
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
   if (!attr_set) {
@@ -270,8 +303,8 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const float* __restr
   const int co0 = blockIdx.y * 32;
 
   for (int i = tid; i < 28 * 32; i += 256) {
-    const int k = i >> 5, c = i & 31;
-    B[i] = (k < 27) ? wf[k * Cout + co0 + c] : 0.f;
+    const int k = i >> 5, c = i & 31;  // k = tap*3 + ci; wf is [tap][co][ci]
+    B[i] = (k < 27) ? wf[((k / 3) * Cout + co0 + c) * 3 + (k % 3)] : 0.f;
   }
   // im2col gather: item = (pixel, tap) -> 3 channels
   for (int it = tid; it < STEM_PIX * 9; it += 256) {
@@ -321,11 +354,8 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const float* __restr
 
 void fill_fwd_taps(IgemmParams& p, int stride) {
   p.ntaps = 9;
-  for (int t = 0; t < 9; ++t) {
-    p.offy[t] = t / 3 - 1;
-    p.offx[t] = t % 3 - 1;
-    p.wtap[t] = t;
-  }
+  p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
+  for (int t = 0; t < 9; ++t) set_tap(p, t, t / 3 - 1, t % 3 - 1, t);
   p.sin = stride;
   p.sout = 1;
   p.py = p.px = 0;
@@ -355,7 +385,13 @@ extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1
   UNET_REQUIRE(C1 == 0 || x1, "conv3x3_fwd: x1 is null with C1=%d", C1);
   IgemmParams p{};
   p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1;
-  p.w = wf; p.ldw = Cout; p.bias = bias;
+  p.w = wf; p.tap_stride = Cout * (C0 + C1); p.n_off = 0; p.bias = bias;
+  UNET_REQUIRE((long long)N * H * W * (C0 > C1 ? C0 : C1) * 4 < (1LL << 31) &&
+                   (long long)9 * Cout * (C0 + C1) * 4 < (1LL << 31),
+               "conv3x3_fwd: tensor exceeds the 2 GiB buffer-descriptor range");
+  p.src0_bytes = (unsigned)((long long)N * H * W * C0 * 4);
+  p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 4);
+  p.w_bytes = (unsigned)((long long)9 * Cout * (C0 + C1) * 4);
   p.out = y; p.ldo = Cout; p.accumulate = 0;
   p.N = N; p.Hin = H; p.Win = W;
   p.Hl = p.Hout = (H - 1) / stride + 1;
@@ -365,20 +401,29 @@ extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1
   return dispatch_igemm(p, stream);
 }
 
-extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int ldw, float* dx, int N,
-                                     int H, int W, int Cout, int Ccols, int stride, int accumulate,
+extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_total,
+                                     int ci_offset, float* dx, int N, int H, int W, int Cout,
+                                     int Ccols, int stride, int accumulate,
                                      unet_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_data: stride %d unsupported", stride);
-  UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ldw >= Ccols,
-               "conv3x3_bwd_data: bad channel counts Cout=%d Ccols=%d ldw=%d", Cout, Ccols, ldw);
+  UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
+                   ci_offset + Ccols <= Cin_total,
+               "conv3x3_bwd_data: bad channel counts Cout=%d Ccols=%d slice %d of %d", Cout, Ccols,
+               ci_offset, Cin_total);
   UNET_REQUIRE(stride == 1 || (H % 2 == 0 && W % 2 == 0),
                "conv3x3_bwd_data: stride 2 needs even H, W");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   IgemmParams p{};
   p.src0 = dy; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
-  p.w = wd; p.ldw = ldw; p.bias = nullptr;
+  p.w = wd; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
+  UNET_REQUIRE((long long)N * Ho * Wo * Cout * 4 < (1LL << 31) &&
+                   (long long)9 * Cout * Cin_total * 4 < (1LL << 31),
+               "conv3x3_bwd_data: tensor exceeds the 2 GiB buffer-descriptor range");
+  p.src0_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
+  p.src1_bytes = 0;
+  p.w_bytes = (unsigned)((long long)9 * Cout * Cin_total * 4);
   p.out = dx; p.ldo = Ccols; p.accumulate = accumulate;
   p.N = N; p.Hin = Ho; p.Win = Wo;
   p.Hout = H; p.Wout = W;
@@ -387,11 +432,8 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int ldw, 
   if (stride == 1) {
     p.Hl = H; p.Wl = W; p.sout = 1; p.py = p.px = 0;
     p.ntaps = 9;
-    for (int t = 0; t < 9; ++t) {
-      p.offy[t] = 1 - t / 3;
-      p.offx[t] = 1 - t % 3;
-      p.wtap[t] = t;
-    }
+    p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
+    for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
     return dispatch_igemm(p, stream);
   }
   // stride 2: dx[2a+py][2b+px] = sum over ky with (py+1-ky) even of dy[a + (py+1-ky)/2][..]
@@ -399,14 +441,13 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int ldw, 
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       p.py = py; p.px = px;
+      p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
       int nt = 0;
       for (int ky = 0; ky < 3; ++ky) {
         if ((py + 1 - ky) & 1) continue;
         for (int kx = 0; kx < 3; ++kx) {
           if ((px + 1 - kx) & 1) continue;
-          p.offy[nt] = (py + 1 - ky) / 2;
-          p.offx[nt] = (px + 1 - kx) / 2;
-          p.wtap[nt] = ky * 3 + kx;
+          set_tap(p, nt, (py + 1 - ky) / 2, (px + 1 - kx) / 2, ky * 3 + kx);
           ++nt;
         }
       }

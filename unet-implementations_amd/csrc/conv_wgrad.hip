@@ -118,18 +118,36 @@ __global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
       if (more) load_stage(g + 1);
       const float* P = smem + buf * STAGE + (tap_u * PW + tap_v) * CI_T;
       const float* D = smem + buf * STAGE + PATCH;
-#pragma unroll 4
-      for (int xx = 0; xx < S; xx += 2) {
-        float a[TI], b[TJ];
+      // operand fragments double-buffered in registers: the reads of pixel pair q+1 are in
+      // flight while the MFMAs of pair q issue
+      float a[2][TI], b[2][TJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) a[i] = P[((xx + lh) * STRIDE) * CI_T + i * 32 + li];
+      for (int i = 0; i < TI; ++i) a[0][i] = P[(lh * STRIDE) * CI_T + i * 32 + li];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) b[j] = D[(xx + lh) * CO_T + j * 32 + li];
+      for (int j = 0; j < TJ; ++j) b[0][j] = D[lh * CO_T + j * 32 + li];
+#pragma unroll
+      for (int q = 0; q < S / 2; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        if (q + 1 < S / 2) {
+          const int xx = 2 * (q + 1) + lh;
+#pragma unroll
+          for (int i = 0; i < TI; ++i) a[nxt][i] = P[(xx * STRIDE) * CI_T + i * 32 + li];
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) b[nxt][j] = D[xx * CO_T + j * 32 + li];
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j < TJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      }
+      // pin the pipeline: the two LDS reads (ds_read_b32 / ds_read2_b32) of pair q+1 are
+      // issued ahead of the MFMAs of pair q
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int q = 0; q < S / 2; ++q) {
+        if (q + 1 < S / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ, 0);
       }
       if (more) store_stage(buf ^ 1);
       __syncthreads();

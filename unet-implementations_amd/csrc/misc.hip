@@ -51,23 +51,24 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restri
 }
 
 // ---- weight packing -----------------------------------------------------------
-// wf[t][ci][co] and wd[t][co][ci] from w[co][ci][t]
+// wf[t][co][ci] (forward: K = ci contiguous) and wd[t][ci][co] (dgrad: K = co contiguous)
+// from w[co][ci][t]
 __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ wf,
                               float* __restrict__ wd, int Cout, int Cin) {
   const long long total = (long long)9 * Cin * Cout;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    if (wf) {  // i = (t*Cin + ci)*Cout + co
+    if (wd) {  // i = (t*Cin + ci)*Cout + co
       const int co = (int)(i % Cout);
       const long long r = i / Cout;
       const int ci = (int)(r % Cin), t = (int)(r / Cin);
-      wf[i] = w[((size_t)co * Cin + ci) * 9 + t];
+      wd[i] = w[((size_t)co * Cin + ci) * 9 + t];
     }
-    if (wd) {  // i = (t*Cout + co)*Cin + ci
+    if (wf) {  // i = (t*Cout + co)*Cin + ci
       const int ci = (int)(i % Cin);
       const long long r = i / Cin;
       const int co = (int)(r % Cout), t = (int)(r / Cout);
-      wd[i] = w[((size_t)co * Cin + ci) * 9 + t];
+      wf[i] = w[((size_t)co * Cin + ci) * 9 + t];
     }
   }
 }

@@ -91,9 +91,9 @@ def pack_conv3x3_weights(w_oihw, wf=None, wd=None, want_wd=True):
     Cout, Cin, kh, kw = w_oihw.shape
     assert kh == 3 and kw == 3
     if wf is None:
-        wf = _f32((9, Cin, Cout), w_oihw)
+        wf = _f32((9, Cout, Cin), w_oihw)   # forward: reduction axis (ci) contiguous
     if wd is None and want_wd:
-        wd = _f32((9, Cout, Cin), w_oihw)
+        wd = _f32((9, Cin, Cout), w_oihw)   # data gradient: reduction axis (co) contiguous
     check(lib().unet_pack_conv3x3_weights(_ptr(w_oihw), _ptr(wf), _ptr(wd), Cout, Cin, _stream()))
     return wf, wd
 
@@ -104,8 +104,8 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None):
     C1 = 0 if x1 is None else x1.shape[3]
     if x1 is not None:
         assert x1.shape[:3] == x0.shape[:3]
-    Cout = wf.shape[2]
-    assert wf.shape[0] == 9 and wf.shape[1] == C0 + C1
+    Cout = wf.shape[1]
+    assert wf.shape[0] == 9 and wf.shape[2] == C0 + C1
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = out if out is not None else _f32((N, Ho, Wo, Cout), x0)
     t0 = _timer.begin() if _timer is not None else None
@@ -118,16 +118,15 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None):
 
 
 def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False):
-    """dx[N,H,W,ccols] (+)= transpose-conv of dy with columns [ci_offset, ci_offset+ccols) of wd."""
+    """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols)."""
     N, Ho, Wo, Cout = dy.shape
-    cin_total = wd.shape[2]
-    assert wd.shape[0] == 9 and wd.shape[1] == Cout
+    cin_total = wd.shape[1]
+    assert wd.shape[0] == 9 and wd.shape[2] == Cout
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
-    wptr = _ptr(wd) + 4 * ci_offset
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv3x3_bwd_data(_ptr(dy), wptr, cin_total, _ptr(dx), N, H, W, Cout, ccols,
-                                      stride, 1 if accumulate else 0, _stream()))
+    check(lib().unet_conv3x3_bwd_data(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N, H, W,
+                                      Cout, ccols, stride, 1 if accumulate else 0, _stream()))
     if t0 is not None:  # stride 2 runs one launch per output parity class
         _timer.end("conv_igemm", 2.0 * N * Ho * Wo * 9 * ccols * Cout, 4 if stride == 2 else 1, t0)
     return dx
