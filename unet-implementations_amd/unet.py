@@ -257,6 +257,13 @@ class UNet(nn.Module):
         self._plan = (enc, dec)
         return self._plan
 
+    def check_supported(self):
+        """Raise NotImplementedError unless this configuration is covered by the HIP path
+        (3x3 / pad 1 / stride 1|2 convs with bias, InstanceNorm2d(affine), LeakyReLU,
+        optional SpatialDropout2d, 32 -> 3 head).  Works without a GPU."""
+        self._build_plan()
+        return True
+
     # -- flat parameter / gradient arenas -------------------------------------------------------
     def _ensure_arena(self):
         params = list(self.parameters())
