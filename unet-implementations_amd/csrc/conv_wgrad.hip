@@ -1,8 +1,9 @@
 // conv_wgrad.hip — 3x3 convolution weight gradient on the fp32 matrix cores.
 //
 // dW[tap][ci][co] = sum over output pixels p of x[p @ tap][ci] * dy[p][co].
-// One workgroup = 9 waves, wave w owns tap w; the block owns a (CI_T x CO_T)
-// channel tile and a contiguous range of output-row segments of S pixels.  Per
+// One workgroup = 4 waves; each wave owns one 32x32 (ci,co) sub-block for all nine taps; the
+// block owns a (CI_T x CO_T) channel tile and a contiguous range of output-row segments of
+// S pixels.  Per
 // segment the 3-row input halo patch [3][(S-1)*stride+3][CI_T] and the dy
 // segment [S][CO_T] are register-staged into double-buffered LDS once and
 // shared by all 9 taps (each input element is fetched ~1.1x instead of 9x).
@@ -26,22 +27,35 @@ struct WgradParams {
   int N, H, W, Ho, Wo;
   int segs_per_row, total_segs, segs_per_block, split;
   int ci_tiles, co_tiles;
+  unsigned x_bytes, dy_bytes;  // buffer-descriptor ranges (< 2 GiB each)
 };
 
+// Workgroup = 4 waves (one per SIMD, so co-resident workgroups load every SIMD alike).
+// The (CI_T x CO_T) tile has NSB = (CI_T/32)*(CO_T/32) 32x32 sub-blocks; wave w owns
+// sub-block w % NSB for ALL nine taps (9 accumulator blocks = 144 VGPRs) and, when NSB < 4,
+// the pixel pairs q = w / NSB (mod NPP) of each segment - its sums then go to a slab of
+// their own (slab index sp*NPP + pp), folded by the ordinary slab reduction.
 template <int CI_T, int CO_T, int S, int STRIDE>
-__global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
-  constexpr int PW = (S - 1) * STRIDE + 3;
-  constexpr int PATCH = 3 * PW * CI_T;
-  constexpr int DYT = S * CO_T;
-  constexpr int STAGE = PATCH + DYT;
-  constexpr int NP4 = PATCH / 4, ND4 = DYT / 4;
-  constexpr int NL = (NP4 + ND4 + 575) / 576;
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
+  constexpr int NSB = TI * TJ, NPP = 4 / NSB;
+  static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
+  constexpr int NT = 256;
+  constexpr int PW = (S - 1) * STRIDE + 3;
+  constexpr int NP4 = 3 * PW * CI_T / 4;   // float4 slots of the patch
+  constexpr int ND4 = S * CO_T / 4;        // float4 slots of the dy segment
+  constexpr int PATCH = NP4 * 4;           // floats
+  constexpr int STAGE = PATCH + ND4 * 4;
+  // loader slots: the first NLP slots of every thread are patch slots, the next NLD dy slots
+  // (slot kind is a compile-time property: no per-slot select, no branch)
+  constexpr int NLP = (NP4 + NT - 1) / NT, NLD = (ND4 + NT - 1) / NT;
+  constexpr int NQ = (S / 2) / NPP;        // pixel pairs per wave per segment
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int tap_u = wave / 3, tap_v = wave - tap_u * 3;
+  const int sb = wave % NSB, pp = wave / NSB;
+  const int wi = sb / TJ, wj = sb - wi * TJ;
 
   int bid = blockIdx.x;
   const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
@@ -51,25 +65,33 @@ __global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
   const int g_begin = sp * p.segs_per_block;
   const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
 
-  // loader slots: LDS float offset == 4*idx for both regions
-  int s_kind[NL], s_a[NL], s_b[NL], s_c[NL];
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+  // patch slot: (row-1, col-1, channel); invalid slots (idx >= NP4) get row = -2^20 so the
+  // bounds test fails and the buffer load returns 0
+  int p_r[NLP], p_c[NLP], p_ch[NLP];
 #pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    const int idx = tid + 576 * k;
-    if (idx < NP4) {
-      const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
-      const int prow = pix / PW, pcol = pix - prow * PW;
-      s_kind[k] = 0; s_a[k] = prow - 1; s_b[k] = pcol - 1; s_c[k] = ci0 + seg * 4;
-    } else if (idx < NP4 + ND4) {
-      const int d = idx - NP4;
-      const int dpix = d / (CO_T / 4), seg = d - dpix * (CO_T / 4);
-      s_kind[k] = 1; s_a[k] = 0; s_b[k] = dpix; s_c[k] = co0 + seg * 4;
-    } else {
-      s_kind[k] = 2; s_a[k] = s_b[k] = s_c[k] = 0;
-    }
+  for (int k = 0; k < NLP; ++k) {
+    const int idx = tid + NT * k;
+    const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    p_r[k] = idx < NP4 ? prow - 1 : -(1 << 20);
+    p_c[k] = pcol - 1;
+    p_ch[k] = ci0 + seg * 4;
+  }
+  int d_p[NLD], d_ch[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int d = tid + NT * k;
+    const int dpix = d / (CO_T / 4), seg = d - dpix * (CO_T / 4);
+    d_p[k] = d < ND4 ? dpix : (1 << 20);
+    d_ch[k] = co0 + seg * 4;
   }
 
-  f32x4 rg[NL];
+  f32x4 rp[NLP], rd[NLD];
   auto load_stage = [&](int g) {
     const int xs = g % p.segs_per_row;
     const int r = g / p.segs_per_row;
@@ -77,36 +99,41 @@ __global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
     const int n = r / p.Ho;
     const int x0 = xs * S;
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (s_kind[k] == 0) {
-        const int iy = oy * STRIDE + s_a[k], ix = x0 * STRIDE + s_b[k];
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(
-              p.x + ((size_t)(n * p.H + iy) * p.W + ix) * p.Cx + s_c[k]);
-      } else if (s_kind[k] == 1) {
-        const int ox = x0 + s_b[k];
-        if (ox < p.Wo)
-          v = *reinterpret_cast<const f32x4*>(
-              p.dy + ((size_t)(n * p.Ho + oy) * p.Wo + ox) * p.Cout + s_c[k]);
-      }
-      rg[k] = v;
+    for (int k = 0; k < NLP; ++k) {
+      const int iy = oy * STRIDE + p_r[k], ix = x0 * STRIDE + p_c[k];
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = ((unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + p_ch[k]) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      rp[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int ox = x0 + d_p[k];
+      const bool ok = ox < p.Wo;
+      const unsigned off = ((unsigned)(((n * p.Ho + oy) * p.Wo + ox) * p.Cout + d_ch[k]) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      rd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
     }
   };
   auto store_stage = [&](int buf) {
     float* base = smem + buf * STAGE;
 #pragma unroll
-    for (int k = 0; k < NL; ++k)
-      if (s_kind[k] != 2) *reinterpret_cast<f32x4*>(base + 4 * (tid + 576 * k)) = rg[k];
+    for (int k = 0; k < NLP; ++k)
+      if (NT * (k + 1) <= NP4 || tid + NT * k < NP4)
+        *reinterpret_cast<f32x4*>(base + 4 * (tid + NT * k)) = rp[k];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (NT * (k + 1) <= ND4 || tid + NT * k < ND4)
+        *reinterpret_cast<f32x4*>(base + PATCH + 4 * (tid + NT * k)) = rd[k];
   };
 
-  f32x16 acc[TI][TJ];
+  f32x16 acc[3][3];
 #pragma unroll
-  for (int i = 0; i < TI; ++i)
+  for (int u = 0; u < 3; ++u)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+    for (int v = 0; v < 3; ++v)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
 
   if (g_begin < g_end) {
     load_stage(g_begin);
@@ -114,56 +141,65 @@ __global__ __launch_bounds__(576) void conv_wgrad_kernel(const WgradParams p) {
     __syncthreads();
     for (int g = g_begin; g < g_end; ++g) {
       const int buf = (g - g_begin) & 1;
-      const bool more = (g + 1 < g_end);
-      if (more) load_stage(g + 1);
-      const float* P = smem + buf * STAGE + (tap_u * PW + tap_v) * CI_T;
-      const float* D = smem + buf * STAGE + PATCH;
-      // operand fragments double-buffered in registers: the reads of pixel pair q+1 are in
-      // flight while the MFMAs of pair q issue
-      float a[2][TI], b[2][TJ];
+      // always stage (the last iteration re-stages the final segment into the idle buffer):
+      // branch-free, so the compute part of a stage is one scheduling region
+      load_stage(min(g + 1, g_end - 1));
+      const float* P = smem + buf * STAGE + wi * 32 + li;
+      const float* D = smem + buf * STAGE + PATCH + wj * 32 + li;
+      float a[2][3][3], b[2];
+      {
+        const int xx = 2 * pp + lh;
 #pragma unroll
-      for (int i = 0; i < TI; ++i) a[0][i] = P[(lh * STRIDE) * CI_T + i * 32 + li];
+        for (int u = 0; u < 3; ++u)
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) b[0][j] = D[lh * CO_T + j * 32 + li];
+          for (int v = 0; v < 3; ++v) a[0][u][v] = P[(u * PW + xx * STRIDE + v) * CI_T];
+        b[0] = D[xx * CO_T];
+      }
 #pragma unroll
-      for (int q = 0; q < S / 2; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int cur = q & 1, nxt = cur ^ 1;
-        if (q + 1 < S / 2) {
-          const int xx = 2 * (q + 1) + lh;
+        if (q + 1 < NQ) {
+          const int xx = 2 * (pp + NPP * (q + 1)) + lh;
 #pragma unroll
-          for (int i = 0; i < TI; ++i) a[nxt][i] = P[(xx * STRIDE) * CI_T + i * 32 + li];
+          for (int u = 0; u < 3; ++u)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j) b[nxt][j] = D[xx * CO_T + j * 32 + li];
+            for (int v = 0; v < 3; ++v) a[nxt][u][v] = P[(u * PW + xx * STRIDE + v) * CI_T];
+          b[nxt] = D[xx * CO_T];
         }
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+        for (int u = 0; u < 3; ++u)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+          for (int v = 0; v < 3; ++v)
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][v], b[cur], acc[u][v], 0, 0, 0);
       }
-      // pin the pipeline: the two LDS reads (ds_read_b32 / ds_read2_b32) of pair q+1 are
-      // issued ahead of the MFMAs of pair q
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      // Pin the software pipeline: LDS fragment reads run one pixel pair ahead of their MFMAs,
+      // the next segment's buffer loads issue right behind the first pair (LDS writes follow;
+      // hipcc otherwise parks the loads at the end and waits for them on the spot).
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      if (NQ > 1) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, NLP + NLD, 0);
 #pragma unroll
-      for (int q = 0; q < S / 2; ++q) {
-        if (q + 1 < S / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ, 0);
+      for (int q = 1; q < NQ; ++q) {
+        if (q + 1 < NQ) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
       }
-      if (more) store_stage(buf ^ 1);
+      store_stage(buf ^ 1);
       __syncthreads();
     }
   }
 
-  float* out = p.partial + ((size_t)(sp * 9 + wave) * p.Cx) * p.Cout;
 #pragma unroll
-  for (int i = 0; i < TI; ++i)
+  for (int u = 0; u < 3; ++u)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+    for (int v = 0; v < 3; ++v) {
+      float* out = p.partial + ((size_t)((sp * NPP + pp) * 9 + u * 3 + v) * p.Cx) * p.Cout;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = ci0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        out[(size_t)row * p.Cout + co0 + j * 32 + li] = acc[i][j][r];
+        const int row = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[u][v][r];
       }
+    }
 }
 
 // Stage A of the slab reduction: out[c][e] = sum of slabs [16c, 16c+16) of in[.][e]
@@ -300,6 +336,7 @@ __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, floa
 }
 
 struct WgradPlan {
+  int npp;
   int ci_t, co_t, S, split, segs_per_row, total_segs, segs_per_block;
   size_t ws_floats;
   bool stem;
@@ -326,7 +363,13 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
   pl.ci_t = (Cx % 64 == 0) ? 64 : 32;
   pl.co_t = (Cout % 64 == 0) ? 64 : 32;
   if (pl.ci_t == 64 && pl.co_t == 32) pl.ci_t = 32;  // instantiated: 32x32, 32x64, 64x64
-  pl.S = (stride == 2 || Wo <= 16) ? 16 : 32;
+  const int nsb = (pl.ci_t / 32) * (pl.co_t / 32);
+  pl.npp = 4 / nsb;  // pixel-pair parts per segment, each with a slab of its own
+  // segment length: enough pixel pairs per wave per stage, within the LDS budget
+  if (Wo <= 16) pl.S = 16;
+  else if (pl.ci_t == 64) pl.S = (stride == 2) ? 16 : 32;
+  else if (pl.co_t == 64) pl.S = 32;                       // 32x64 tile
+  else pl.S = (stride == 1 && Wo >= 64) ? 64 : 32;         // 32x32 tile
   pl.segs_per_row = ceil_div(Wo, pl.S);
   pl.total_segs = N * Ho * pl.segs_per_row;
   const int tiles = (Cx / pl.ci_t) * (Cout / pl.co_t);
@@ -339,7 +382,8 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
   pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
   // slabs + ping-pong room for the staged reduction (each stage shrinks 16x)
   const size_t E = (size_t)9 * Cx * Cout;
-  pl.ws_floats = (size_t)pl.split * E + 2 * (size_t)ceil_div(pl.split, kSlabChunk) * E;
+  const int slabs = pl.split * pl.npp;
+  pl.ws_floats = (size_t)slabs * E + 2 * (size_t)ceil_div(slabs, kSlabChunk) * E;
   return pl;
 }
 
@@ -347,6 +391,7 @@ template <int CI_T, int CO_T, int S, int STRIDE>
 int launch_wgrad(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = (S - 1) * STRIDE + 3;
   constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
+  constexpr int NT = 256;
   static bool attr_set = false;
   auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE>;
   if (!attr_set) {
@@ -355,7 +400,7 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(576), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_wgrad");
   return UNET_OK;
 }
@@ -435,26 +480,40 @@ extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, 
     p.segs_per_row = pl.segs_per_row; p.total_segs = pl.total_segs;
     p.segs_per_block = pl.segs_per_block; p.split = pl.split;
     p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
+    UNET_REQUIRE((long long)N * H * W * Cx * 4 < (1LL << 31) &&
+                     (long long)N * Ho * Wo * Cout * 4 < (1LL << 31),
+                 "conv3x3_bwd_weight: tensor exceeds the 2 GiB buffer-descriptor range");
+    p.x_bytes = (unsigned)((long long)N * H * W * Cx * 4);
+    p.dy_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
     int rc;
     if (pl.ci_t == 32 && pl.co_t == 32) {
-      if (stride == 1) rc = (pl.S == 32) ? launch_wgrad<32, 32, 32, 1>(p, stream)
-                                         : launch_wgrad<32, 32, 16, 1>(p, stream);
-      else rc = launch_wgrad<32, 32, 16, 2>(p, stream);
+      if (stride == 1)
+        rc = pl.S == 64 ? launch_wgrad<32, 32, 64, 1>(p, stream)
+           : pl.S == 32 ? launch_wgrad<32, 32, 32, 1>(p, stream)
+                        : launch_wgrad<32, 32, 16, 1>(p, stream);
+      else
+        rc = pl.S == 32 ? launch_wgrad<32, 32, 32, 2>(p, stream)
+                        : launch_wgrad<32, 32, 16, 2>(p, stream);
     } else if (pl.ci_t == 32 && pl.co_t == 64) {
-      if (stride == 1) rc = (pl.S == 32) ? launch_wgrad<32, 64, 32, 1>(p, stream)
-                                         : launch_wgrad<32, 64, 16, 1>(p, stream);
-      else rc = launch_wgrad<32, 64, 16, 2>(p, stream);
+      if (stride == 1)
+        rc = pl.S == 32 ? launch_wgrad<32, 64, 32, 1>(p, stream)
+                        : launch_wgrad<32, 64, 16, 1>(p, stream);
+      else
+        rc = pl.S == 32 ? launch_wgrad<32, 64, 32, 2>(p, stream)
+                        : launch_wgrad<32, 64, 16, 2>(p, stream);
     } else {
-      if (stride == 1) rc = (pl.S == 32) ? launch_wgrad<64, 64, 32, 1>(p, stream)
-                                         : launch_wgrad<64, 64, 16, 1>(p, stream);
-      else rc = launch_wgrad<64, 64, 16, 2>(p, stream);
+      if (stride == 1)
+        rc = pl.S == 32 ? launch_wgrad<64, 64, 32, 1>(p, stream)
+                        : launch_wgrad<64, 64, 16, 1>(p, stream);
+      else
+        rc = launch_wgrad<64, 64, 16, 2>(p, stream);
     }
     if (rc != UNET_OK) return rc;
     const size_t E = (size_t)9 * Cx * Cout;
     const float* cur = ws;
-    int nslab = pl.split;
-    float* ping = ws + (size_t)pl.split * E;
-    float* pong = ping + (size_t)ceil_div(pl.split, kSlabChunk) * E;
+    int nslab = pl.split * pl.npp;
+    float* ping = ws + (size_t)nslab * E;
+    float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
     while (nslab > 8) {
       const int chunks = ceil_div(nslab, kSlabChunk);
       dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
