@@ -65,6 +65,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("UNET_SHARE_GPU"):   # rehearsal: every rank on device 0
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
@@ -76,7 +78,13 @@ def main():
     from unet_implementations_amd import ddp
 
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # backend "nccl" is RCCL on ROCm; UNET_DIST_BACKEND=gloo lets the N>1 path be rehearsed
+        # with several ranks sharing one GPU (RCCL refuses duplicate devices)
+        backend = os.environ.get("UNET_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     torch.manual_seed(1234)          # same initial replica on every rank
     model = ua.create_model(dev).train()
