@@ -69,6 +69,8 @@ CONV_SHAPES = [
     (2, 34, 18, 32, 0, 32, 2),
     (1, 128, 128, 64, 32, 32, 1),
     (1, 32, 32, 256, 128, 128, 1),
+    (2, 4, 256, 32, 0, 32, 1),      # row-fused kernel (W % 128 == 0, Cout 32)
+    (1, 3, 128, 64, 32, 32, 1),
 ]
 
 
@@ -100,6 +102,8 @@ DGRAD_SHAPES = [
     (2, 32, 32, 64, 128, 2, (0, 64)),
     (2, 16, 16, 128, 128, 1, (0, 128)),
     (2, 64, 64, 32, 64, 2, (0, 32)),
+    (2, 5, 128, 32, 32, 1, (0, 32)),     # row-fused kernel
+    (1, 4, 256, 96, 32, 1, (64, 32)),
 ]
 
 

@@ -15,6 +15,7 @@
 // Replaces nn.Conv2d forward / aten::convolution_backward(data) of
 // Our_UNet/models/unet.py:106-115 (reference is NCHW via oneDNN/cuDNN).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,15 +48,16 @@ inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
   p.tapw[t >> 2] |= e << ((t & 3) * 8);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p) {
-  constexpr int BK = 32;
-  constexpr int LDA = BK + 4;  // 144-B rows: conflict-free ds_read_b128 across 16 rows
+  constexpr int LDA = BK + 4;  // 144-B (80-B) rows: conflict-free ds_read_b128 across 16 rows
+  constexpr int SEGS = BK / 4;         // 16-B segments per tile row
+  constexpr int ROWS = 256 / SEGS;     // tile rows covered by one loader pass
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  constexpr int A_PASSES = BM / 32;
-  constexpr int B_PASSES = BN / 32;
+  constexpr int A_PASSES = BM / ROWS;
+  constexpr int B_PASSES = BN / ROWS;
   constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   const int Ktot = p.C0 + p.C1;
 
   // ---- loaders: thread -> (row lrow + 32*i, 16-B segment lseg) for both tiles ----
-  const int lrow = tid >> 3, lseg = tid & 7;
+  const int lrow = tid / SEGS, lseg = tid % SEGS;
   int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + ROWS * i;
     if (m < M) {
       const int n = m / HlWl;
       const int r = m - n * HlWl;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     const unsigned woff = wrow_off + (unsigned)(wt * p.tap_stride + c) * 4u;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (unsigned)(32 * j * Ktot) * 4u, 0, 0);
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (unsigned)(ROWS * j * Ktot) * 4u, 0, 0);
       rb[j] = __builtin_bit_cast(f32x4, v);
     }
   };
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     float* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
     float* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + 32 * i * LDA) = ra[i];
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[i];
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + 32 * j * LDA) = rb[j];
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + ROWS * j * LDA) = rb[j];
   };
 
   int t_next = 0, chunk_next = 0;
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     // Pin the software pipeline (hipcc otherwise sinks every read to just before its first
     // use): fragment reads run one k-group ahead of the MFMAs, the next tile's buffer loads
     // issue behind the first MFMA group, the LDS writes of the staged tile come last.
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+    if (BK / 8 > 1) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+    else __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
 #pragma unroll
@@ -250,12 +253,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
-  constexpr int BK = 32, LDA = BK + 4;
+  constexpr int LDA = BK + 4;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * LDA * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK>;
   if (!attr_set) {
     UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -268,13 +271,255 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Row-fused variant for stride-1 layers whose logical row length is a multiple of BM
+// (the full-resolution, narrow layers where A traffic, not MFMA, limits the generic
+// kernel).  One K step = (32-channel chunk, kernel row ky): the A tile is the BM+2
+// consecutive pixels x0-1 .. x0+BM of ONE image row, staged once and consumed by the three
+// taps kx through row shifts 0/1/2 of the fragment reads; three [BN][32] weight tiles ride
+// along.  3x less A traffic and 3x fewer barriers per MFMA than the per-tap K loop.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool PW>
+__global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams p, int ntiles) {
+  // PW (persistent weights): Ktot == 32, so all nine [BN][32] weight tiles are loaded into LDS
+  // once per workgroup and only the A rows stream through the double buffer.
+  constexpr int BK = 32, LDA = BK + 4;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  constexpr int AR = BM + 2;                       // staged pixels per K step
+  constexpr int A_PASSES = (AR + 31) / 32;
+  constexpr int B_PASSES = PW ? 0 : 3 * BN / 32;
+  constexpr int A_TILE = AR * LDA, B_TILE = 3 * BN * LDA;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_TILE;   // PW: [3 ky][3 shifts][BN][LDA], else 2 x [3 shifts][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int Ktot = p.C0 + p.C1;
+  const int HW = p.Hin * p.Win;
+  const int flip = p.sin;  // reused: 0 = forward (dy = ky-1), 1 = data gradient (dy = 1-ky)
+
+  // Persistent workgroup: tiles are walked so that the workgroups of one XCD (blockIdx % 8)
+  // cover one contiguous eighth of the image rows (halo rows stay in that XCD's L2); the
+  // K-step pipeline runs across tile boundaries, so the short K loop of a 32-channel layer
+  // (3 steps) never drains.  Requires Ncols == BN (one column tile).
+  const int G = gridDim.x;
+  int t_first, t_stride, t_end;
+  if ((ntiles & 7) == 0 && (G & 7) == 0) {
+    const int per = ntiles >> 3, xcd = blockIdx.x & 7;
+    t_first = xcd * per + (blockIdx.x >> 3);
+    t_stride = G >> 3;
+    t_end = (xcd + 1) * per;
+  } else {
+    t_first = blockIdx.x; t_stride = G; t_end = ntiles;
+  }
+  if (t_first >= t_end) return;
+
+  const int lrow = tid >> 3, lseg = tid & 7;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  // B slot j: row rr = lrow + 32*j of the [3][BN] panel -> (shift s, column n)
+  constexpr int BP = B_PASSES > 0 ? B_PASSES : 1;
+  int b_s[BP], b_off[BP];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int rr = lrow + 32 * j;
+    const int sft = rr / BN, n = rr - sft * BN;
+    b_s[j] = flip ? 2 - sft : sft;                     // kx of that shift
+    b_off[j] = ((p.n_off + n) * Ktot + lseg * 4) * 4;  // bytes within a tap
+  }
+  if (PW) {  // one-time fill of the persistent weight panel [ky][shift][n][k]
+    for (int rr = lrow; rr < 9 * BN; rr += 32) {
+      const int ky = rr / (3 * BN), r2 = rr - ky * 3 * BN;
+      const int sft = r2 / BN, n = r2 - sft * BN;
+      const int kx = flip ? 2 - sft : sft;
+      const unsigned off = (unsigned)(((ky * 3 + kx) * p.tap_stride + (p.n_off + n) * Ktot + lseg * 4)) * 4u;
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+      *reinterpret_cast<f32x4*>(Bs + rr * LDA + lseg * 4) = v;
+    }
+  }
+
+  f32x4 ra[A_PASSES], rb[BP];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int KS = 3 * (Ktot / BK);
+
+  auto load_tiles = [&](int tile, int ky, int chunk) {
+    const int m0 = tile * BM;             // the whole tile lies in one image row
+    const int img = m0 / HW;
+    const int rem = m0 - img * HW;
+    const int y0 = rem / p.Win, x0 = rem - y0 * p.Win;
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4;
+    const int y = y0 + (flip ? 1 - ky : ky - 1);
+    const bool yok = (unsigned)y < (unsigned)p.Hin;
+    const int rowbase = (img * p.Hin + y) * p.Win;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int r = lrow + 32 * i;
+      const int x = x0 - 1 + r;
+      const bool ok = yok && r < AR && (unsigned)x < (unsigned)p.Win;
+      const unsigned off = ((unsigned)((rowbase + x) * Cs + coff) * 4u) | (ok ? 0u : 0x80000000u);
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const unsigned off = (unsigned)b_off[j] + (unsigned)((ky * 3 + b_s[j]) * p.tap_stride + c) * 4u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
+    float* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      if (32 * (i + 1) <= AR || lrow + 32 * i < AR) *reinterpret_cast<f32x4*>(Ab + 32 * i * LDA) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + 32 * j * LDA) = rb[j];
+  };
+
+  // load cursor (tile, ky, chunk); it stops advancing on the last step of the last tile
+  int l_tile = t_first, l_ky = 0, l_chunk = 0;
+  auto advance = [&]() {
+    int ky = l_ky + 1, ch = l_chunk, tl = l_tile;
+    if (ky == 3) { ky = 0; ch += 1; }
+    if (ch == Ktot / BK) { ch = 0; tl += t_stride; }
+    const bool on = tl < t_end;
+    l_ky = on ? ky : l_ky; l_chunk = on ? ch : l_chunk; l_tile = on ? tl : l_tile;
+  };
+
+  load_tiles(l_tile, l_ky, l_chunk);
+  advance();
+  store_tiles(0);
+  __syncthreads();
+
+  const int frag_off = li * LDA + 4 * lh;
+  int step = 0;
+  for (int tile = t_first; tile < t_end; tile += t_stride) {
+    for (int ks = 0; ks < KS; ++ks, ++step) {
+      const int buf = step & 1;
+      load_tiles(l_tile, l_ky, l_chunk);
+      advance();
+      const float* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
+      const float* Bb = Bs + (PW ? ks : buf) * B_TILE + wn0 * LDA + frag_off;
+      constexpr int NG = 3 * (BK / 8);  // (shift, k-group) steps
+      f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDA);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) b[0][n] = *reinterpret_cast<const f32x4*>(Bb + n * 32 * LDA);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g + 1 < NG) {
+          const int sft = (g + 1) / (BK / 8), kk = (g + 1) % (BK / 8);
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+            a[nxt][m] = *reinterpret_cast<const f32x4*>(Ab + (m * 32 + sft) * LDA + kk * 8);
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            b[nxt][n] = *reinterpret_cast<const f32x4*>(Bb + (sft * BN + n * 32) * LDA + kk * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][n][r],
+                                                               acc[m][n], 0, 0, 0);
+      }
+      // pinned pipeline: reads one group ahead, next step's loads behind the first group
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
+#pragma unroll
+      for (int g = 1; g < NG; ++g) {
+        if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      }
+      store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+    // tile epilogue (stores drain while the next tile's K steps run)
+    const int m0 = tile * BM;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = wn0 + n * 32 + li;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float* o = p.out + (size_t)(m0 + row) * p.ldo + col;
+          float v = acc[m][n][r] + bv;
+          if (p.accumulate) v += *o;
+          *o = v;
+          acc[m][n][r] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool PW>
+int launch_igemm_rf(const IgemmParams& p, int flip, hipStream_t stream) {
+  constexpr int LDA = 36;
+  constexpr size_t lds = PW ? (size_t)(2 * (BM + 2) + 9 * BN) * LDA * sizeof(float)
+                            : 2 * (size_t)((BM + 2) + 3 * BN) * LDA * sizeof(float);
+  static bool attr_set = false;
+  auto kern = conv_igemm_rf_kernel<BM, BN, WM, WN, PW>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.sin = flip;
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int ntiles = (int)(M / BM);
+  const int resident = 256 * (int)((160 * 1024) / lds);   // CUs x workgroups that fit in LDS
+  const int grid = ntiles < resident ? ntiles : resident;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, q, ntiles);
+  UNET_CHECK_LAUNCH("conv_igemm_rf");
+  return UNET_OK;
+}
+
+// stride-1 3x3 with rows that tile exactly: use the row-fused kernel for narrow outputs
+bool rf_applicable(const IgemmParams& p) {
+  static const int off = getenv("UNET_NO_ROWFUSE") ? 1 : 0;
+  return !off && p.ntaps == 9 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
+         p.Hl == p.Hout && p.Wl == p.Wout && p.Wl % 128 == 0 && p.Ncols == 32;
+}
+
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   // Largest tile that still yields >= 256 workgroups (one per CU); otherwise the
   // small 64x64 tile.
+  static const int bk16 = getenv("UNET_IGEMM_BK16") ? 1 : 0;
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
-    return launch_igemm<128, 128, 64, 64>(p, stream);
+    return bk16 ? launch_igemm<128, 128, 64, 64, 16>(p, stream)
+                : launch_igemm<128, 128, 64, 64>(p, stream);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
     return launch_igemm<128, 64, 64, 32>(p, stream);
   if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm<64, 64, 32, 32>(p, stream);
@@ -398,6 +643,9 @@ extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1
   p.Wl = p.Wout = (W - 1) / stride + 1;
   p.Ncols = Cout;
   fill_fwd_taps(p, stride);
+  if (stride == 1 && rf_applicable(p))
+    return (C0 + C1 == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 0, stream)
+                           : launch_igemm_rf<128, 32, 32, 32, false>(p, 0, stream);
   return dispatch_igemm(p, stream);
 }
 
@@ -434,6 +682,9 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_t
     p.ntaps = 9;
     p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
+    if (rf_applicable(p))
+      return (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream)
+                          : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream);
     return dispatch_igemm(p, stream);
   }
   // stride 2: dx[2a+py][2b+px] = sum over ky with (py+1-ky) even of dy[a + (py+1-ky)/2][..]
