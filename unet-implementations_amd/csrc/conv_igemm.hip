@@ -511,6 +511,194 @@ bool rf_applicable(const IgemmParams& p) {
          p.Hl == p.Hout && p.Wl == p.Wout && p.Wl % 128 == 0 && p.Ncols == 32;
 }
 
+
+// ---------------------------------------------------------------------------
+// Stride-2 data gradient in ONE launch.  Logical position (a,b) of the dy grid produces the
+// four dx pixels (2a+py, 2b+px).  The nine taps fall into four dy shifts (oy,ox) in {0,1}^2:
+//   (0,0): taps (1,1)->class 0, (1,2)->1, (2,1)->2, (2,2)->3      class = py*2+px
+//   (0,1): taps (1,0)->1, (2,0)->3      (1,0): taps (0,1)->2, (0,2)->3      (1,1): tap (0,0)->3
+// so a K step = (32-channel chunk of dy, shift): ONE staged dy tile feeds 4/2/2/1 weight
+// tiles, each accumulating into its class's accumulator block (4 x 16 VGPRs per wave).  The
+// four shifts are unrolled so every step has a compile-time tap list (no per-step branch).
+// Block = 4 waves stacked along M (128 logical positions) x 32 dx channels.
+// ---------------------------------------------------------------------------
+struct S2Tap { int ky, kx, cls; };
+template <int SH> struct S2Shift;
+template <> struct S2Shift<0> { static constexpr int n = 4, oy = 0, ox = 0;
+  static constexpr S2Tap t[4] = {{1, 1, 0}, {1, 2, 1}, {2, 1, 2}, {2, 2, 3}}; };
+template <> struct S2Shift<1> { static constexpr int n = 2, oy = 0, ox = 1;
+  static constexpr S2Tap t[4] = {{1, 0, 1}, {2, 0, 3}, {0, 0, 0}, {0, 0, 0}}; };
+template <> struct S2Shift<2> { static constexpr int n = 2, oy = 1, ox = 0;
+  static constexpr S2Tap t[4] = {{0, 1, 2}, {0, 2, 3}, {0, 0, 0}, {0, 0, 0}}; };
+template <> struct S2Shift<3> { static constexpr int n = 1, oy = 1, ox = 1;
+  static constexpr S2Tap t[4] = {{0, 0, 3}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; };
+
+__global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(const IgemmParams p) {
+  constexpr int BM = 128, BN = 32, BK = 32, LDA = BK + 4;
+  constexpr int A_TILE = BM * LDA, B_TILE = 4 * BN * LDA;
+  constexpr int STAGE = A_TILE + B_TILE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = wave * 32;
+  const int tiles_n = p.Ncols / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int HlWl = p.Hl * p.Wl;   // dy grid
+  const int M = p.N * HlWl;
+  const int Ktot = p.C0;          // Cout of the forward conv
+
+  const int lrow = tid >> 3, lseg = tid & 7;
+  int a_nb[4], a_y[4], a_x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < M) {
+      const int n = m / HlWl;
+      const int r = m - n * HlWl;
+      a_y[i] = r / p.Wl;
+      a_x[i] = r - a_y[i] * p.Wl;
+      a_nb[i] = n * HlWl;
+    } else {
+      a_nb[i] = 0; a_y[i] = -(1 << 24); a_x[i] = 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
+
+  f32x4 ra[4], rb[4];
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const int nchunks = Ktot / BK;
+
+  auto load_step = [&](auto shift_tag, int chunk) {
+    using SHT = decltype(shift_tag);
+    const int c = chunk * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = a_y[i] + SHT::oy, x = a_x[i] + SHT::ox;
+      const bool ok = (unsigned)y < (unsigned)p.Hl && (unsigned)x < (unsigned)p.Wl;
+      const unsigned off = ((unsigned)((a_nb[i] + y * p.Wl + x) * Ktot + c + lseg * 4) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < SHT::n; ++j) {
+      const unsigned off = wrow_off + (unsigned)((SHT::t[j].ky * 3 + SHT::t[j].kx) * p.tap_stride + c) * 4u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
+    }
+  };
+  auto store_step = [&](auto shift_tag, int buf) {
+    using SHT = decltype(shift_tag);
+    float* Ab = smem + buf * STAGE + lrow * LDA + lseg * 4;
+    float* Bb = smem + buf * STAGE + A_TILE + lrow * LDA + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ab + 32 * i * LDA) = ra[i];
+#pragma unroll
+    for (int j = 0; j < SHT::n; ++j) *reinterpret_cast<f32x4*>(Bb + 32 * j * LDA) = rb[j];
+  };
+  const int frag_off = li * LDA + 4 * lh;
+  auto compute_step = [&](auto shift_tag, int buf) {
+    using SHT = decltype(shift_tag);
+    const float* Ab = smem + buf * STAGE + wm0 * LDA + frag_off;
+    const float* Bb = smem + buf * STAGE + A_TILE + frag_off;
+    f32x4 a[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a[kk] = *reinterpret_cast<const f32x4*>(Ab + kk * 8);
+#pragma unroll
+    for (int j = 0; j < SHT::n; ++j) {
+      f32x4 b[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) b[kk] = *reinterpret_cast<const f32x4*>(Bb + 32 * j * LDA + kk * 8);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[SHT::t[j].cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][r], b[kk][r],
+                                                                    acc[SHT::t[j].cls], 0, 0, 0);
+    }
+    // pinned pipeline: A fragments + first tap's B fragments, then each tap's 16 MFMAs with the
+    // next tap's reads ahead of them; the next step's buffer loads follow the first MFMA group
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int j = 0; j < SHT::n; ++j) {
+      if (j + 1 < SHT::n) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      if (j == 0) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+    }
+  };
+
+  // software pipeline over the flattened (chunk, shift) sequence, two LDS stages
+  load_step(S2Shift<0>{}, 0);
+  store_step(S2Shift<0>{}, 0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int nc = min(chunk + 1, nchunks - 1);   // last chunk re-stages itself (harmless)
+    load_step(S2Shift<1>{}, chunk);
+    compute_step(S2Shift<0>{}, 0);
+    store_step(S2Shift<1>{}, 1);
+    __syncthreads();
+    load_step(S2Shift<2>{}, chunk);
+    compute_step(S2Shift<1>{}, 1);
+    store_step(S2Shift<2>{}, 0);
+    __syncthreads();
+    load_step(S2Shift<3>{}, chunk);
+    compute_step(S2Shift<2>{}, 0);
+    store_step(S2Shift<3>{}, 1);
+    __syncthreads();
+    load_step(S2Shift<0>{}, nc);
+    compute_step(S2Shift<3>{}, 1);
+    store_step(S2Shift<0>{}, 0);
+    __syncthreads();
+  }
+
+  // epilogue: logical row -> (n, a, b); class c -> dx pixel (2a + c/2, 2b + c%2)
+  const int col = n0 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int mg = m0 + row;
+    if (mg < M) {
+      const int nn = mg / HlWl;
+      const int rr = mg - nn * HlWl;
+      const int a = rr / p.Wl;
+      const int b = rr - a * p.Wl;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t opix = ((size_t)nn * p.Hout + (2 * a + (c >> 1))) * p.Wout + (2 * b + (c & 1));
+        float* o = p.out + opix * p.ldo + col;
+        float v = acc[c][r];
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
+    }
+  }
+}
+
+int launch_dgrad_s2(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)(128 + 4 * 32) * 36 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const long long tiles = ceil_div64(M, 128) * (p.Ncols / 32);
+  hipLaunchKernelGGL(conv_dgrad_s2_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_dgrad_s2");
+  return UNET_OK;
+}
+
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
@@ -689,6 +877,12 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_t
   }
   // stride 2: dx[2a+py][2b+px] = sum over ky with (py+1-ky) even of dy[a + (py+1-ky)/2][..]
   p.Hl = H / 2; p.Wl = W / 2; p.sout = 2;
+  {
+    static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
+    // one launch for all four parity classes when there are enough tiles to fill the chip
+    const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
+    if (!per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
+  }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       p.py = py; p.px = px;
