@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--hw", type=int, default=512)
+    ap.add_argument("--matmul", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16 = BASELINE config 4 (bf16 MFMA operands, fp32 accumulate/storage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -88,6 +90,7 @@ def main():
 
     torch.manual_seed(1234)          # same initial replica on every rank
     model = ua.create_model(dev).train()
+    model.matmul_precision = args.matmul
     opt = ua.create_optimizer(model)
     lossf = ua.get_loss_function()
     sync = None
@@ -136,7 +139,8 @@ def main():
             "metric": "images/sec (512x512, bs/GPU=8) Our_UNet train step",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.matmul == "fp32" else "bf16 (MFMA operands; f32 accumulate + storage)",
             "data": "synthetic",
             "config": {"workload": f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
                                    "fp32 train step (fwd + Dice/wCE loss + bwd + SGD-Nesterov), "
@@ -149,7 +153,7 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
-            k = summ.get("conv_igemm")
+            k = summ.get("conv_igemm") or summ.get("conv_igemm_bf16")
             if k:
                 ach = k["flops"] / (k["ms"] * 1e-3) * 1e-12
                 result["roofline"] = {

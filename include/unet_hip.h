@@ -71,6 +71,17 @@ int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1, const flo
                      const float* bias, float* y, int N, int H, int W, int Cout, int stride,
                      unet_stream_t stream);
 
+/* bf16 mixed-precision variants (BASELINE.json config 4; the reference's AMP path,
+ * Our_UNet/src/train.py:638-652, is fp16 autocast): identical arguments and fp32 tensors; both
+ * operands are rounded to bf16 while staged on chip and contracted on the bf16 matrix cores with
+ * fp32 accumulation.  The RGB stem (C0 == 3) stays fp32. */
+int unet_conv3x3_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const float* wf,
+                          const float* bias, float* y, int N, int H, int W, int Cout, int stride,
+                          unet_stream_t stream);
+int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int Cin_total, int ci_offset,
+                               float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
+                               int accumulate, unet_stream_t stream);
+
 /* dx[N][H][W][Ccols] (+)= conv3x3_transpose(dy[N][Ho][Wo][Cout], wd slice).
  * Replaces the data-gradient half of aten::convolution_backward reached from
  * loss.backward() (Our_UNet/src/train.py:663).  wd is the whole

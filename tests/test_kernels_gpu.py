@@ -88,6 +88,49 @@ def test_conv3x3_fwd(ua, shape):
     check(from_nhwc(y), ref, 2e-5, f"conv fwd {shape}")
 
 
+BF16_SHAPES = [(2, 12, 20, 32, 0, 32, 1), (2, 12, 20, 32, 0, 64, 2), (1, 16, 16, 64, 32, 128, 1),
+               (1, 16, 16, 512, 0, 512, 1), (2, 2, 2, 512, 0, 512, 1), (1, 64, 64, 64, 0, 64, 1),
+               (1, 8, 128, 64, 32, 32, 1), (1, 24, 40, 3, 0, 32, 1)]
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_conv3x3_fwd_bf16(ua, shape):
+    """bf16 operands, fp32 accumulation: exact products, so the result matches an fp32 conv of
+    the bf16-rounded operands up to summation order (the RGB stem stays fp32)."""
+    N, H, W, C0, C1, Cout, s = shape
+    x = rnd(N, C0 + C1, H, W, seed=3)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=4, scale=0.1)
+    b = rnd(Cout, seed=5)
+    ref = F.conv2d(x, w, b, stride=s, padding=1) if C0 == 3 else \
+        F.conv2d(_bf(x), _bf(w), b, stride=s, padding=1)
+    wf, _ = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    x0 = to_nhwc(x[:, :C0])
+    x1 = to_nhwc(x[:, C0:]) if C1 else None
+    y = ua.ops.conv3x3_fwd(x0, x1, wf, b.to(DEV), s, bf16=True)
+    check(from_nhwc(y), ref, 2e-5, f"bf16 conv fwd {shape}")
+    full = F.conv2d(x, w, b, stride=s, padding=1)     # and it is a bf16-accurate conv
+    assert relerr(from_nhwc(y), full) < 2e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 20, 32, 32, 1, (0, 32)), (1, 16, 16, 96, 64, 1, (32, 64)),
+                                   (2, 16, 24, 32, 64, 2, (0, 32)), (2, 4, 4, 512, 512, 2, (0, 512)),
+                                   (1, 64, 64, 64, 64, 1, (0, 64))])
+def test_conv3x3_bwd_data_bf16(ua, shape):
+    N, H, W, Cin, Cout, s, (off, cc) = shape
+    x = rnd(N, Cin, H, W, seed=6).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=7, scale=0.1)
+    y = F.conv2d(x, _bf(w), None, stride=s, padding=1)
+    gy = rnd(*y.shape, seed=8)
+    (gx,) = torch.autograd.grad(y, x, _bf(gy))
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    dx = ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, off, cc, H, W, s, bf16=True)
+    check(from_nhwc(dx), gx[:, off:off + cc], 2e-5, f"bf16 dgrad {shape}")
+
+
 # --------------------------------------------------------------------------- conv dgrad
 DGRAD_SHAPES = [
     # N, H, W, Cin, Cout, stride, (ci_offset, ccols)

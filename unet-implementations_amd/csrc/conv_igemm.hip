@@ -19,6 +19,9 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
 struct IgemmParams {
   const float* src0;
   const float* src1;
@@ -252,6 +255,212 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// bf16 mixed-precision variant (BASELINE config 4 / SURVEY a15): tensors stay fp32 in HBM,
+// the loader rounds both operands to bf16 (v_cvt_pk_bf16_f32) while staging them into LDS
+// and the contraction runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the fp32
+// matrix rate, so the kernel turns load/L2-bound).  Same gather-GEMM, tap table, tiles and
+// epilogue as conv_igemm_kernel; LDS rows hold 32 bf16 + 8 pad (80 B: conflict-free b128).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmParams p) {
+  constexpr int BK = 32;
+  constexpr int LDA = BK + 8;  // bf16 elements per LDS row
+  constexpr int SEGS = BK / 4;         // 16-B segments per tile row
+  constexpr int ROWS = 256 / SEGS;     // tile rows covered by one loader pass
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  constexpr int A_PASSES = BM / ROWS;
+  constexpr int B_PASSES = BN / ROWS;
+  constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* As = smem_h;
+  __bf16* Bs = smem_h + 2 * A_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+  const int tiles_n = p.Ncols / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int HlWl = p.Hl * p.Wl;
+  const int M = p.N * HlWl;
+  const int Ktot = p.C0 + p.C1;
+
+  // ---- loaders: thread -> (row lrow + 32*i, 16-B segment lseg) for both tiles ----
+  const int lrow = tid / SEGS, lseg = tid % SEGS;
+  int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + lrow + ROWS * i;
+    if (m < M) {
+      const int n = m / HlWl;
+      const int r = m - n * HlWl;
+      const int a = r / p.Wl;
+      const int b = r - a * p.Wl;
+      a_nb[i] = n * p.Hin * p.Win;
+      a_iy[i] = a * p.sin;
+      a_ix[i] = b * p.sin;
+    } else {
+      a_nb[i] = 0;
+      a_iy[i] = -(1 << 24);
+      a_ix[i] = 0;
+    }
+  }
+  // Buffer descriptors: out-of-range lanes (zero padding, rows past M) get an offset beyond
+  // num_records and read 0 with no branch, so the K loop is one basic block.
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  // weight rows of this thread: ((n_off + n0 + lrow + 32*j) * Ktot + lseg*4) floats
+  const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[A_PASSES], rb[B_PASSES];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int KS = p.ntaps * (Ktot / BK);
+
+  auto load_tiles = [&](int t, int chunk) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const int wt = (int)(e >> 4);
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      // invalid lanes get bit 31 set: beyond num_records (< 2 GiB), the load returns 0
+      const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
+    }
+    const unsigned woff = wrow_off + (unsigned)(wt * p.tap_stride + c) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (unsigned)(ROWS * j * Ktot) * 4u, 0, 0);
+      rb[j] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto to_bf16 = [](const f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    return h;
+  };
+  auto store_tiles = [&](int buf) {
+    __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
+    __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[i]);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<bf16x4*>(Bb + ROWS * j * LDA) = to_bf16(rb[j]);
+  };
+
+  int t_next = 0, chunk_next = 0;
+  auto advance = [&](bool on) {  // branch-free: keeps the K step a single basic block
+    const int tn = t_next + 1;
+    const bool wrap = tn == p.ntaps;
+    t_next = on ? (wrap ? 0 : tn) : t_next;
+    chunk_next = on ? chunk_next + (wrap ? 1 : 0) : chunk_next;
+  };
+
+  load_tiles(t_next, chunk_next);
+  advance(KS > 1);
+  store_tiles(0);
+  __syncthreads();
+
+  // fragment addresses: lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of row li
+  // (the natural A/B operand map of v_mfma_f32_32x32x16_bf16)
+  const int frag_off = li * LDA + 8 * lh;
+  for (int ks = 0; ks < KS; ++ks) {
+    const int buf = ks & 1;
+    load_tiles(t_next, chunk_next);
+    advance(ks + 2 < KS);
+    const __bf16* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
+    const __bf16* Bb = Bs + buf * B_TILE + wn0 * LDA + frag_off;
+    bf16x8 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const bf16x8*>(Ab + m * 32 * LDA);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) b[0][n] = *reinterpret_cast<const bf16x8*>(Bb + n * 32 * LDA);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 16) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+          a[nxt][m] = *reinterpret_cast<const bf16x8*>(Ab + m * 32 * LDA + (kk + 1) * 16);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          b[nxt][n] = *reinterpret_cast<const bf16x8*>(Bb + n * 32 * LDA + (kk + 1) * 16);
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m], b[cur][n], acc[m][n], 0, 0, 0);
+    }
+    store_tiles(buf ^ 1);
+    // buffer loads first (they are the critical path here), fragment reads ahead of the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D row = (reg&3) + 8*(reg>>2) + 4*lh, column = li ----
+  const bool direct = (p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout);
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    const int col = n0 + wn0 + n * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int mg = m0 + row;
+        if (mg < M) {
+          size_t opix;
+          if (direct) {
+            opix = (size_t)mg;
+          } else {
+            const int nn = mg / HlWl;
+            const int rr = mg - nn * HlWl;
+            const int a = rr / p.Wl;
+            const int b = rr - a * p.Wl;
+            opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
+          }
+          float* o = p.out + opix * p.ldo + col;
+          float v = acc[m][n][r] + bv;
+          if (p.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
 
 template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
@@ -699,6 +908,28 @@ int launch_dgrad_s2(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 40 * sizeof(__bf16);
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles), dim3(256), lds,
+                     stream, p);
+  UNET_CHECK_LAUNCH("conv_igemm_bf16");
+  return UNET_OK;
+}
+
+int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+    return launch_igemm_bf16<128, 128, 64, 64>(p, stream);
+  if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+    return launch_igemm_bf16<128, 64, 64, 32>(p, stream);
+  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_bf16<64, 64, 32, 32>(p, stream);
+  return launch_igemm_bf16<128, 32, 32, 32>(p, stream);
+}
+
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
@@ -796,10 +1027,9 @@ void fill_fwd_taps(IgemmParams& p, int stride) {
 
 }  // namespace
 
-extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1, const float* wf,
-                                const float* bias, float* y, int N, int H, int W, int Cout,
-                                int stride, unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, const float* wf,
+                            const float* bias, float* y, int N, int H, int W, int Cout,
+                            int stride, bool bf16, hipStream_t stream) {
   UNET_REQUIRE(x0 && wf && y, "conv3x3_fwd: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_fwd: stride %d unsupported", stride);
   UNET_REQUIRE(N > 0 && H > 0 && W > 0, "conv3x3_fwd: bad shape");
@@ -831,17 +1061,33 @@ extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1
   p.Wl = p.Wout = (W - 1) / stride + 1;
   p.Ncols = Cout;
   fill_fwd_taps(p, stride);
+  if (bf16) return dispatch_igemm_bf16(p, stream);
   if (stride == 1 && rf_applicable(p))
     return (C0 + C1 == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 0, stream)
                            : launch_igemm_rf<128, 32, 32, 32, false>(p, 0, stream);
   return dispatch_igemm(p, stream);
 }
 
-extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_total,
-                                     int ci_offset, float* dx, int N, int H, int W, int Cout,
-                                     int Ccols, int stride, int accumulate,
-                                     unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1, const float* wf,
+                                const float* bias, float* y, int N, int H, int W, int Cout,
+                                int stride, unet_stream_t stream) {
+  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, false,
+                          (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_fwd_bf16(const float* x0, int C0, const float* x1, int C1,
+                                     const float* wf, const float* bias, float* y, int N, int H,
+                                     int W, int Cout, int stride, unet_stream_t stream) {
+  if (C0 == 3)   // the RGB stem is HBM-bound: it stays on the fp32 path
+    return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, false,
+                            (hipStream_t)stream);
+  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, true,
+                          (hipStream_t)stream);
+}
+
+static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total, int ci_offset,
+                                 float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
+                                 int accumulate, bool bf16, hipStream_t stream) {
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_data: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
@@ -870,6 +1116,7 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_t
     p.ntaps = 9;
     p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
+    if (bf16) return dispatch_igemm_bf16(p, stream);
     if (rf_applicable(p))
       return (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream)
                           : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream);
@@ -881,7 +1128,7 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_t
     static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
     // one launch for all four parity classes when there are enough tiles to fill the chip
     const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
-    if (!per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
+    if (!bf16 && !per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
   }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
@@ -897,8 +1144,24 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_t
         }
       }
       p.ntaps = nt;
-      int rc = dispatch_igemm(p, stream);
+      int rc = bf16 ? dispatch_igemm_bf16(p, stream) : dispatch_igemm(p, stream);
       if (rc != UNET_OK) return rc;
     }
   return UNET_OK;
+}
+
+extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_total,
+                                     int ci_offset, float* dx, int N, int H, int W, int Cout,
+                                     int Ccols, int stride, int accumulate,
+                                     unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
+                               accumulate, false, (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int Cin_total,
+                                          int ci_offset, float* dx, int N, int H, int W, int Cout,
+                                          int Ccols, int stride, int accumulate,
+                                          unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
+                               accumulate, true, (hipStream_t)stream);
 }

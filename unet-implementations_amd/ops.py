@@ -99,7 +99,7 @@ def pack_conv3x3_weights(w_oihw, wf=None, wd=None, want_wd=True):
 
 
 # ---- convolution ---------------------------------------------------------------
-def conv3x3_fwd(x0, x1, wf, bias, stride, out=None):
+def conv3x3_fwd(x0, x1, wf, bias, stride, out=None, bf16=False):
     N, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     if x1 is not None:
@@ -109,15 +109,17 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None):
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = out if out is not None else _f32((N, Ho, Wo, Cout), x0)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv3x3_fwd(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(bias), _ptr(y), N, H,
-                                 W, Cout, stride, _stream()))
+    fn = lib().unet_conv3x3_fwd_bf16 if bf16 else lib().unet_conv3x3_fwd
+    check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(bias), _ptr(y), N, H, W, Cout, stride,
+             _stream()))
     if t0 is not None:
-        _timer.end("conv_stem_fwd" if C0 == 3 else "conv_igemm",
+        _timer.end("conv_stem_fwd" if C0 == 3 else ("conv_igemm_bf16" if bf16 else "conv_igemm"),
                    2.0 * N * Ho * Wo * 9 * (C0 + C1) * Cout, 1, t0)
     return y
 
 
-def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False):
+def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False,
+                     bf16=False):
     """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols)."""
     N, Ho, Wo, Cout = dy.shape
     cin_total = wd.shape[1]
@@ -125,10 +127,16 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv3x3_bwd_data(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N, H, W,
-                                      Cout, ccols, stride, 1 if accumulate else 0, _stream()))
-    if t0 is not None:  # stride 2 runs one launch per output parity class
-        _timer.end("conv_igemm", 2.0 * N * Ho * Wo * 9 * ccols * Cout, 4 if stride == 2 else 1, t0)
+    fn = lib().unet_conv3x3_bwd_data_bf16 if bf16 else lib().unet_conv3x3_bwd_data
+    check(fn(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N, H, W, Cout, ccols, stride,
+             1 if accumulate else 0, _stream()))
+    if t0 is not None:
+        launches = 1
+        if stride == 2:  # fp32: one launch when >= 512 tiles, else one per output parity class
+            tiles = -(-(N * Ho * Wo) // 128) * (ccols // 32)
+            launches = 1 if (not bf16 and tiles >= 512) else 4
+        _timer.end("conv_igemm_bf16" if bf16 else "conv_igemm",
+                   2.0 * N * Ho * Wo * 9 * ccols * Cout, launches, t0)
     return dx
 
 

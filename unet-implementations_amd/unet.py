@@ -195,6 +195,10 @@ class UNet(nn.Module):
         # data-parallel hook: called during backward as `hook(lo)` once every gradient at arena
         # offsets >= lo is final (backward completes the arena back to front)
         self.grad_ready_hook = None
+        # "fp32" (default, the parity path) or "bf16": conv forward / data-gradient operands are
+        # rounded to bf16 on chip and contracted on the bf16 matrix cores with fp32 accumulation
+        # (tensors, InstanceNorm statistics, weight gradients, master weights stay fp32)
+        self.matmul_precision = "fp32"
 
     # -- reference: Our_UNet/models/unet.py:386-397 --------------------------------------
     def initialize_weights(self):
@@ -348,11 +352,14 @@ class _UNetFunction(torch.autograd.Function):
         masks = _draw_masks(model, layers, N, x.device) if use_masks else [None] * len(layers)
         mask_of = {id(l): m for l, m in zip(layers, masks)}
         saved = []  # per layer: dict(inputs, y, stats, mask, a)
+        if model.matmul_precision not in ("fp32", "bf16"):
+            raise ValueError("matmul_precision must be 'fp32' or 'bf16'")
+        bf16 = model.matmul_precision == "bf16"
 
         def run_layer(l, x0, x1):
             w = l.conv.weight
             wf, wd = ops.pack_conv3x3_weights(w.detach(), want_wd=need_grad)
-            y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride)
+            y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride, bf16=bf16)
             st = ops.instnorm_stats(y, l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps)
             m = mask_of[id(l)]
             a = ops.instnorm_lrelu_drop_fwd(y, st[2], st[3], m, l.slope)
@@ -382,6 +389,7 @@ class _UNetFunction(torch.autograd.Function):
             ctx.saved = saved
             ctx.n_enc_blocks = len(enc)
             ctx.params = params
+            ctx.bf16 = bf16
         return logits
 
     @staticmethod
@@ -427,9 +435,10 @@ class _UNetFunction(torch.autograd.Function):
             if need_dx:
                 N, H, W, C0 = x0.shape
                 dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
-                                           accumulate=dx0_acc)
+                                           accumulate=dx0_acc, bf16=ctx.bf16)
                 if x1 is not None:
-                    dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride)
+                    dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride,
+                                               bf16=ctx.bf16)
             return dx0, dx1
 
         # decoder stages, last to first
