@@ -22,6 +22,18 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE = 385.188   # fwd + dgrad + wgrad, convolutions only
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (spec)
+
+
+def hbm_traffic(args):
+    """HBM bytes per conv_igemm launch from the PMC passes committed under profiles/ (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950); valid for the default fp32 bs=8 512x512 workload."""
+    path = os.path.join(ROOT, "profiles", "r01_igemm_hbm_traffic.json")
+    if args.matmul != "fp32" or args.hw != 512 or args.batch != 8 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["hbm_bytes_per_launch"]
 
 
 def cpu_baseline(steps=3, hw=512, n=2):
@@ -156,9 +168,10 @@ def main():
             k = summ.get("conv_igemm") or summ.get("conv_igemm_bf16")
             if k:
                 ach = k["flops"] / (k["ms"] * 1e-3) * 1e-12
+                peak = PEAK_F32_MFMA_TFLOPS if args.matmul == "fp32" else PEAK_BF16_MFMA_TFLOPS
                 result["roofline"] = {
-                    "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "bound": "mfma", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": hbm_traffic(args),
                     "kernel": "conv_igemm_kernel (3x3 conv forward + data gradient, all tile "
                               "instantiations)",
                     "launches_per_step": k["launches"] / args.steps,
