@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--hw", type=int, default=512)
     ap.add_argument("--matmul", choices=["fp32", "bf16"], default="fp32",
                     help="bf16 = BASELINE config 4 (bf16 MFMA operands, fp32 accumulate/storage)")
+    ap.add_argument("--clip", action="store_true",
+                    help="BASELINE config 5: CLIP_UNet variant with synthetic CLIP features")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -101,7 +103,10 @@ def main():
             dist.init_process_group(backend=backend)
 
     torch.manual_seed(1234)          # same initial replica on every rank
-    model = ua.create_model(dev).train()
+    if args.clip:
+        model = ua.CLIPUNet(with_clip_features=True, clip_dim=512).to(dev).train()
+    else:
+        model = ua.create_model(dev).train()
     model.matmul_precision = args.matmul
     opt = ua.create_optimizer(model)
     lossf = ua.get_loss_function()
@@ -113,8 +118,19 @@ def main():
     img, tgt = img.to(dev), tgt.to(dev)
     torch.manual_seed(99 + rank)     # dropout stream differs per rank
 
+    clip = torch.randn(args.batch, 512, args.hw // 32, args.hw // 32, device=dev) if args.clip else None
+
     def step():
-        return ua.train_step(model, opt, lossf, img, tgt, grad_sync=sync.finish if sync else None)
+        if clip is None:
+            return ua.train_step(model, opt, lossf, img, tgt,
+                                 grad_sync=sync.finish if sync else None)
+        opt.zero_grad()
+        loss = lossf(model(img, clip), tgt)
+        loss.backward()
+        if sync:
+            sync.finish()
+        opt.step()
+        return loss.detach()
 
     for _ in range(args.warmup):
         loss = step()
@@ -154,7 +170,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.matmul == "fp32" else "bf16 (MFMA operands; f32 accumulate + storage)",
             "data": "synthetic",
-            "config": {"workload": f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
+            "config": {"workload": ("CLIP_UNet (synthetic CLIP features [N,512,16,16]) " if args.clip else "") +
+                                   f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
                                    "fp32 train step (fwd + Dice/wCE loss + bwd + SGD-Nesterov), "
                                    "train mode, HIP conv/IN/upsample kernels",
                        "global_batch": args.batch * world, "image": [args.hw, args.hw],

@@ -104,6 +104,26 @@ int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, float* dw_o
                             size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
                             unet_stream_t stream);
 
+/* ---- 1x1 convolution (CLIP fusion layer) ---------------------------------- */
+
+/* y = conv1x1(cat(x0, x1)) + bias with w[Cout][C0+C1]; replaces clip_fusion_conv[0] =
+ * nn.Conv2d(512 + clip_dim, 512, 1) and the torch.cat in front of it
+ * (CLIP_UNet/models/unet.py:356-362, :477-478). */
+int unet_conv1x1_fwd(const float* x0, int C0, const float* x1, int C1, const float* w,
+                     const float* bias, float* y, int N, int H, int W, int Cout,
+                     unet_stream_t stream);
+/* dx[.., Ccols] (+)= dy . wT[ci_offset.., :] with wT[Cin_total][Cout] (unet_transpose2d of w) */
+int unet_conv1x1_bwd_data(const float* dy, const float* wT, int Cin_total, int ci_offset,
+                          float* dx, int N, int H, int W, int Cout, int Ccols, int accumulate,
+                          unet_stream_t stream);
+/* dw[Cout][Cin_total] (columns ci_offset .. ci_offset+Cx); workspace sized by
+ * unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1) */
+int unet_conv1x1_bwd_weight(const float* x, int Cx, const float* dy, float* dw, int ci_offset,
+                            int Cin_total, void* workspace, size_t workspace_bytes, int N, int H,
+                            int W, int Cout, unet_stream_t stream);
+/* dst[C][R] = src[R][C]^T */
+int unet_transpose2d(const float* src, float* dst, int R, int C, unet_stream_t stream);
+
 /* ---- InstanceNorm2d(eps, affine) + LeakyReLU + SpatialDropout2d ----------- */
 
 /* Per-(n,c) statistics of y[N][HW][C] and the folded affine coefficients

@@ -55,7 +55,7 @@ def dropout_layers():
 
 
 # --------------------------------------------------------------------------- weights
-def fill_state_dict(seed, trained_like=True):
+def fill_state_dict(seed, trained_like=True, clip_dim=None):
     """Deterministic weights shared by the reference, the oracle and the HIP model.
 
     numpy PCG64 stream -> Kaiming-normal(fan_out, gain sqrt(2)) conv weights
@@ -82,6 +82,19 @@ def fill_state_dict(seed, trained_like=True):
         conv(f"{prefix}.{ci}", cout, cin, 3)
         norm(f"{prefix}.{ni}", cout)
     conv("segmentation_output", 3, FEATURES[0], 1)
+    if clip_dim is None:
+        return sd
+    # CLIP_UNet variant: clip_fusion_conv sits between encoder and decoder in the state_dict
+    # (CLIP_UNet/models/unet.py:356-362).  Its tensors come from a separate stream so the 90
+    # base tensors stay identical to the plain network's.
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    base, sd = sd, {}
+    f = FEATURES[-1]
+    for k, v in base.items():
+        if k.startswith("decoder_stages.0.") and "clip_fusion_conv.0.weight" not in sd:
+            conv("clip_fusion_conv.0", f, f + clip_dim, 1)
+            norm("clip_fusion_conv.1", f)
+        sd[k] = v
     return sd
 
 
@@ -140,15 +153,23 @@ def upsample_concat(x, skip):
 
 
 # --------------------------------------------------------------------------- network
-def unet_forward(sd, x, masks=None, record=None):
+def unet_forward(sd, x, masks=None, record=None, clip_features=None):
     """UNet.forward (models/unet.py:399-432).  `masks`: list from draw_dropout_masks (train
-    mode) or None (eval / rates 0).  `record` (debug): collects each conv's raw output."""
+    mode) or None (eval / rates 0).  `record` (debug): collects each conv's raw output.
+    `clip_features` [N,clip_dim,h/32,w/32]: the CLIP_UNet bottleneck fusion
+    (CLIP_UNet/models/unet.py:441-478): cat -> 1x1 conv -> InstanceNorm -> LeakyReLU."""
     mi = iter(masks) if masks is not None else None
     skips = []
     rows = layer_table()
     cur = x
     n_enc = 2 * len(FEATURES)
     for li, (prefix, ci, ni, _, _, stride, p, kind) in enumerate(rows):
+        if li == n_enc and clip_features is not None:
+            cur = torch.cat([cur, clip_features], dim=1)
+            cur = F.conv2d(cur, sd["clip_fusion_conv.0.weight"], sd["clip_fusion_conv.0.bias"])
+            cur = F.instance_norm(cur, weight=sd["clip_fusion_conv.1.weight"],
+                                  bias=sd["clip_fusion_conv.1.bias"], eps=EPS)
+            cur = F.leaky_relu(cur, NEG_SLOPE)
         if kind == "dec_first":
             cur = upsample_concat(cur, skips.pop())
         m = next(mi) if (mi is not None and p > 0) else None
@@ -209,13 +230,14 @@ def sgd_nesterov_(params, grads, bufs, lr=0.005, momentum=0.99, weight_decay=1e-
             p.add_(g, alpha=-lr)
 
 
-def train_step(sd, bufs, images, target, masks=None, lr=0.005, momentum=0.99, weight_decay=1e-4):
+def train_step(sd, bufs, images, target, masks=None, lr=0.005, momentum=0.99, weight_decay=1e-4,
+               clip_features=None):
     """One step in the order of train_one_epoch (src/train.py:634-664).  `sd` values must be
     leaf tensors with requires_grad=True; returns (loss, {name: grad})."""
     names = list(sd.keys())
     for v in sd.values():
         v.grad = None
-    logits = unet_forward(sd, images, masks)
+    logits = unet_forward(sd, images, masks, clip_features=clip_features)
     loss = simple_loss(logits, target)
     loss.backward()
     grads = {k: sd[k].grad.detach().clone() for k in names}

@@ -135,3 +135,17 @@ def test_poly_lr_schedule(ua):
         lrs.append(opt.param_groups[0]["lr"])
         sched.step()
     assert np.allclose(lrs, [0.005 * (1 - e / 10) ** 0.9 for e in range(3)])
+
+
+def test_clip_unet_surface(ua, golden):
+    g = golden("clip64")
+    m = ua.CLIPUNet()
+    assert [k for k, _ in m.named_parameters()] == [str(s) for s in g["param_names"]]
+    assert len(m.state_dict()) == 94 and sum(p.numel() for p in m.parameters()) == 20_181_059
+    assert (m.with_clip_features, m.clip_dim) == (True, 512)
+    assert m.check_supported() and m._fusion_layer.ksize == 1
+    assert isinstance(m.clip_fusion_conv[0], nn.Conv2d) and m.clip_fusion_conv[0].in_channels == 1024
+    plain = ua.CLIPUNet(with_clip_features=False)
+    assert len(plain.state_dict()) == 90 and not hasattr(plain, "clip_fusion_conv")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 3, 64, 64), torch.randn(1, 512, 2, 2))

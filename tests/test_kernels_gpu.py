@@ -168,6 +168,36 @@ def test_conv3x3_bwd_data(ua, shape):
     check(from_nhwc(buf), gx[:, off:off + cc] + base, 2e-5, f"dgrad acc {shape}")
 
 
+# --------------------------------------------------------------------------- 1x1 conv (CLIP fusion)
+@pytest.mark.parametrize("shape", [(2, 2, 2, 512, 512, 512), (1, 16, 16, 512, 512, 512),
+                                   (2, 4, 6, 64, 32, 96), (3, 5, 7, 32, 0, 32)])
+def test_conv1x1(ua, shape):
+    N, H, W, C0, C1, Cout = shape
+    x = rnd(N, C0 + C1, H, W, seed=40).requires_grad_(True)
+    w = rnd(Cout, C0 + C1, 1, 1, seed=41, scale=0.1).requires_grad_(True)
+    b = rnd(Cout, seed=42)
+    y = F.conv2d(x, w, b)
+    gy = rnd(*y.shape, seed=43)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    w2d = w.detach().view(Cout, C0 + C1).to(DEV).contiguous()
+    x0 = to_nhwc(x.detach()[:, :C0])
+    x1 = to_nhwc(x.detach()[:, C0:]) if C1 else None
+    yd = ua.ops.conv1x1_fwd(x0, x1, w2d, b.to(DEV))
+    check(from_nhwc(yd), y.detach(), 2e-5, f"conv1x1 fwd {shape}")
+    wT = ua.ops.transpose2d(w2d)
+    assert torch.equal(wT.cpu(), w2d.cpu().t().contiguous())
+    dx0 = ua.ops.conv1x1_bwd_data(to_nhwc(gy), wT, 0, C0)
+    check(from_nhwc(dx0), gx[:, :C0], 2e-5, f"conv1x1 dgrad {shape}")
+    if C1:
+        dx1 = ua.ops.conv1x1_bwd_data(to_nhwc(gy), wT, C0, C1)
+        check(from_nhwc(dx1), gx[:, C0:], 2e-5, f"conv1x1 dgrad slice {shape}")
+    dw = torch.full((Cout, C0 + C1), 3.0, device=DEV)
+    ua.ops.conv1x1_bwd_weight(x0, to_nhwc(gy), dw, 0)
+    if C1:
+        ua.ops.conv1x1_bwd_weight(x1, to_nhwc(gy), dw, C0)
+    check(dw.cpu(), gw.view(Cout, C0 + C1), 3e-5, f"conv1x1 wgrad {shape}")
+
+
 # --------------------------------------------------------------------------- conv wgrad
 WGRAD_SHAPES = [
     # N, H, W, Cx, ci_offset, Cin_total, Cout, stride

@@ -281,3 +281,53 @@ def test_bf16_matmul_mode_tracks_fp32(ua):
     img, tgt = O.synthetic_batch(3, 2, 64, 64)
     losses = [ua.train_step(model, opt, lossf, img.to(DEV), tgt.to(DEV)).item() for _ in range(12)]
     assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]
+
+
+def test_clip_unet_golden(ua, golden):
+    """CLIP_UNet variant (BASELINE config 5) against the fixture recorded from the reference's
+    CLIP_UNet/models/unet.py with synthetic CLIP features: eval + train logits, loss, gradients."""
+    g = golden("clip64")
+    n, hw, clip_dim = int(g["n"]), int(g["hw"]), int(g["clip_dim"])
+    sd0 = O.fill_state_dict(int(g["seed_w"]), clip_dim=clip_dim)
+    model = ua.CLIPUNet(with_clip_features=True, clip_dim=clip_dim)
+    assert [k for k, _ in model.named_parameters()] == [str(s) for s in g["param_names"]]
+    model.load_state_dict(sd0)
+    model = model.to(DEV)
+    img, tgt = O.synthetic_batch(int(g["seed_x"]), n, hw, hw)
+    img, tgt = img.to(DEV), tgt.to(DEV)
+    clip = torch.from_numpy(g["clip_features"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        le = model(img, clip)
+        plain = model(img)            # without features the fusion layer is skipped
+    assert relerr(le, torch.from_numpy(g["eval_logits"])) <= 1e-4
+    assert relerr(plain, le) > 1e-3
+    model.train()
+    model.dropout_mask_override = O.draw_dropout_masks(int(g["seed_drop"]), n)
+    logits = model(img, clip)
+    loss = ua.SimpleLoss()(logits, tgt)
+    loss.backward()
+    assert relerr(logits, torch.from_numpy(g["train_logits"])) <= 1e-4
+    assert abs(loss.item() - float(g["loss_0"])) <= 2e-4 * abs(float(g["loss_0"]))
+    bad = []
+    for i, (k, p) in enumerate(model.named_parameters()):
+        ref_norm = float(g[f"gnorm_{i}"])
+        got = p.grad.double().norm().item()
+        if ref_norm < 1e-4:
+            if got >= 1e-3:
+                bad.append(f"{k}: should be ~0")
+            continue
+        if abs(got - ref_norm) > 5e-3 * ref_norm:
+            bad.append(f"{k}: grad norm {got} vs {ref_norm}")
+        gk = p.grad.reshape(-1)
+        idx = torch.from_numpy(sample_idx(gk.numel())).to(DEV)
+        ref_s = torch.from_numpy(g[f"gsamp_{i}"])
+        err = (gk[idx].cpu() - ref_s).abs()
+        tol = 1e-2 * max(ref_s.abs().max().item(), ref_norm / gk.numel() ** 0.5)
+        if (err > tol).sum().item() > 3 or err.max().item() > 20 * tol:
+            bad.append(f"{k}: sampled grad err {err.max().item():.3e} (tol {tol:.3e})")
+    assert not bad, "\n".join(bad)
+    # one optimizer step through the flat arena (94 tensors)
+    opt = ua.create_optimizer(model)
+    loss2 = ua.train_step(model, opt, ua.get_loss_function(), img, tgt)
+    assert np.isfinite(loss2.item())

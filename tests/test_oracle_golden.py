@@ -131,3 +131,22 @@ def test_synthetic_batch_structure(hw):
     for i in range(4):
         vals = set(tgt[i].unique().tolist())
         assert vals <= {0, 1 + (i % 2), 255} and 255 in vals and 0 in vals
+
+
+def test_clip_variant_restatement(golden):
+    g = golden("clip64")
+    n, hw, clip_dim = int(g["n"]), int(g["hw"]), int(g["clip_dim"])
+    sd0 = O.fill_state_dict(int(g["seed_w"]), clip_dim=clip_dim)
+    assert list(sd0.keys()) == [str(s) for s in g["param_names"]] and len(sd0) == 94
+    base = O.fill_state_dict(int(g["seed_w"]))
+    assert all(torch.equal(sd0[k], v) for k, v in base.items())   # base tensors unchanged
+    img, tgt = O.synthetic_batch(int(g["seed_x"]), n, hw, hw)
+    clip = torch.from_numpy(g["clip_features"])
+    with torch.no_grad():
+        le = O.unet_forward(sd0, img, clip_features=clip)
+    assert relerr(le, torch.from_numpy(g["eval_logits"])) <= 1e-5
+    masks = O.draw_dropout_masks(int(g["seed_drop"]), n)
+    osd = O.leaf_state_dict(sd0)
+    loss, logits, grads = O.train_step(osd, [None] * len(osd), img, tgt, masks, clip_features=clip)
+    assert relerr(logits, torch.from_numpy(g["train_logits"])) <= 1e-5
+    assert abs(loss.item() - float(g["loss_0"])) <= 1e-5 * abs(float(g["loss_0"]))

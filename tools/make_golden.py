@@ -201,16 +201,66 @@ def net_run(hw, n, steps, tag, full_logits):
     print(f"{tag}.npz written")
 
 
+def clip_run():
+    """CLIP_UNet variant (reference: CLIP_UNet/models/unet.py, torch-only file) with synthetic
+    CLIP features: eval logits, one train step's loss and gradient norms/samples."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("clip_ref_unet",
+                                                  "/root/reference/CLIP_UNet/models/unet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, hw, clip_dim = 2, 64, 512
+    sd0 = O.fill_state_dict(SEED_W, clip_dim=clip_dim)
+    model = mod.UNet(with_clip_features=True, clip_dim=clip_dim)
+    model.load_state_dict(sd0)
+    img, tgt = O.synthetic_batch(SEED_X, n, hw, hw)
+    gen = torch.Generator().manual_seed(SEED_X + 1)
+    clip = torch.randn(n, clip_dim, hw // 32, hw // 32, generator=gen)
+    out = dict(seed_w=SEED_W, seed_x=SEED_X, seed_drop=SEED_DROP, n=n, hw=hw, clip_dim=clip_dim,
+               clip_features=npf(clip))
+    model.eval()
+    with torch.no_grad():
+        le = model(img, clip)
+        lo = O.unet_forward(sd0, img, clip_features=clip)
+    assert torch.equal(le, lo), "oracle CLIP eval forward != reference"
+    out["eval_logits"] = npf(le)
+    model.train()
+    torch.manual_seed(SEED_DROP)
+    logits = model(img, clip)
+    loss = RefLoss()(logits, tgt)
+    loss.backward()
+    masks = O.draw_dropout_masks(SEED_DROP, n)
+    osd = O.leaf_state_dict(sd0)
+    ol = O.unet_forward(osd, img, masks, clip_features=clip)
+    assert torch.equal(ol.detach(), logits.detach()), "oracle CLIP train forward != reference"
+    out["train_logits"] = npf(logits)
+    out["loss_0"] = npf(loss)
+    names = [k for k, _ in model.named_parameters()]
+    for i, (k, p) in enumerate(model.named_parameters()):
+        gk = p.grad.reshape(-1)
+        out[f"gnorm_{i}"] = np.float64(gk.double().norm().item())
+        out[f"gsamp_{i}"] = npf(gk[torch.from_numpy(sample_idx(gk.numel()))])
+    out["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "clip64.npz"), **out)
+    print("clip64.npz written, loss", loss.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-512", action="store_true")
+    ap.add_argument("--only-clip", action="store_true")
     args = ap.parse_args()
+    if args.only_clip:
+        os.makedirs(OUT, exist_ok=True)
+        clip_run()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     ops_small()
     net_run(64, 2, 3, "net64", full_logits=True)
     if not args.skip_512:
         net_run(512, 2, 3, "net512", full_logits=False)
+    clip_run()
 
 
 if __name__ == "__main__":

@@ -31,6 +31,10 @@ SIGNATURES = {
     "unet_conv3x3_bwd_data": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_fwd_bf16": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_data_bf16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_conv1x1_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "unet_conv1x1_bwd_data": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_conv1x1_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_transpose2d": (_i, [_p, _p, _i, _i, _p]),
     "unet_conv3x3_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "unet_conv3x3_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),
     "unet_instnorm_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -1165,3 +1165,53 @@ extern "C" int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int 
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
                                accumulate, true, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------
+// 1x1 convolution (the CLIP fusion layer of CLIP_UNet/models/unet.py:356-362): the same
+// gather-GEMM with a one-entry tap table.  w is [Cout][Cin] (the OIHW tensor itself),
+// wT is [Cin_total][Cout] for the data gradient.
+// ---------------------------------------------------------------------------
+extern "C" int unet_conv1x1_fwd(const float* x0, int C0, const float* x1, int C1, const float* w,
+                                const float* bias, float* y, int N, int H, int W, int Cout,
+                                unet_stream_t stream) {
+  UNET_REQUIRE(x0 && w && y, "conv1x1_fwd: null pointer");
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 32 == 0 && C0 > 0 && C0 % 32 == 0 &&
+                   C1 >= 0 && C1 % 32 == 0 && (C1 == 0 || x1),
+               "conv1x1_fwd: channel counts (%d,%d)->%d must be multiples of 32", C0, C1, Cout);
+  IgemmParams p{};
+  p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1;
+  p.w = w; p.tap_stride = Cout * (C0 + C1); p.n_off = 0; p.bias = bias;
+  UNET_REQUIRE((long long)N * H * W * (C0 > C1 ? C0 : C1) * 4 < (1LL << 31),
+               "conv1x1_fwd: tensor exceeds the 2 GiB buffer-descriptor range");
+  p.src0_bytes = (unsigned)((long long)N * H * W * C0 * 4);
+  p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 4);
+  p.w_bytes = (unsigned)((long long)Cout * (C0 + C1) * 4);
+  p.out = y; p.ldo = Cout; p.accumulate = 0;
+  p.N = N; p.Hin = p.Hl = p.Hout = H; p.Win = p.Wl = p.Wout = W;
+  p.Ncols = Cout; p.sin = 1; p.sout = 1; p.py = p.px = 0;
+  p.ntaps = 1; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
+  set_tap(p, 0, 0, 0, 0);
+  return dispatch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int unet_conv1x1_bwd_data(const float* dy, const float* wT, int Cin_total,
+                                     int ci_offset, float* dx, int N, int H, int W, int Cout,
+                                     int Ccols, int accumulate, unet_stream_t stream) {
+  UNET_REQUIRE(dy && wT && dx, "conv1x1_bwd_data: null pointer");
+  UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
+                   ci_offset + Ccols <= Cin_total, "conv1x1_bwd_data: bad channel slice");
+  IgemmParams p{};
+  p.src0 = dy; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
+  p.w = wT; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
+  UNET_REQUIRE((long long)N * H * W * Cout * 4 < (1LL << 31),
+               "conv1x1_bwd_data: tensor exceeds the 2 GiB buffer-descriptor range");
+  p.src0_bytes = (unsigned)((long long)N * H * W * Cout * 4);
+  p.src1_bytes = 0;
+  p.w_bytes = (unsigned)((long long)Cout * Cin_total * 4);
+  p.out = dx; p.ldo = Ccols; p.accumulate = accumulate;
+  p.N = N; p.Hin = p.Hl = p.Hout = H; p.Win = p.Wl = p.Wout = W;
+  p.Ncols = Ccols; p.sin = 1; p.sout = 1; p.py = p.px = 0;
+  p.ntaps = 1; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
+  set_tap(p, 0, 0, 0, 0);
+  return dispatch_igemm(p, (hipStream_t)stream);
+}

@@ -219,6 +219,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   reinterpret_cast<f32x4*>(out)[(size_t)c * E4 + e] = acc;
 }
 
+// 1x1 weight gradient = centre tap of the 3x3 slabs: dw[co][ci_off+ci] = sum_s partial[s][4][ci][co]
+__global__ __launch_bounds__(256) void wgrad_reduce_center_kernel(const float* __restrict__ partial,
+                                                                  float* __restrict__ dw, int split,
+                                                                  int Cx, int Cout, int ci_off,
+                                                                  int Cin_total) {
+  __shared__ float tile[32][33];
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const size_t slab = (size_t)9 * Cx * Cout;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ci = r + 8 * k;
+    const float* src = partial + ((size_t)4 * Cx + ci0 + ci) * Cout + co0 + c;
+    float s = 0.f;
+    for (int q = 0; q < split; ++q) s += src[(size_t)q * slab];
+    tile[ci][c] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int co = r + 8 * k;
+    dw[(size_t)(co0 + co) * Cin_total + ci_off + ci0 + c] = tile[c][co];
+  }
+}
+
 // dw_oihw[co][ci_off+ci][tap] = sum_s partial[s][tap][ci][co]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            float* __restrict__ dw, int split,
@@ -431,11 +456,10 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
   return make_plan(N, H, W, Cx, Cout, stride).ws_floats * sizeof(float);
 }
 
-extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, float* dw_oihw,
-                                       int ci_offset, int Cin_total, float* db, void* workspace,
-                                       size_t workspace_bytes, int N, int H, int W, int Cout,
-                                       int stride, unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
+                                int ci_offset, int Cin_total, float* db, void* workspace,
+                                size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
+                                bool center_only, hipStream_t stream) {
   UNET_REQUIRE(x && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
@@ -524,9 +548,15 @@ extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, 
       float* t = ping; ping = pong; pong = t;
       nslab = chunks;
     }
-    dim3 rgrid(Cout / 32, Cx / 8);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
-                       Cout, ci_offset, Cin_total);
+    if (center_only) {
+      dim3 rgrid(Cout / 32, Cx / 32);
+      hipLaunchKernelGGL(wgrad_reduce_center_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw,
+                         nslab, Cx, Cout, ci_offset, Cin_total);
+    } else {
+      dim3 rgrid(Cout / 32, Cx / 8);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
+                         Cout, ci_offset, Cin_total);
+    }
     UNET_CHECK_LAUNCH("wgrad_reduce");
   }
   if (db) {
@@ -535,4 +565,24 @@ extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, 
     UNET_CHECK_LAUNCH("bias_grad");
   }
   return UNET_OK;
+}
+
+extern "C" int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, float* dw_oihw,
+                                       int ci_offset, int Cin_total, float* db, void* workspace,
+                                       size_t workspace_bytes, int N, int H, int W, int Cout,
+                                       int stride, unet_stream_t stream) {
+  return conv_bwd_weight_impl(x, Cx, dy, dw_oihw, ci_offset, Cin_total, db, workspace,
+                              workspace_bytes, N, H, W, Cout, stride, false, (hipStream_t)stream);
+}
+
+// 1x1 weight gradient dw[Cout][Cin_total] (columns ci_offset .. +Cx).  Runs the 3x3 kernel and
+// keeps its centre tap (the fusion layer sits at 1/32 resolution: 2,048 pixels at bs 8, so the
+// 9x matrix work is ~0.2 ms); workspace as unet_conv3x3_bwd_weight_workspace_bytes(.., 1).
+extern "C" int unet_conv1x1_bwd_weight(const float* x, int Cx, const float* dy, float* dw,
+                                       int ci_offset, int Cin_total, void* workspace,
+                                       size_t workspace_bytes, int N, int H, int W, int Cout,
+                                       unet_stream_t stream) {
+  UNET_REQUIRE(Cx % 32 == 0, "conv1x1_bwd_weight: Cx %d must be a multiple of 32", Cx);
+  return conv_bwd_weight_impl(x, Cx, dy, dw, ci_offset, Cin_total, nullptr, workspace,
+                              workspace_bytes, N, H, W, Cout, 1, true, (hipStream_t)stream);
 }

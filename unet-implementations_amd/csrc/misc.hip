@@ -50,6 +50,25 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// ---- 2-D transpose (1x1 weights for the data gradient) ------------------------------------
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, int R, int C) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    t[ty + 8 * k][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < R && c < C) dst[(size_t)c * R + r] = t[tx][ty + 8 * k];
+  }
+}
+
 // ---- weight packing -----------------------------------------------------------
 // wf[t][co][ci] (forward: K = ci contiguous) and wd[t][ci][co] (dgrad: K = co contiguous)
 // from w[co][ci][t]
@@ -274,5 +293,13 @@ extern "C" int unet_add_inplace(float* a, const float* b, int64_t n, unet_stream
   hipLaunchKernelGGL(add_inplace_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream,
                      a, b, (long long)n);
   UNET_CHECK_LAUNCH("add_inplace");
+  return UNET_OK;
+}
+
+extern "C" int unet_transpose2d(const float* src, float* dst, int R, int C, unet_stream_t stream) {
+  UNET_REQUIRE(src && dst && R > 0 && C > 0, "transpose2d: bad argument");
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, R, C);
+  UNET_CHECK_LAUNCH("transpose2d");
   return UNET_OK;
 }

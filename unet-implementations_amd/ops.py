@@ -158,6 +158,47 @@ def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None):
     return dw_oihw
 
 
+# ---- 1x1 convolution (CLIP fusion layer) ------------------------------------------------
+def conv1x1_fwd(x0, x1, w2d, bias):
+    """y = conv1x1(cat(x0, x1)) + bias; w2d is [Cout, C0+C1]."""
+    N, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    Cout = w2d.shape[0]
+    assert w2d.shape[1] == C0 + C1 and w2d.is_contiguous()
+    y = _f32((N, H, W, Cout), x0)
+    check(lib().unet_conv1x1_fwd(_ptr(x0), C0, _ptr(x1), C1, _ptr(w2d), _ptr(bias), _ptr(y), N, H,
+                                 W, Cout, _stream()))
+    return y
+
+
+def transpose2d(w2d):
+    R, C = w2d.shape
+    out = _f32((C, R), w2d)
+    check(lib().unet_transpose2d(_ptr(w2d), _ptr(out), R, C, _stream()))
+    return out
+
+
+def conv1x1_bwd_data(dy, wT, ci_offset, ccols, accumulate=False, out=None):
+    N, H, W, Cout = dy.shape
+    cin_total = wT.shape[0]
+    assert wT.shape[1] == Cout
+    dx = out if out is not None else _f32((N, H, W, ccols), dy)
+    check(lib().unet_conv1x1_bwd_data(_ptr(dy), _ptr(wT), cin_total, ci_offset, _ptr(dx), N, H, W,
+                                      Cout, ccols, 1 if accumulate else 0, _stream()))
+    return dx
+
+
+def conv1x1_bwd_weight(x, dy, dw2d, ci_offset):
+    N, H, W, Cx = x.shape
+    Cout = dy.shape[3]
+    assert dw2d.shape[0] == Cout and dw2d.is_contiguous()
+    ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1), x)
+    check(lib().unet_conv1x1_bwd_weight(_ptr(x), Cx, _ptr(dy), _ptr(dw2d), ci_offset,
+                                        dw2d.shape[1], _ptr(ws), ws.numel(), N, H, W, Cout,
+                                        _stream()))
+    return dw2d
+
+
 # ---- InstanceNorm + LeakyReLU + channel dropout -----------------------------------
 def instnorm_stats(y, gamma, beta, eps):
     N, H, W, C = y.shape

@@ -112,11 +112,12 @@ class UpBlock(nn.Module):
 class _Layer:
     """One conv3x3 + InstanceNorm + LeakyReLU (+ dropout) unit of the fused plan."""
 
-    __slots__ = ("conv", "norm", "slope", "drop", "stride", "first_of_decoder", "name")
+    __slots__ = ("conv", "norm", "slope", "drop", "stride", "first_of_decoder", "name", "ksize")
 
-    def __init__(self, conv, norm, slope, drop, stride, first_of_decoder, name):
+    def __init__(self, conv, norm, slope, drop, stride, first_of_decoder, name, ksize=3):
         self.conv, self.norm, self.slope, self.drop = conv, norm, slope, drop
         self.stride, self.first_of_decoder, self.name = stride, first_of_decoder, name
+        self.ksize = ksize
 
 
 def _as_int(v):
@@ -176,6 +177,8 @@ class UNet(nn.Module):
                           n_convs=n_conv_per_stage[s],
                           spatial_dropout_rate=encoder_dropout_rates[s], **common))
             cin = features_per_stage[s]
+        self._fusion_layer = None
+        self._build_bottleneck(common)      # registration order = state_dict / arena order
         self.decoder_stages = nn.ModuleList()
         for s in range(n_stages - 1):
             lvl = n_stages - 2 - s
@@ -199,6 +202,9 @@ class UNet(nn.Module):
         # rounded to bf16 on chip and contracted on the bf16 matrix cores with fp32 accumulation
         # (tensors, InstanceNorm statistics, weight gradients, master weights stay fp32)
         self.matmul_precision = "fp32"
+
+    def _build_bottleneck(self, common):
+        """Hook for variants that add modules between encoder and decoder (CLIPUNet)."""
 
     # -- reference: Our_UNet/models/unet.py:386-397 --------------------------------------
     def initialize_weights(self):
@@ -307,7 +313,7 @@ class UNet(nn.Module):
         return self._grad_arena[off:off + p.numel()].view(p.shape)
 
     # -- forward ----------------------------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, extra=None):
         if not x.is_cuda:
             raise RuntimeError("unet-implementations_amd.UNet runs on MI355X only: move the model "
                                "and the input to a ROCm device (no CPU fallback exists)")
@@ -323,7 +329,13 @@ class UNet(nn.Module):
         params = list(self.parameters())
         self._param_index = {id(p): i for i, p in enumerate(params)}
         x = x.contiguous().float()
-        return _UNetFunction.apply(self, x, *params)
+        return _UNetFunction.apply(self, x, self._bottleneck_input(x, extra), *params)
+
+    def _bottleneck_input(self, x, extra):
+        """Second source of the bottleneck fusion layer (NHWC) or None; CLIPUNet overrides."""
+        if extra is not None:
+            raise TypeError("this UNet takes no extra bottleneck features")
+        return None
 
 
 def _draw_masks(model, layers, n, device):
@@ -343,9 +355,11 @@ def _draw_masks(model, layers, n, device):
 
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, x, *params):
+    def forward(ctx, model, x, extra, *params):
         enc, dec = model._plan
-        layers = [l for blk in enc for l in blk] + [l for blk in dec for l in blk]
+        fusion = model._fusion_layer if extra is not None else None
+        layers = [l for blk in enc for l in blk] + ([fusion] if fusion is not None else []) + \
+            [l for blk in dec for l in blk]
         need_grad = any(ctx.needs_input_grad)  # False under no_grad / frozen parameters
         N = x.shape[0]
         use_masks = model.training or model.dropout_mask_override is not None
@@ -358,8 +372,13 @@ class _UNetFunction(torch.autograd.Function):
 
         def run_layer(l, x0, x1):
             w = l.conv.weight
-            wf, wd = ops.pack_conv3x3_weights(w.detach(), want_wd=need_grad)
-            y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride, bf16=bf16)
+            if l.ksize == 1:
+                w2d = w.detach().view(w.shape[0], w.shape[1])
+                wd = ops.transpose2d(w2d) if need_grad else None
+                y = ops.conv1x1_fwd(x0, x1, w2d, l.conv.bias.detach())
+            else:
+                wf, wd = ops.pack_conv3x3_weights(w.detach(), want_wd=need_grad)
+                y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride, bf16=bf16)
             st = ops.instnorm_stats(y, l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps)
             m = mask_of[id(l)]
             a = ops.instnorm_lrelu_drop_fwd(y, st[2], st[3], m, l.slope)
@@ -374,6 +393,11 @@ class _UNetFunction(torch.autograd.Function):
                 cur = run_layer(l, cur, None)
             if bi < len(enc) - 1:
                 skips.append(cur)
+        if fusion is not None:
+            if extra.shape[:3] != cur.shape[:3]:
+                raise NotImplementedError("bottleneck features must match the 1/32-resolution "
+                                          f"grid {tuple(cur.shape[1:3])} (got {tuple(extra.shape[1:3])})")
+            cur = run_layer(fusion, cur, extra)
         for di, blk in enumerate(dec):
             skip = skips[len(skips) - 1 - di]
             if cur.shape[1] * 2 != skip.shape[1] or cur.shape[2] * 2 != skip.shape[2]:
@@ -390,6 +414,7 @@ class _UNetFunction(torch.autograd.Function):
             ctx.n_enc_blocks = len(enc)
             ctx.params = params
             ctx.bf16 = bf16
+            ctx.fusion = fusion
         return logits
 
     @staticmethod
@@ -428,6 +453,13 @@ class _UNetFunction(torch.autograd.Function):
                 dbg.append((l.name, "dy", dy.clone()))
             x0, x1 = rec["x0"], rec["x1"]
             dw = gv(l.conv.weight)
+            if l.ksize == 1:
+                dw2d = dw.view(dw.shape[0], dw.shape[1])
+                ops.conv1x1_bwd_weight(x0, dy, dw2d, 0)
+                if x1 is not None:
+                    ops.conv1x1_bwd_weight(x1, dy, dw2d, x0.shape[3])
+                dx0 = ops.conv1x1_bwd_data(dy, rec["wd"], 0, x0.shape[3]) if need_dx else None
+                return dx0, None      # the second source (frozen CLIP features) needs no gradient
             ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride)
             if x1 is not None:
                 ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride)
@@ -452,6 +484,10 @@ class _UNetFunction(torch.autograd.Function):
             skip_grads[len(enc) - 2 - di] = g_skip
             g = ops.upsample2x_bwd(g_up)
             ready(model.decoder_stages[di])
+        if ctx.fusion is not None:
+            g, _ = layer_bwd(saved[idx], g)
+            idx -= 1
+            ready(model.clip_fusion_conv)
         # encoder stages, last to first
         for bi in range(len(enc) - 1, -1, -1):
             blk = enc[bi]
@@ -472,4 +508,4 @@ class _UNetFunction(torch.autograd.Function):
         assert idx == -1 and n_enc_layers > 0
         ctx.saved = None
         grads = [gv(p) if p.requires_grad else None for p in params]
-        return (None, None, *grads)
+        return (None, None, None, *grads)
