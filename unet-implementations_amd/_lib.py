@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+# UNET_HIP_LIB selects an alternative in-tree build (A/B experiments of kernel variants)
+LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(_HERE, "libunet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _c = ctypes

@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     advance(ks + 2 < KS);
     const float* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
     const float* Bb = Bs + buf * B_TILE + wn0 * LDA + frag_off;
+#ifdef UNET_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     f32x4 a[2][TM], b[2][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDA);
@@ -206,6 +209,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][n][r], acc[m][n],
                                                              0, 0, 0);
     }
+#ifdef UNET_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     store_tiles(buf ^ 1);
     // Pin the software pipeline (hipcc otherwise sinks every read to just before its first
     // use): fragment reads run one k-group ahead of the MFMAs, the next tile's buffer loads
