@@ -104,6 +104,13 @@ int unet_conv3x3_bwd_weight(const float* x, int Cx, const float* dy, float* dw_o
                             size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
                             unet_stream_t stream);
 
+/* bf16 mixed-precision weight gradient (config 4): same arguments; stride-1 layers run on the
+ * bf16 matrix cores (operands rounded on chip, fp32 sums), the rest fall back to fp32. */
+int unet_conv3x3_bwd_weight_bf16(const float* x, int Cx, const float* dy, float* dw_oihw,
+                                 int ci_offset, int Cin_total, float* db, void* workspace,
+                                 size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
+                                 unet_stream_t stream);
+
 /* ---- 1x1 convolution (CLIP fusion layer) ---------------------------------- */
 
 /* y = conv1x1(cat(x0, x1)) + bias with w[Cout][C0+C1]; replaces clip_fusion_conv[0] =

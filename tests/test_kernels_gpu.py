@@ -131,6 +131,33 @@ def test_conv3x3_bwd_data_bf16(ua, shape):
     check(from_nhwc(dx), gx[:, off:off + cc], 2e-5, f"bf16 dgrad {shape}")
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 64, 32, 0, 32, 32, 1), (1, 16, 16, 64, 0, 64, 64, 1),
+                                   (2, 8, 8, 128, 0, 128, 128, 1), (1, 32, 32, 64, 32, 96, 64, 1),
+                                   (1, 64, 128, 32, 0, 32, 32, 1), (1, 32, 64, 32, 0, 32, 64, 1),
+                                   (2, 16, 24, 32, 0, 32, 64, 2), (3, 34, 70, 32, 0, 32, 32, 1)])
+def test_conv3x3_bwd_weight_bf16(ua, shape):
+    """bf16 operands via ds_read_b64_tr_b16, fp32 sums: equals the fp32 weight gradient of the
+    bf16-rounded x and dy (shapes the bf16 kernel does not cover fall back to fp32)."""
+    N, H, W, Cx, off, Ct, Cout, s = shape
+    x = rnd(N, Ct, H, W, seed=10)
+    w = rnd(Cout, Ct, 3, 3, seed=11, scale=0.1).requires_grad_(True)
+    y = F.conv2d(_bf(x), w, None, stride=s, padding=1)
+    gy = rnd(*y.shape, seed=12)
+    (gw,) = torch.autograd.grad(y, w, _bf(gy))
+    y32 = F.conv2d(x, w, None, stride=s, padding=1)
+    (gw32,) = torch.autograd.grad(y32, w, gy)
+    dw = torch.zeros((Cout, Ct, 3, 3), device=DEV)
+    ua.ops.conv3x3_bwd_weight(to_nhwc(x[:, off:off + Cx]), to_nhwc(gy), dw, off, s, bf16=True)
+    got = dw[:, off:off + Cx].cpu()
+    e_bf, e_32 = relerr(got, gw[:, off:off + Cx]), relerr(got, gw32[:, off:off + Cx])
+    on_bf16_kernel = s == 1 and not (Cx == 32 and Cout == 32 and W < 64)   # mirrors make_plan()
+    if on_bf16_kernel:
+        assert e_bf <= 3e-5 and e_32 > 1e-4, \
+            f"bf16 wgrad {shape}: vs bf16-rounded {e_bf:.2e}, vs fp32 {e_32:.2e}"
+    else:
+        assert e_32 <= 3e-5, f"fp32 fallback {shape}: {e_32:.2e}"
+
+
 # --------------------------------------------------------------------------- conv dgrad
 DGRAD_SHAPES = [
     # N, H, W, Cin, Cout, stride, (ci_offset, ccols)

@@ -19,6 +19,9 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
 struct WgradParams {
   const float* x;   // [N][H][W][Cx]
   const float* dy;  // [N][Ho][Wo][Cout]
@@ -201,6 +204,184 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       }
     }
 }
+
+// ---------------------------------------------------------------------------
+// bf16 mixed-precision weight gradient (stride 1): same blocking, slabs and loader as
+// conv_wgrad_kernel; operands are rounded to bf16 while staged into LDS as
+// [32-channel sub-tile][pixel][32] (64-B rows) and read as MFMA fragments with the gfx950
+// transposing LDS read ds_read_b64_tr_b16 (the reduction axis = pixels is the ROW axis of
+// both tiles): per 16-pixel k-group 2 reads per operand, v_mfma_f32_32x32x16_bf16, fp32 sums.
+// Lane l: g = l>>4, h = g>>1, q = (l&15)>>2, p = l&3 supplies row 8h + 4*half + q, columns
+// 16*(g&1) + 4p and receives column l&31 of those four rows = operand element k = 8h+4*half+q'.
+// ---------------------------------------------------------------------------
+template <int CI_T, int CO_T, int S>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradParams p) {
+  constexpr int STRIDE = 1;
+  constexpr int TI = CI_T / 32, TJ = CO_T / 32;
+  constexpr int NSB = TI * TJ, NPP = 4 / NSB;
+  static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
+  constexpr int NT = 256;
+  constexpr int PW = (S - 1) * STRIDE + 3;
+  constexpr int NP4 = 3 * PW * CI_T / 4;   // float4 slots of the patch
+  constexpr int ND4 = S * CO_T / 4;        // float4 slots of the dy segment
+  constexpr int PATCH = NP4 * 4;           // elements
+  constexpr int STAGE = PATCH + ND4 * 4;
+  // loader slots: the first NLP slots of every thread are patch slots, the next NLD dy slots
+  // (slot kind is a compile-time property: no per-slot select, no branch)
+  constexpr int NLP = (NP4 + NT - 1) / NT, NLD = (ND4 + NT - 1) / NT;
+  constexpr int NG = (S / 16) / NPP;       // 16-pixel k-groups per wave per segment
+  static_assert((S / 16) % NPP == 0 && NG >= 1, "segment must split into whole k-groups");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  constexpr int PSUB = 3 * PW * 32, DSUB = S * 32;   // elements per 32-channel sub-tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int sb = wave % NSB, pp = wave / NSB;
+  const int wi = sb / TJ, wj = sb - wi * TJ;
+
+  int bid = blockIdx.x;
+  const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+  const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+  const int sp = bid;
+  const int ci0 = ci_t * CI_T, co0 = co_t * CO_T;
+  const int g_begin = sp * p.segs_per_block;
+  const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+  // patch slot: (row-1, col-1, channel); invalid slots (idx >= NP4) get row = -2^20 so the
+  // bounds test fails and the buffer load returns 0
+  int p_r[NLP], p_c[NLP], p_ch[NLP];
+#pragma unroll
+  for (int k = 0; k < NLP; ++k) {
+    const int idx = tid + NT * k;
+    const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    p_r[k] = idx < NP4 ? prow - 1 : -(1 << 20);
+    p_c[k] = pcol - 1;
+    p_ch[k] = ci0 + seg * 4;
+  }
+  int d_p[NLD], d_ch[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int d = tid + NT * k;
+    const int dpix = d / (CO_T / 4), seg = d - dpix * (CO_T / 4);
+    d_p[k] = d < ND4 ? dpix : (1 << 20);
+    d_ch[k] = co0 + seg * 4;
+  }
+
+  f32x4 rp[NLP], rd[NLD];
+  auto load_stage = [&](int g) {
+    const int xs = g % p.segs_per_row;
+    const int r = g / p.segs_per_row;
+    const int oy = r % p.Ho;
+    const int n = r / p.Ho;
+    const int x0 = xs * S;
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int iy = oy * STRIDE + p_r[k], ix = x0 * STRIDE + p_c[k];
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = ((unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + p_ch[k]) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      rp[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int ox = x0 + d_p[k];
+      const bool ok = ox < p.Wo;
+      const unsigned off = ((unsigned)(((n * p.Ho + oy) * p.Wo + ox) * p.Cout + d_ch[k]) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      rd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+    }
+  };
+  auto to_bf16 = [](const f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    return h;
+  };
+  // LDS element offset of patch slot idx: [sub][pixel][32]; seg = idx % (CI_T/4) -> channel 4*seg
+  auto store_stage = [&](int buf) {
+    __bf16* base = smem_h + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < NLP; ++k) {
+      const int idx = tid + NT * k;
+      const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
+      if (NT * (k + 1) <= NP4 || idx < NP4)
+        *reinterpret_cast<bf16x4*>(base + (seg >> 3) * PSUB + pix * 32 + (seg & 7) * 4) = to_bf16(rp[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int d = tid + NT * k;
+      const int dpix = d / (CO_T / 4), seg = d - dpix * (CO_T / 4);
+      if (NT * (k + 1) <= ND4 || d < ND4)
+        *reinterpret_cast<bf16x4*>(base + PATCH + (seg >> 3) * DSUB + dpix * 32 + (seg & 7) * 4) = to_bf16(rd[k]);
+    }
+  };
+
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+
+  if (g_begin < g_end) {
+    load_stage(g_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int g = g_begin; g < g_end; ++g) {
+      const int buf = (g - g_begin) & 1;
+      // always stage (the last iteration re-stages the final segment into the idle buffer):
+      // branch-free, so the compute part of a stage is one scheduling region
+      load_stage(min(g + 1, g_end - 1));
+      const __bf16* P = smem_h + buf * STAGE + wi * PSUB;
+      const __bf16* D = smem_h + buf * STAGE + PATCH + wj * DSUB;
+      const int tg = lane >> 4, th = tg >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+      const int tcol = 16 * (tg & 1) + 4 * tp;
+      typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const int xx0 = 16 * (pp + NPP * gq);          // first pixel of this k-group
+        const int r0 = xx0 + 8 * th + tq;              // this lane's row for half 0 (+4 for half 1)
+        bf16x8 b;
+        {
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(D + r0 * 32 + tcol));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(D + (r0 + 4) * 32 + tcol));
+          b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            const __bf16* pa = P + (u * PW + r0 + v) * 32 + tcol;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pa);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pa + 4 * 32));
+            const bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[u][v], 0, 0, 0);
+          }
+      }
+      store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      float* out = p.partial + ((size_t)((sp * NPP + pp) * 9 + u * 3 + v) * p.Cx) * p.Cout;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[u][v][r];
+      }
+    }
+}
+
 
 // Stage A of the slab reduction: out[c][e] = sum of slabs [16c, 16c+16) of in[.][e]
 // (fixed order).  Applied until <= 8 slabs remain so the final kernel stays shallow.
@@ -430,21 +611,35 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, long long M,
-                                 int C) {
-  // one block per 32 channels; threads stride over pixels; fixed-order tree => deterministic
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
+  constexpr int PW = S + 2;
+  constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<CI_T, CO_T, S>), dim3(grid), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_wgrad_bf16");
+  return UNET_OK;
+}
+
+// db[c] = sum over pixels of dy[.][c]: 64 row chunks per 32-channel group, then the chunk sums
+// (fixed order => deterministic).  out[chunk][C] when chunks > 1.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
+                                                        float* __restrict__ out, long long M,
+                                                        int C, long long rows_per_chunk) {
   __shared__ float red[8][33];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   const int r = threadIdx.x >> 5;
+  const long long m0 = (long long)blockIdx.y * rows_per_chunk;
+  const long long m1 = m0 + rows_per_chunk < M ? m0 + rows_per_chunk : M;
   float s = 0.f;
-  for (long long m = r; m < M; m += 8) s += dy[(size_t)m * C + c];
+  for (long long m = m0 + r; m < m1; m += 8) s += dy[(size_t)m * C + c];
   red[r][threadIdx.x & 31] = s;
   __syncthreads();
   if (r == 0) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-    db[c] = t;
+    out[(size_t)blockIdx.y * C + c] = t;
   }
 }
 
@@ -459,7 +654,7 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
 static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
                                 int ci_offset, int Cin_total, float* db, void* workspace,
                                 size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
-                                bool center_only, hipStream_t stream) {
+                                bool center_only, hipStream_t stream, bool bf16 = false) {
   UNET_REQUIRE(x && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
@@ -510,7 +705,14 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     p.x_bytes = (unsigned)((long long)N * H * W * Cx * 4);
     p.dy_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
     int rc;
-    if (pl.ci_t == 32 && pl.co_t == 32) {
+    // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
+    const bool use_bf16 = bf16 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
+    if (use_bf16) {
+      if (pl.ci_t == 32 && pl.co_t == 32) rc = launch_wgrad_bf16<32, 32, 64>(p, stream);
+      else if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32>(p, stream);
+      else rc = pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
+                           : launch_wgrad_bf16<64, 64, 16>(p, stream);
+    } else if (pl.ci_t == 32 && pl.co_t == 32) {
       if (stride == 1)
         rc = pl.S == 64 ? launch_wgrad<32, 32, 64, 1>(p, stream)
            : pl.S == 32 ? launch_wgrad<32, 32, 32, 1>(p, stream)
@@ -560,8 +762,20 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     UNET_CHECK_LAUNCH("wgrad_reduce");
   }
   if (db) {
+    // the slab workspace is free again at this point of the stream; reuse its head as scratch
     const long long M = (long long)N * Ho * Wo;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 32), dim3(256), 0, stream, dy, db, M, Cout);
+    const int chunks = M >= 4096 ? 64 : 1;
+    const long long rpc = ceil_div64(M, chunks);
+    if (chunks == 1) {
+      hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 32, 1), dim3(256), 0, stream, dy, db, M,
+                         Cout, rpc);
+    } else {
+      hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 32, chunks), dim3(256), 0, stream, dy, ws, M,
+                         Cout, rpc);
+      UNET_CHECK_LAUNCH("bias_grad(stage)");
+      hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout / 32, 1), dim3(256), 0, stream, ws, db,
+                         (long long)chunks, Cout, (long long)chunks);
+    }
     UNET_CHECK_LAUNCH("bias_grad");
   }
   return UNET_OK;
@@ -585,4 +799,14 @@ extern "C" int unet_conv1x1_bwd_weight(const float* x, int Cx, const float* dy, 
   UNET_REQUIRE(Cx % 32 == 0, "conv1x1_bwd_weight: Cx %d must be a multiple of 32", Cx);
   return conv_bwd_weight_impl(x, Cx, dy, dw, ci_offset, Cin_total, nullptr, workspace,
                               workspace_bytes, N, H, W, Cout, 1, true, (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_bwd_weight_bf16(const float* x, int Cx, const float* dy,
+                                            float* dw_oihw, int ci_offset, int Cin_total,
+                                            float* db, void* workspace, size_t workspace_bytes,
+                                            int N, int H, int W, int Cout, int stride,
+                                            unet_stream_t stream) {
+  return conv_bwd_weight_impl(x, Cx, dy, dw_oihw, ci_offset, Cin_total, db, workspace,
+                              workspace_bytes, N, H, W, Cout, stride, false, (hipStream_t)stream,
+                              true);
 }

@@ -140,7 +140,7 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     return dx
 
 
-def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None):
+def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None, bf16=False):
     N, H, W, Cx = x.shape
     Cout = dy.shape[3]
     cin_total = dw_oihw.shape[1]
@@ -148,12 +148,12 @@ def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None):
     nbytes = lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride)
     ws = _ws(nbytes, x)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv3x3_bwd_weight(_ptr(x), Cx, _ptr(dy), _ptr(dw_oihw), ci_offset,
-                                        cin_total, _ptr(db), _ptr(ws), ws.numel(), N, H, W, Cout,
-                                        stride, _stream()))
+    fn = lib().unet_conv3x3_bwd_weight_bf16 if bf16 else lib().unet_conv3x3_bwd_weight
+    check(fn(_ptr(x), Cx, _ptr(dy), _ptr(dw_oihw), ci_offset, cin_total, _ptr(db), _ptr(ws),
+             ws.numel(), N, H, W, Cout, stride, _stream()))
     if t0 is not None:  # wgrad kernel + slab reduce
         Ho, Wo = dy.shape[1], dy.shape[2]
-        _timer.end("conv_stem_wgrad" if Cx == 3 else "conv_wgrad",
+        _timer.end("conv_stem_wgrad" if Cx == 3 else ("conv_wgrad_bf16" if bf16 else "conv_wgrad"),
                    2.0 * N * Ho * Wo * 9 * Cx * Cout, 2, t0)
     return dw_oihw
 

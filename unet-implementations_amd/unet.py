@@ -198,9 +198,9 @@ class UNet(nn.Module):
         # data-parallel hook: called during backward as `hook(lo)` once every gradient at arena
         # offsets >= lo is final (backward completes the arena back to front)
         self.grad_ready_hook = None
-        # "fp32" (default, the parity path) or "bf16": conv forward / data-gradient operands are
-        # rounded to bf16 on chip and contracted on the bf16 matrix cores with fp32 accumulation
-        # (tensors, InstanceNorm statistics, weight gradients, master weights stay fp32)
+        # "fp32" (default, the parity path) or "bf16": the conv operands (forward, data gradient,
+        # stride-1 weight gradient) are rounded to bf16 on chip and contracted on the bf16 matrix
+        # cores with fp32 accumulation (tensors, InstanceNorm statistics, master weights: fp32)
         self.matmul_precision = "fp32"
 
     def _build_bottleneck(self, common):
@@ -460,9 +460,9 @@ class _UNetFunction(torch.autograd.Function):
                     ops.conv1x1_bwd_weight(x1, dy, dw2d, x0.shape[3])
                 dx0 = ops.conv1x1_bwd_data(dy, rec["wd"], 0, x0.shape[3]) if need_dx else None
                 return dx0, None      # the second source (frozen CLIP features) needs no gradient
-            ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride)
+            ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride, bf16=ctx.bf16)
             if x1 is not None:
-                ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride)
+                ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride, bf16=ctx.bf16)
             dx0 = dx1 = None
             if need_dx:
                 N, H, W, C0 = x0.shape
