@@ -331,3 +331,91 @@ def test_clip_unet_golden(ua, golden):
     opt = ua.create_optimizer(model)
     loss2 = ua.train_step(model, opt, ua.get_loss_function(), img, tgt)
     assert np.isfinite(loss2.item())
+
+
+def _grads_after_backward(ua, model, img, tgt, masks):
+    model.dropout_mask_override = masks
+    for p in model.parameters():
+        p.grad = None
+    loss = ua.SimpleLoss()(model(img), tgt)
+    loss.backward()
+    return {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("frozen_stages", [6, 3])
+def test_frozen_encoder_backward(ua, frozen_stages):
+    """AE-transfer style freezing (AE_pretrained/transfer_learning/models/unet.py:448-454): the
+    trainable parameters get exactly the gradients of the unfrozen run, frozen ones get none
+    and are not touched by the optimizer."""
+    sd0 = O.fill_state_dict(11)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    img, tgt = O.synthetic_batch(21, 2, 64, 64)
+    img, tgt = img.to(DEV), tgt.to(DEV)
+    masks = O.draw_dropout_masks(3, 2)
+    full = _grads_after_backward(ua, model, img, tgt, masks)
+    if frozen_stages == 6:
+        missing = model.load_pretrained_encoder({"model_state_dict": sd0})
+        assert missing == []
+    else:
+        for s in range(frozen_stages):
+            for p in model.encoder_stages[s].parameters():
+                p.requires_grad = False
+    part = _grads_after_backward(ua, model, img, tgt, masks)
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            assert part[k] is None, k
+        else:
+            assert torch.equal(part[k], full[k]), f"{k}: gradient changed by freezing"
+    opt = ua.create_optimizer(model)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    for k, p in model.named_parameters():
+        changed = not torch.equal(p.detach(), before[k])
+        assert changed == p.requires_grad, k
+
+
+def test_checkpoint_roundtrip(ua, tmp_path):
+    """save_checkpoint/load_checkpoint keep the reference's dictionary layout and resume the
+    FusedSGD trajectory exactly (momentum buffers re-adopted into the flat arena)."""
+    torch.manual_seed(5)
+    img, tgt = O.synthetic_batch(8, 2, 64, 64)
+    img, tgt = img.to(DEV), tgt.to(DEV)
+    masks = [O.draw_dropout_masks(40 + s, 2) for s in range(3)]
+
+    def run(model, opt, steps):
+        out = None
+        for s in steps:
+            model.dropout_mask_override = masks[s]
+            out = ua.train_step(model, opt, ua.get_loss_function(), img, tgt)
+        return out
+
+    a = ua.create_model(DEV).train()
+    a.load_state_dict(O.fill_state_dict(6))
+    opt_a = ua.create_optimizer(a)
+    sched_a = ua.create_lr_scheduler(opt_a, 10)
+    run(a, opt_a, [0, 1])
+    path = ua.save_checkpoint(a, opt_a, sched_a, epoch=4, best_dice=0.5, output_dir=tmp_path,
+                              is_best=True)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict",
+                       "best_dice", "config"}
+    assert len(ck["model_state_dict"]) == 90
+    assert len(ck["optimizer_state_dict"]["state"]) == 90
+    assert (tmp_path / "best_model.pth").exists()
+    # a stock torch optimizer accepts the optimizer state (same layout)
+    ref_opt = torch.optim.SGD(ua.UNet().parameters(), lr=0.005, momentum=0.99, nesterov=True,
+                              weight_decay=1e-4)
+    ref_opt.load_state_dict(ck["optimizer_state_dict"])
+    loss_a = run(a, opt_a, [2])
+
+    b = ua.create_model(DEV).train()
+    opt_b = ua.create_optimizer(b)
+    sched_b = ua.create_lr_scheduler(opt_b, 10)
+    start, best = ua.load_checkpoint(path, b, opt_b, sched_b, device=DEV)
+    assert (start, best) == (5, 0.5)
+    loss_b = run(b, opt_b, [2])
+    assert loss_a.item() == loss_b.item()
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(p.detach(), q.detach()), k

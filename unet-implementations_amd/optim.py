@@ -45,6 +45,10 @@ class FusedSGD(torch.optim.Optimizer):
                 return False
         return True
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat_buf = None      # adopt the loaded momentum buffers on the next step
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -60,6 +60,42 @@ def train_step(model, optimizer, loss_function, images, masks, grad_sync=None):
     return loss.detach()
 
 
+def save_checkpoint(model, optimizer, scheduler, epoch, best_dice, output_dir, is_best=False):
+    """Same files and dictionary keys as Our_UNet/src/train.py:683-739 (the reference's embedded
+    `config` block describes an 8-stage net that is not the model it saves; here it records the
+    actual constructor geometry)."""
+    import os
+    ckpt_dir = os.path.join(str(output_dir), "checkpoints")
+    os.makedirs(ckpt_dir, exist_ok=True)
+    checkpoint = {
+        "epoch": epoch,
+        "model_state_dict": model.state_dict(),
+        "optimizer_state_dict": optimizer.state_dict(),
+        "scheduler_state_dict": scheduler.state_dict() if scheduler is not None else None,
+        "best_dice": best_dice,
+        "config": {"in_channels": model.in_channels, "num_classes": model.num_classes,
+                   "n_stages": model.n_stages, "features_per_stage": list(model.features_per_stage),
+                   "conv_bias": True, "norm_op_kwargs": {"eps": 1e-5, "affine": True},
+                   "nonlin_kwargs": {"inplace": True}},
+    }
+    path = os.path.join(ckpt_dir, f"checkpoint_epoch_{epoch}.pth")
+    torch.save(checkpoint, path)
+    if is_best:
+        torch.save(checkpoint, os.path.join(str(output_dir), "best_model.pth"))
+    return path
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None, device="cuda"):
+    """Resume as Our_UNet/src/train.py:888-902 does; returns (start_epoch, best_dice)."""
+    checkpoint = torch.load(path, map_location=device, weights_only=True)
+    model.load_state_dict(checkpoint["model_state_dict"])
+    if optimizer is not None and checkpoint.get("optimizer_state_dict") is not None:
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+    if scheduler is not None and checkpoint.get("scheduler_state_dict") is not None:
+        scheduler.load_state_dict(checkpoint["scheduler_state_dict"])
+    return checkpoint["epoch"] + 1, checkpoint["best_dice"]
+
+
 def train_one_epoch(model, train_loader, optimizer, loss_function, device, scaler=None):
     """Signature-compatible with the reference's train_one_epoch (src/train.py:592-680)."""
     if scaler is not None:

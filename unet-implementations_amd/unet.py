@@ -267,6 +267,28 @@ class UNet(nn.Module):
         self._plan = (enc, dec)
         return self._plan
 
+    def load_pretrained_encoder(self, pretrained, freeze=True):
+        """Counterpart of AE_pretrained/transfer_learning/models/unet.py:409-454: load
+        `encoder_stages.*` from a checkpoint (path, full checkpoint dict or state_dict) and
+        freeze the encoder.  Files are read with `torch.load(..., weights_only=True)`."""
+        ckpt = pretrained
+        if isinstance(pretrained, (str, bytes)) or hasattr(pretrained, "__fspath__"):
+            ckpt = torch.load(pretrained, map_location="cpu", weights_only=True)
+        if "model_state_dict" in ckpt:
+            ckpt = ckpt["model_state_dict"]
+        if "encoder_stages" in ckpt and isinstance(ckpt["encoder_stages"], dict):
+            enc_sd = ckpt["encoder_stages"]
+        else:
+            enc_sd = {k[len("encoder_stages."):]: v for k, v in ckpt.items()
+                      if k.startswith("encoder_stages.")}
+        own = self.encoder_stages.state_dict()
+        matched = {k: v for k, v in enc_sd.items() if k in own and own[k].shape == v.shape}
+        self.encoder_stages.load_state_dict(matched, strict=False)
+        if freeze:
+            for p in self.encoder_stages.parameters():
+                p.requires_grad = False
+        return sorted(set(own) - set(matched))     # keys that could not be loaded
+
     def check_supported(self):
         """Raise NotImplementedError unless this configuration is covered by the HIP path
         (3x3 / pad 1 / stride 1|2 convs with bias, InstanceNorm2d(affine), LeakyReLU,
@@ -428,7 +450,6 @@ class _UNetFunction(torch.autograd.Function):
         g = ops.head1x1_bwd(last["a"], dlogits, head.weight.detach().view(head.out_channels, -1),
                             gv(head.weight).view(head.out_channels, -1), gv(head.bias))
 
-        n_enc_layers = sum(len(b) for b in enc)
         idx = len(saved) - 1
         skip_grads = {}
         hook = model.grad_ready_hook
@@ -440,9 +461,25 @@ class _UNetFunction(torch.autograd.Function):
 
         ready(head)
 
-        def layer_bwd(rec, g_a, dx0_out=None, dx0_acc=False, need_dx=True):
+        def trainable(l):
+            return any(q.requires_grad for q in (l.conv.weight, l.conv.bias, l.norm.weight,
+                                                 l.norm.bias))
+
+        # Frozen layers (AE-transfer freezes encoder_stages): nothing upstream of
+        # the first trainable layer needs a backward pass, and frozen layers in between only
+        # propagate the data gradient (no weight-gradient kernels).
+        stop = min((i for i, r in enumerate(saved) if trainable(r["layer"])), default=len(saved))
+        skip_src = {}        # encoder stage e -> index in `saved` of the layer producing skip e
+        pos = 0
+        for bi, blk in enumerate(enc):
+            pos += len(blk)
+            skip_src[bi] = pos - 1
+
+        def layer_bwd(i, g_a, dx0_out=None, dx0_acc=False, need_dx=True, need_dx1=True):
+            rec = saved[i]
             l = rec["layer"]
             st = rec["st"]
+            need_dx = need_dx and i > stop       # the first trainable layer needs no dx
             dbg = getattr(model, "_debug_capture", None)
             if dbg is not None:
                 dbg.append((l.name, "ga", g_a.clone()))
@@ -453,59 +490,81 @@ class _UNetFunction(torch.autograd.Function):
                 dbg.append((l.name, "dy", dy.clone()))
             x0, x1 = rec["x0"], rec["x1"]
             dw = gv(l.conv.weight)
+            want_dw = l.conv.weight.requires_grad
             if l.ksize == 1:
-                dw2d = dw.view(dw.shape[0], dw.shape[1])
-                ops.conv1x1_bwd_weight(x0, dy, dw2d, 0)
-                if x1 is not None:
-                    ops.conv1x1_bwd_weight(x1, dy, dw2d, x0.shape[3])
+                if want_dw:
+                    dw2d = dw.view(dw.shape[0], dw.shape[1])
+                    ops.conv1x1_bwd_weight(x0, dy, dw2d, 0)
+                    if x1 is not None:
+                        ops.conv1x1_bwd_weight(x1, dy, dw2d, x0.shape[3])
                 dx0 = ops.conv1x1_bwd_data(dy, rec["wd"], 0, x0.shape[3]) if need_dx else None
                 return dx0, None      # the second source (frozen CLIP features) needs no gradient
-            ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride, bf16=ctx.bf16)
-            if x1 is not None:
-                ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride, bf16=ctx.bf16)
+            if want_dw:
+                ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride, bf16=ctx.bf16)
+                if x1 is not None:
+                    ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride, bf16=ctx.bf16)
             dx0 = dx1 = None
+            N, H, W, C0 = x0.shape
             if need_dx:
-                N, H, W, C0 = x0.shape
                 dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
                                            accumulate=dx0_acc, bf16=ctx.bf16)
-                if x1 is not None:
-                    dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride,
-                                               bf16=ctx.bf16)
+            if x1 is not None and need_dx1:
+                dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride,
+                                           bf16=ctx.bf16)
             return dx0, dx1
 
+        done = False
         # decoder stages, last to first
         for di in range(len(dec) - 1, -1, -1):
             blk = dec[di]
+            if done or idx < stop:
+                done = True
+                break
             for li in range(len(blk) - 1, 0, -1):
-                g, _ = layer_bwd(saved[idx], g)
+                if idx < stop:
+                    done = True
+                    break
+                g, _ = layer_bwd(idx, g)
                 idx -= 1
-            g_up, g_skip = layer_bwd(saved[idx], g)
+            if done or idx < stop:
+                done = True
+                break
+            e = len(enc) - 2 - di
+            g_up, g_skip = layer_bwd(idx, g, need_dx1=skip_src[e] >= stop)
             idx -= 1
-            skip_grads[len(enc) - 2 - di] = g_skip
-            g = ops.upsample2x_bwd(g_up)
+            if g_skip is not None:
+                skip_grads[e] = g_skip
+            if g_up is not None:
+                g = ops.upsample2x_bwd(g_up)
             ready(model.decoder_stages[di])
-        if ctx.fusion is not None:
-            g, _ = layer_bwd(saved[idx], g)
+        if ctx.fusion is not None and not done and idx >= stop:
+            g, _ = layer_bwd(idx, g)
             idx -= 1
             ready(model.clip_fusion_conv)
         # encoder stages, last to first
         for bi in range(len(enc) - 1, -1, -1):
             blk = enc[bi]
+            if done or idx < stop:
+                break
             for li in range(len(blk) - 1, -1, -1):
-                rec = saved[idx]
-                idx -= 1
+                if idx < stop:
+                    done = True
+                    break
                 first_layer_of_net = (bi == 0 and li == 0)
                 if first_layer_of_net:
-                    layer_bwd(rec, g, need_dx=False)
+                    layer_bwd(idx, g, need_dx=False)
                     g = None
                 elif li == 0 and (bi - 1) in skip_grads:
                     # input of this layer is the skip tensor of stage bi-1: accumulate into the
                     # gradient the decoder already wrote for it
-                    g, _ = layer_bwd(rec, g, dx0_out=skip_grads.pop(bi - 1), dx0_acc=True)
+                    g, _ = layer_bwd(idx, g, dx0_out=skip_grads.pop(bi - 1), dx0_acc=True)
                 else:
-                    g, _ = layer_bwd(rec, g)
-            ready(model.encoder_stages[bi])
-        assert idx == -1 and n_enc_layers > 0
+                    g, _ = layer_bwd(idx, g)
+                idx -= 1
+            if not done:
+                ready(model.encoder_stages[bi])
+        if hook is not None:
+            hook(0)       # frozen prefix: everything below is final (and zero-filled by us)
         ctx.saved = None
         grads = [gv(p) if p.requires_grad else None for p in params]
         return (None, None, None, *grads)
