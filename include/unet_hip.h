@@ -197,6 +197,22 @@ int unet_dice_wce_loss_fwd_bwd(const float* logits_nchw, const int64_t* target, 
                                int ignore_index, int dynamic_weights, const float* class_weights,
                                float grad_scale, unet_stream_t stream);
 
+/* ---- validation metrics and input pipeline ------------------------- */
+
+/* preds[N][H][W] (uint8, optional) = argmax over the class planes; counts[9] (uint64, device) =
+ * per class {intersection, predicted, labelled} over the batch, ignore_index pixels excluded:
+ * the integers behind the Dice scores of validate() (Our_UNet/src/train.py:556-577). */
+int unet_argmax_dice_counts(const float* logits_nchw, const int64_t* target, uint8_t* preds,
+                            uint64_t* counts, int N, int H, int W, int ignore_index,
+                            unet_stream_t stream);
+
+/* uint8 HWC image (+ uint8 mask) -> ((v/255) - mean)/std NHWC fp32 (+ int64 target with values
+ * > 2 other than 255 mapped to 0): PetSegmentationDataset.__getitem__, src/train.py:300-311.
+ * mean3 / std3 are HOST pointers to 3 floats. */
+int unet_preprocess_u8(const uint8_t* image_hwc, const uint8_t* mask, float* out_nhwc,
+                       int64_t* target, int N, int H, int W, const float* mean3, const float* std3,
+                       unet_stream_t stream);
+
 /* ---- SGD with Nesterov momentum over a flat arena -------------------------- */
 
 /* g' = g*grad_scale + wd*p; buf = first_step ? g' : mu*buf + g'; p -= lr*(g' + mu*buf).

@@ -248,3 +248,43 @@ def train_step(sd, bufs, images, target, masks=None, lr=0.005, momentum=0.99, we
 
 def leaf_state_dict(sd):
     return {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------- validation / input pipeline
+# PARITY UNPINNED for the three functions below: Our_UNet/src/train.py imports cv2, which is not
+# installed here, so the reference's validate() / dataset code could not be executed to record
+# fixtures.  They restate the arithmetic read from the source lines cited; the argmax/count part
+# is integer-exact against torch.argmax in tests/test_kernels_gpu.py.
+def batch_dice_scores(logits, masks, ignore_label=255):
+    """Per-class Dice of one validation batch, as Our_UNet/src/train.py:556-577 computes it:
+    argmax predictions, ignore pixels masked out, 2I/(|P|+|M|+1e-5), or 1.0 for an absent class."""
+    preds = torch.argmax(logits, dim=1)
+    valid = masks != ignore_label
+    out = []
+    for cls in range(3):
+        pred_cls = ((preds == cls) & valid).float()
+        mask_cls = ((masks == cls) & valid).float()
+        inter = (pred_cls * mask_cls).sum().item()
+        union = (pred_cls.sum() + mask_cls.sum()).item()
+        out.append(2.0 * inter / (union + 1e-5) if union > 0 else 1.0)
+    return out
+
+
+def validate_scores(logit_batches, mask_batches, ignore_label=255):
+    """Batch-averaged scores dictionary of validate() (src/train.py:579-589)."""
+    per = [batch_dice_scores(l, m, ignore_label) for l, m in zip(logit_batches, mask_batches)]
+    n = max(len(per), 1)
+    d = [sum(p[c] for p in per) / n for c in range(3)]
+    return {"background": d[0], "cat": d[1], "dog": d[2], "mean_foreground": (d[1] + d[2]) / 2.0}
+
+
+def preprocess_sample(image_hwc_u8, mask_u8):
+    """PetSegmentationDataset.__getitem__ arithmetic (Our_UNet/src/train.py:300-311) on numpy
+    uint8 arrays: returns (CHW float32 image, int64 mask)."""
+    import numpy as np
+    mask = np.where((mask_u8 > 2) & (mask_u8 != 255), 0, mask_u8)
+    image = torch.from_numpy(image_hwc_u8).float().permute(2, 0, 1) / 255.0
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    image = (image - mean) / std
+    return image, torch.from_numpy(mask).long()

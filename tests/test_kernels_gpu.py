@@ -514,3 +514,83 @@ def test_upblock_golden(ua, golden):
             assert (v.cpu() - ref).abs().max() < 1e-4
         else:
             check(v.cpu(), ref, 5e-5, f"UpBlock grad {k}")
+
+
+# ---------------------------------------------------------------- validation metrics / input
+@pytest.mark.parametrize("n,h,w", [(1, 64, 64), (3, 96, 160), (8, 512, 512)])
+def test_argmax_dice_counts_exact(ua, n, h, w):
+    g = torch.Generator().manual_seed(n * h + w)
+    logits = torch.randn(n, 3, h, w, generator=g)
+    logits[:, :, : h // 4] = logits[:, :1, : h // 4]          # three-way ties -> class 0
+    logits[:, 2, h // 4: h // 2] = logits[:, 1, h // 4: h // 2]  # 1/2 ties -> class 1 when largest
+    target = torch.randint(0, 3, (n, h, w), generator=g)
+    target[torch.rand(n, h, w, generator=g) < 0.1] = 255
+    preds, counts = ua.ops.argmax_dice_counts(logits.cuda(), target.cuda())
+    ref_p = logits.argmax(dim=1)
+    assert torch.equal(preds.cpu().long(), ref_p)
+    valid = target != 255
+    for c in range(3):
+        pc, mc = (ref_p == c) & valid, (target == c) & valid
+        assert counts[c].tolist() == [int((pc & mc).sum()), int(pc.sum()), int(mc.sum())]
+
+
+def test_argmax_dice_counts_absent_class_and_all_ignored(ua):
+    logits = torch.zeros(2, 3, 64, 64)
+    logits[:, 1] = 1.0
+    target = torch.full((2, 64, 64), 255, dtype=torch.int64)
+    _, counts = ua.ops.argmax_dice_counts(logits.cuda(), target.cuda(), want_preds=False)
+    assert counts.sum().item() == 0
+    target[0] = 1
+    _, counts = ua.ops.argmax_dice_counts(logits.cuda(), target.cuda(), want_preds=False)
+    assert counts.tolist() == [[0, 0, 0], [4096, 4096, 4096], [0, 0, 0]]
+
+
+def test_validate_matches_reference_arithmetic(ua):
+    from oracle import unet_ref as O
+    model = ua.create_model()
+    model.load_state_dict(O.fill_state_dict(3, trained_like=True))
+    loss_fn = ua.get_loss_function()
+    batches = []
+    for s in range(3):
+        img, tgt = O.synthetic_batch(20 + s, 2, 64, 64)
+        if s == 1:
+            tgt[tgt == 2] = 0          # a batch without dogs: the 1.0 branch
+        batches.append({"image": img, "mask": tgt})
+    val_loss, scores = ua.validate(model, batches, loss_fn, "cuda")
+    model.eval()
+    with torch.no_grad():
+        outs = [model(b["image"].cuda()).cpu() for b in batches]
+        ref_loss = sum(O.simple_loss(o, b["mask"]).item() for o, b in zip(outs, batches)) / 3
+    ref = O.validate_scores(outs, [b["mask"] for b in batches])
+    assert abs(val_loss - ref_loss) <= 1e-5 * abs(ref_loss)
+    for k in ref:
+        assert abs(scores[k] - ref[k]) <= 1e-9, k        # integer counts -> same quotient
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 64, 64), (2, 75, 131), (8, 512, 512)])
+def test_preprocess_u8_bit_exact(ua, n, h, w):
+    from oracle import unet_ref as O
+    rng = np.random.default_rng(h)
+    img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    img[0, 0, :256 if w >= 256 else w, 0] = np.arange(min(w, 256), dtype=np.uint8)
+    mask = rng.choice(np.array([0, 1, 2, 3, 7, 254, 255], dtype=np.uint8), (n, h, w))
+    out, tgt = ua.ops.preprocess_u8(torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda())
+    for i in range(n):
+        ri, rm = O.preprocess_sample(img[i], mask[i])
+        assert torch.equal(out[i].permute(2, 0, 1).cpu(), ri)
+        assert torch.equal(tgt[i].cpu(), rm)
+    out2, none = ua.ops.preprocess_u8(torch.from_numpy(img).cuda())
+    assert none is None and torch.equal(out2, out)
+
+
+def test_forward_accepts_preprocessed_nhwc(ua):
+    from oracle import unet_ref as O
+    model = ua.create_model().eval()
+    model.load_state_dict(O.fill_state_dict(5, trained_like=True))
+    rng = np.random.default_rng(0)
+    img = torch.from_numpy(rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)).cuda()
+    x_nhwc, _ = ua.ops.preprocess_u8(img)
+    with torch.no_grad():
+        a = model(x_nhwc, input_layout="nhwc")
+        b = model(x_nhwc.permute(0, 3, 1, 2).contiguous())
+    assert torch.equal(a, b)

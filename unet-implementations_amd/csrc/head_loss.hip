@@ -312,6 +312,57 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ validation metrics
+// argmax over the 3 class planes (lowest index wins ties, like torch.argmax) and, per class,
+// the exact integer counts the reference's validate() turns into Dice scores
+// (Our_UNet/src/train.py:556-577): counts[c] = {intersection, predicted, labelled}, pixels
+// labelled ignore_index excluded.
+__global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restrict__ logits,
+                                                            const long long* __restrict__ target,
+                                                            unsigned char* __restrict__ preds,
+                                                            unsigned long long* __restrict__ counts,
+                                                            int HW, int ignore_index) {
+  __shared__ unsigned int red[4][9];
+  const int n = blockIdx.y;
+  const float* z = logits + (size_t)n * 3 * HW;
+  const long long* tg = target + (size_t)n * HW;
+  unsigned int q[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q[i] = 0;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const float z0 = z[p], z1 = z[HW + p], z2 = z[2 * HW + p];
+    int am = 0;
+    float best = z0;
+    if (z1 > best) { best = z1; am = 1; }
+    if (z2 > best) { best = z2; am = 2; }
+    if (preds) preds[(size_t)n * HW + p] = (unsigned char)am;
+    const long long t = tg[p];
+    if (t != (long long)ignore_index) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const unsigned int pc = (am == c), mc = (t == c);
+        q[c * 3 + 0] += pc & mc;
+        q[c * 3 + 1] += pc;
+        q[c * 3 + 2] += mc;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    unsigned int v = q[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const unsigned int s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                           red[3][threadIdx.x];
+    if (s) atomicAdd(&counts[threadIdx.x], (unsigned long long)s);   // integer: order-independent
+  }
+}
+
 struct LossWs {
   float* partial; LossCoef* coef; float* dice_ab;
 };
@@ -413,5 +464,22 @@ extern "C" int unet_dice_wce_loss_fwd_bwd(const float* logits, const int64_t* ta
                        ignore_index);
     UNET_CHECK_LAUNCH("loss_grad");
   }
+  return UNET_OK;
+}
+
+extern "C" int unet_argmax_dice_counts(const float* logits_nchw, const int64_t* target,
+                                       uint8_t* preds, uint64_t* counts, int N, int H, int W,
+                                       int ignore_index, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(logits_nchw && target && counts, "argmax_dice_counts: null pointer");
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0, "argmax_dice_counts: bad shape");
+  const int HW = H * W;
+  UNET_HIP_CALL(hipMemsetAsync(counts, 0, 9 * sizeof(uint64_t), stream));
+  int blocks = ceil_div(HW, 256 * 4);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(argmax_counts_kernel, dim3(blocks, N), dim3(256), 0, stream, logits_nchw,
+                     reinterpret_cast<const long long*>(target), preds,
+                     reinterpret_cast<unsigned long long*>(counts), HW, ignore_index);
+  UNET_CHECK_LAUNCH("argmax_counts");
   return UNET_OK;
 }

@@ -50,6 +50,29 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// ---- input pipeline: uint8 HWC image + uint8 mask -> normalised NHWC fp32 + int64 target ---
+// image: ((v / 255) - mean[c]) / std[c] in the reference's operation order
+// (Our_UNet/src/train.py:303-308); mask: values > 2 other than 255 become 0 (:300).
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ img,
+                                                            const unsigned char* __restrict__ mask,
+                                                            float* __restrict__ out,
+                                                            long long* __restrict__ target,
+                                                            long long pixels, float m0, float m1,
+                                                            float m2, float s0, float s1, float s2) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += stride) {
+    const unsigned char* s = img + p * 3;
+    float* o = out + p * 3;
+    o[0] = ((float)s[0] / 255.0f - m0) / s0;
+    o[1] = ((float)s[1] / 255.0f - m1) / s1;
+    o[2] = ((float)s[2] / 255.0f - m2) / s2;
+    if (mask) {
+      const unsigned char v = mask[p];
+      target[p] = (v > 2 && v != 255) ? 0 : (long long)v;
+    }
+  }
+}
+
 // ---- 2-D transpose (1x1 weights for the data gradient) ------------------------------------
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src,
                                                           float* __restrict__ dst, int R, int C) {
@@ -301,5 +324,20 @@ extern "C" int unet_transpose2d(const float* src, float* dst, int R, int C, unet
   hipLaunchKernelGGL(transpose2d_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, R, C);
   UNET_CHECK_LAUNCH("transpose2d");
+  return UNET_OK;
+}
+
+extern "C" int unet_preprocess_u8(const uint8_t* image_hwc, const uint8_t* mask, float* out_nhwc,
+                                  int64_t* target, int N, int H, int W, const float* mean3,
+                                  const float* std3, unet_stream_t stream) {
+  UNET_REQUIRE(image_hwc && out_nhwc && mean3 && std3 && N > 0 && H > 0 && W > 0 &&
+                   (mask == nullptr || target != nullptr),
+               "preprocess_u8: bad argument");
+  const long long pixels = (long long)N * H * W;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(stream_grid(pixels)), dim3(256), 0,
+                     (hipStream_t)stream, image_hwc, mask, out_nhwc,
+                     reinterpret_cast<long long*>(target), pixels, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2]);
+  UNET_CHECK_LAUNCH("preprocess_u8");
   return UNET_OK;
 }

@@ -283,6 +283,46 @@ def dice_wce_loss_fwd_bwd(logits, target, smooth, w_dice, w_ce, ignore_index, dy
     return out, dl
 
 
+# ---- validation metrics / input pipeline ---------------------------------------------------
+def argmax_dice_counts(logits, target, ignore_index=255, want_preds=True):
+    """Returns (preds uint8 [N,H,W] or None, counts int64 [3,3] = per class
+    {intersection, predicted, labelled}); everything stays on the device."""
+    N, K, H, W = logits.shape
+    if K != 3:
+        raise ValueError("3 classes expected")
+    logits, target = logits.contiguous(), target.contiguous()
+    if logits.dtype != torch.float32 or target.dtype != torch.int64:
+        raise TypeError("argmax_dice_counts takes fp32 logits and int64 targets")
+    preds = torch.empty((N, H, W), dtype=torch.uint8, device=logits.device) if want_preds else None
+    counts = torch.empty((3, 3), dtype=torch.int64, device=logits.device)
+    check(lib().unet_argmax_dice_counts(_ptr(logits), _ptr(target), _ptr(preds), counts.data_ptr(),
+                                        N, H, W, ignore_index, _stream()))
+    return preds, counts
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def preprocess_u8(image_hwc_u8, mask_u8=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 [N,H,W,3] (+ uint8 [N,H,W]) on the device -> (fp32 NHWC image, int64 target)."""
+    import ctypes
+    N, H, W, C = image_hwc_u8.shape
+    if C != 3 or image_hwc_u8.dtype != torch.uint8 or not image_hwc_u8.is_contiguous():
+        raise TypeError("preprocess_u8 takes a contiguous uint8 [N,H,W,3] tensor")
+    out = _f32((N, H, W, 3), image_hwc_u8)
+    tgt = None
+    if mask_u8 is not None:
+        if mask_u8.dtype != torch.uint8 or tuple(mask_u8.shape) != (N, H, W) or \
+                not mask_u8.is_contiguous():
+            raise TypeError("mask must be a contiguous uint8 [N,H,W] tensor")
+        tgt = torch.empty((N, H, W), dtype=torch.int64, device=image_hwc_u8.device)
+    m3 = (ctypes.c_float * 3)(*mean)
+    s3 = (ctypes.c_float * 3)(*std)
+    check(lib().unet_preprocess_u8(_ptr(image_hwc_u8), _ptr(mask_u8), _ptr(out), _ptr(tgt), N, H,
+                                   W, m3, s3, _stream()))
+    return out, tgt
+
+
 # ---- optimizer -------------------------------------------------------------------------
 def sgd_nesterov_step(params, grads, momentum, lr, mu, weight_decay, first_step, grad_scale=1.0):
     n = params.numel()

@@ -9,6 +9,7 @@
 """
 import torch
 
+from . import ops
 from .losses import SimpleLoss
 from .optim import FusedSGD
 from .unet import UNet
@@ -58,6 +59,32 @@ def train_step(model, optimizer, loss_function, images, masks, grad_sync=None):
         grad_sync()
     optimizer.step()
     return loss.detach()
+
+
+@torch.no_grad()
+def validate(model, val_loader, loss_function, device, ignore_label=255):
+    """Counterpart of validate() (Our_UNet/src/train.py:510-589): eval-mode forward, loss, and
+    per-batch Dice of the argmax predictions for background / cat / dog, averaged over batches.
+    argmax and the nine integer counts come from one kernel and the per-batch Dice arithmetic
+    stays on the device, so the loop has no host sync (the reference syncs 4 times per batch)."""
+    model.eval()
+    val_loss = torch.zeros((), device=device)
+    dice_sum = torch.zeros(3, device=device, dtype=torch.float64)
+    n = 0
+    for batch in val_loader:
+        images = batch["image"].to(device, non_blocking=True)
+        masks = batch["mask"].to(device, non_blocking=True)
+        outputs = model(images)
+        val_loss += loss_function(outputs, masks).detach()
+        _, counts = ops.argmax_dice_counts(outputs, masks, ignore_label, want_preds=False)
+        inter = counts[:, 0].double()
+        union = (counts[:, 1] + counts[:, 2]).double()
+        dice_sum += torch.where(union > 0, 2.0 * inter / (union + 1e-5), torch.ones_like(inter))
+        n += 1
+    n = max(n, 1)
+    d = (dice_sum / n).tolist()
+    scores = {"background": d[0], "cat": d[1], "dog": d[2], "mean_foreground": (d[1] + d[2]) / 2.0}
+    return (val_loss / n).item(), scores
 
 
 def save_checkpoint(model, optimizer, scheduler, epoch, best_dice, output_dir, is_best=False):

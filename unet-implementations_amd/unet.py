@@ -335,7 +335,12 @@ class UNet(nn.Module):
         return self._grad_arena[off:off + p.numel()].view(p.shape)
 
     # -- forward ----------------------------------------------------------------------------------
-    def forward(self, x, extra=None):
+    def forward(self, x, extra=None, input_layout="nchw"):
+        """`input_layout="nhwc"` takes the [N,H,W,3] tensor of `ops.preprocess_u8` directly."""
+        if input_layout == "nhwc":
+            x = x.permute(0, 3, 1, 2)      # a view: the shape checks below see NCHW sizes
+        elif input_layout != "nchw":
+            raise ValueError("input_layout must be 'nchw' or 'nhwc'")
         if not x.is_cuda:
             raise RuntimeError("unet-implementations_amd.UNet runs on MI355X only: move the model "
                                "and the input to a ROCm device (no CPU fallback exists)")
@@ -350,8 +355,11 @@ class UNet(nn.Module):
         self._ensure_arena()
         params = list(self.parameters())
         self._param_index = {id(p): i for i, p in enumerate(params)}
-        x = x.contiguous().float()
-        return _UNetFunction.apply(self, x, self._bottleneck_input(x, extra), *params)
+        if input_layout == "nhwc":
+            x_nhwc = x.permute(0, 2, 3, 1).contiguous().float()     # already NHWC in memory
+        else:
+            x_nhwc = ops.nchw_to_nhwc(x.contiguous().float())
+        return _UNetFunction.apply(self, x_nhwc, self._bottleneck_input(x, extra), *params)
 
     def _bottleneck_input(self, x, extra):
         """Second source of the bottleneck fusion layer (NHWC) or None; CLIPUNet overrides."""
@@ -408,7 +416,7 @@ class _UNetFunction(torch.autograd.Function):
                 saved.append(dict(layer=l, x0=x0, x1=x1, y=y, st=st, mask=m, a=a, wd=wd))
             return a
 
-        cur = ops.nchw_to_nhwc(x)
+        cur = x          # NHWC image
         skips = []
         for bi, blk in enumerate(enc):
             for l in blk:
