@@ -74,6 +74,9 @@ def main():
                     help="bf16 = BASELINE config 4 (bf16 MFMA operands, fp32 accumulate/storage)")
     ap.add_argument("--clip", action="store_true",
                     help="BASELINE config 5: CLIP_UNet variant with synthetic CLIP features")
+    ap.add_argument("--loss-sync", choices=["local", "global"], default="local",
+                    help="N>1: per-shard loss + averaged gradients (default) or the loss of the "
+                         "concatenated batch + summed gradients")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -110,10 +113,11 @@ def main():
     model.matmul_precision = args.matmul
     opt = ua.create_optimizer(model)
     lossf = ua.get_loss_function()
+    lossf.batch_sync = args.loss_sync
     sync = None
     if world > 1:
         ddp.broadcast_parameters(model)
-        sync = ddp.GradBucketAllReduce(model, opt)
+        sync = ddp.GradBucketAllReduce(model, opt, average=args.loss_sync != "global")
     img, tgt = O.synthetic_batch(1234 + rank, args.batch, args.hw, args.hw)
     img, tgt = img.to(dev), tgt.to(dev)
     torch.manual_seed(99 + rank)     # dropout stream differs per rank

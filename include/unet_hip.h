@@ -197,6 +197,25 @@ int unet_dice_wce_loss_fwd_bwd(const float* logits_nchw, const int64_t* target, 
                                int ignore_index, int dynamic_weights, const float* class_weights,
                                float grad_scale, unet_stream_t stream);
 
+/* The same loss over a batch SHARDED across processes (data parallel, SURVEY.md 8e
+ * "global-exact"): the value and gradient of SimpleLoss on the concatenated batch.
+ * shard_stats leaves per-image sums in `workspace` and writes stats[10] (device, double) =
+ * {class counts[3], per-class NLL sums[3], valid pixels, sum over images of Dice[3]}; the host
+ * sums stats over the shards (one 80-byte all-reduce) and passes the result, with the global
+ * image count, to shard_apply together with the SAME workspace.  loss_out is identical on every
+ * shard; dlogits already carry the global normalisation, so parameter gradients are SUMMED
+ * (not averaged) across shards. */
+int unet_dice_wce_loss_shard_stats(const float* logits_nchw, const int64_t* target, double* stats,
+                                   void* workspace, size_t workspace_bytes, int N, int H, int W,
+                                   float smooth, int ignore_index, unet_stream_t stream);
+int unet_dice_wce_loss_shard_apply(const float* logits_nchw, const int64_t* target,
+                                   const double* global_stats, int N_global, float* loss_out,
+                                   float* dlogits, void* workspace, size_t workspace_bytes, int N,
+                                   int H, int W, float smooth, float w_dice, float w_ce,
+                                   int ignore_index, int dynamic_weights,
+                                   const float* class_weights, float grad_scale,
+                                   unet_stream_t stream);
+
 /* ---- validation metrics and input pipeline ------------------------- */
 
 /* preds[N][H][W] (uint8, optional) = argmax over the class planes; counts[9] (uint64, device) =

@@ -87,3 +87,55 @@ def test_two_rank_step_matches_shard_sum():
     expect = sd0[k] - 0.005 * (1 + 0.99) * g
     got = out["param0"][off:off + n].view_as(sd0[k])
     assert ((got - expect).abs().max() / expect.abs().max()).item() <= 1e-6
+
+
+def _worker_global(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_implementations_amd import ddp
+    ua, model, img, tgt = _setup(rank)
+    opt = ua.create_optimizer(model)
+    sync = ddp.GradBucketAllReduce(model, opt, bucket_bytes=8 << 20, average=False)
+    ddp.broadcast_parameters(model)
+    loss_fn = ua.SimpleLoss(batch_sync="global")
+    loss = ua.train_step(model, opt, loss_fn, img, tgt, grad_sync=sync.finish)
+    torch.cuda.synchronize()
+    arena, garena = model.flat_parameters()
+    out[f"grad{rank}"] = garena.cpu()
+    out[f"param{rank}"] = arena.cpu()
+    out[f"loss{rank}"] = loss.item()
+    dist.destroy_process_group()
+
+
+def test_two_rank_global_exact_equals_one_process_on_concatenated_batch():
+    """batch_sync="global": 2 ranks x batch 2 == 1 process x batch 4 (loss, gradient, step)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_global, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out["loss0"] == out["loss1"]
+    assert torch.equal(out["param0"], out["param1"])
+    import unet_implementations_amd as ua
+    from oracle import unet_ref as O
+    parts = [_setup(r) for r in range(world)]
+    model = parts[0][1]
+    img = torch.cat([p[2] for p in parts])
+    tgt = torch.cat([p[3] for p in parts])
+    m0, m1 = parts[0][1].dropout_mask_override, parts[1][1].dropout_mask_override
+    model.dropout_mask_override = [torch.cat([a, b]) for a, b in zip(m0, m1)]
+    opt = ua.create_optimizer(model)
+    loss = ua.train_step(model, opt, ua.get_loss_function(), img, tgt)
+    arena, garena = model.flat_parameters()
+    assert abs(loss.item() - out["loss0"]) <= 2e-6 * abs(loss.item())
+    g, ref = out["grad0"], garena.cpu()
+    assert ((g - ref).norm() / ref.norm()).item() <= 1e-5
+    p, pref = out["param0"], arena.cpu()
+    assert ((p - pref).abs().max() / pref.abs().max()).item() <= 1e-6
+    # and the loss is the reference's loss of the 4-image batch
+    sd0 = O.fill_state_dict(31)
+    masks = [torch.cat([a, b]) for a, b in zip(m0, m1)]
+    with torch.no_grad():
+        logits = O.unet_forward(sd0, img.cpu(), masks)
+        ref_loss = O.simple_loss(logits, tgt.cpu()).item()
+    assert abs(out["loss0"] - ref_loss) <= 2e-5 * abs(ref_loss)

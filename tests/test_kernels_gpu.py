@@ -594,3 +594,33 @@ def test_forward_accepts_preprocessed_nhwc(ua):
         a = model(x_nhwc, input_layout="nhwc")
         b = model(x_nhwc.permute(0, 3, 1, 2).contiguous())
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_sharded_loss_equals_loss_of_concatenated_batch(ua, dynamic):
+    """shard_stats -> sum -> shard_apply on 3 shards == SimpleLoss of the whole batch."""
+    g = torch.Generator().manual_seed(11)
+    shards = []
+    for s, n in enumerate([2, 2, 2]):
+        lg = torch.randn(n, 3, 64, 96, generator=g) * 2
+        tg = torch.randint(0, 3, (n, 64, 96), generator=g)
+        tg[torch.rand(n, 64, 96, generator=g) < 0.15] = 255
+        if s == 1:
+            tg[tg == 2] = 0                     # a shard with no class-2 pixel
+        shards.append((lg, tg))
+    cw = None if dynamic else torch.tensor([0.5, 1.25, 1.25])
+    all_lg = torch.cat([s[0] for s in shards]).requires_grad_(True)
+    all_tg = torch.cat([s[1] for s in shards])
+    ref = O.simple_loss(all_lg, all_tg, dynamic_weights=dynamic, fixed_weights=cw)
+    ref.backward()
+    dev = [(lg.cuda(), tg.cuda()) for lg, tg in shards]
+    phase1 = [ua.ops.dice_wce_loss_shard_stats(lg, tg, 1e-5, 255) for lg, tg in dev]
+    gstats = sum(p[0] for p in phase1)
+    n0 = 0
+    for (lg, tg), (_, ws) in zip(dev, phase1):
+        out, dl = ua.ops.dice_wce_loss_shard_apply(lg, tg, gstats, 6, ws, 1e-5, 1.0, 1.0, 255,
+                                                   dynamic, class_weights=None if cw is None else cw.cuda())
+        assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item())
+        rg = all_lg.grad[n0:n0 + lg.shape[0]]
+        assert ((dl.cpu() - rg).abs().max() / rg.abs().max()).item() <= 2e-5
+        n0 += lg.shape[0]

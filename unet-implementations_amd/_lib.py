@@ -53,6 +53,9 @@ SIGNATURES = {
     "unet_dice_wce_loss_workspace_bytes": (_sz, [_i, _i, _i]),
     "unet_dice_wce_loss_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _f, _f, _f, _i, _i,
                                         _p, _f, _p]),
+    "unet_dice_wce_loss_shard_stats": (_i, [_p, _p, _p, _p, _sz, _i, _i, _i, _f, _i, _p]),
+    "unet_dice_wce_loss_shard_apply": (_i, [_p, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _i, _f, _f, _f,
+                                            _i, _i, _p, _f, _p]),
     "unet_argmax_dice_counts": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _p]),
     "unet_sgd_nesterov_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),

@@ -269,6 +269,86 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(
   coef->wdice = w_dice * grad_scale;
 }
 
+// ---- sharded batch (data parallel, "global-exact"): the loss of the concatenated batch ------
+// Phase 1 leaves this shard's per-image sums in the workspace and its contribution to the
+// batch-wide statistics in stats[10] = {cnt[3], nll[3], valid, sum_n dice_n[3]}; the host sums
+// stats over the shards (an all-reduce of 80 bytes); phase 2 turns the global statistics into
+// the loss value (identical on every shard) and this shard's gradient coefficients.
+constexpr int LSTATS = 10;
+
+__global__ __launch_bounds__(256) void loss_shard_stats_kernel(const float* __restrict__ partial,
+                                                               int N, int nblocks, float smooth,
+                                                               double* __restrict__ sums,
+                                                               double* __restrict__ stats) {
+  for (int i = threadIdx.x; i < N * LQ; i += blockDim.x) {
+    const int n = i / LQ, k = i - n * LQ;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[((size_t)n * nblocks + b) * LQ + k];
+    sums[i] = s;
+  }
+  __syncthreads();   // global writes of this block are visible to it after the barrier
+  if (threadIdx.x >= LSTATS) return;
+  const int k = threadIdx.x;
+  double s = 0.0;
+  if (k < 7) {
+    const int col = k < 6 ? k : 12;
+    for (int n = 0; n < N; ++n) s += sums[n * LQ + col];
+  } else {
+    const int c = k - 7;
+    for (int n = 0; n < N; ++n) {
+      const double I = sums[n * LQ + 6 + c], U = sums[n * LQ + 9 + c] + sums[n * LQ + c];
+      s += (2.0 * I + smooth) / (U + smooth);
+    }
+  }
+  stats[k] = s;
+}
+
+__global__ void loss_shard_apply_kernel(const double* __restrict__ sums, int N,
+                                        const double* __restrict__ g, int n_global, float smooth,
+                                        float w_dice, float w_ce, int dynamic_weights,
+                                        const float* __restrict__ class_weights, float grad_scale,
+                                        float* __restrict__ loss_out, LossCoef* __restrict__ coef,
+                                        float* __restrict__ dice_ab) {
+  const double k = 1.0 / (3.0 * n_global);
+  for (int i = threadIdx.x; i < N * 3; i += blockDim.x) {
+    const int n = i / 3, c = i - n * 3;
+    const double I = sums[n * LQ + 6 + c], U = sums[n * LQ + 9 + c] + sums[n * LQ + c];
+    dice_ab[i * 2 + 0] = (float)(-2.0 * k / (U + smooth));
+    dice_ab[i * 2 + 1] = (float)((2.0 * I + smooth) * k / ((U + smooth) * (U + smooth)));
+  }
+  if (threadIdx.x != 0) return;
+  const double total = g[6];
+  float w[3];
+  if (dynamic_weights) {
+    float cw[3], ws = 0.f;
+    for (int c = 0; c < 3; ++c) {
+      const float cp = g[c] == 0 ? 1.f : (float)g[c];
+      cw[c] = (float)total / cp;
+      ws += cw[c];
+    }
+    for (int c = 0; c < 3; ++c) w[c] = cw[c] * (3.f / ws);
+  } else {
+    for (int c = 0; c < 3; ++c) w[c] = class_weights ? class_weights[c] : 1.f;
+  }
+  double num = 0, den = 0, dice_sum = 0;
+  for (int c = 0; c < 3; ++c) {
+    num += (double)w[c] * g[3 + c];
+    den += (double)w[c] * g[c];
+    dice_sum += 1.0 - g[7 + c] / n_global;
+  }
+  const float ce = (float)(num / den);
+  const float dice = (float)(dice_sum / 3.0);
+  loss_out[0] = w_ce * ce + w_dice * dice;
+  loss_out[1] = ce;
+  loss_out[2] = dice;
+  for (int c = 0; c < 3; ++c) {
+    loss_out[3 + c] = w[c];
+    coef->w[c] = w[c];
+  }
+  coef->inv_wsum = (float)((double)w_ce * grad_scale / den);
+  coef->wdice = w_dice * grad_scale;
+}
+
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ logits,
                                                         const long long* __restrict__ target,
                                                         const LossCoef* __restrict__ coef,
@@ -364,7 +444,7 @@ __global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restr
 }
 
 struct LossWs {
-  float* partial; LossCoef* coef; float* dice_ab;
+  float* partial; LossCoef* coef; float* dice_ab; double* sums;
 };
 size_t loss_ws_layout(int N, LossWs* out, char* base) {
   size_t off = 0;
@@ -375,8 +455,9 @@ size_t loss_ws_layout(int N, LossWs* out, char* base) {
     out->partial = reinterpret_cast<float*>(base + off);
     out->coef = reinterpret_cast<LossCoef*>(base + off + partial_b);
     out->dice_ab = reinterpret_cast<float*>(base + off + partial_b + coef_b);
+    out->sums = reinterpret_cast<double*>(base + off + partial_b + coef_b + ab_b);
   }
-  off = partial_b + coef_b + ab_b;
+  off = partial_b + coef_b + ab_b + align_up((size_t)N * LQ * sizeof(double), 256);
   return off;
 }
 
@@ -481,5 +562,72 @@ extern "C" int unet_argmax_dice_counts(const float* logits_nchw, const int64_t* 
                      reinterpret_cast<const long long*>(target), preds,
                      reinterpret_cast<unsigned long long*>(counts), HW, ignore_index);
   UNET_CHECK_LAUNCH("argmax_counts");
+  return UNET_OK;
+}
+
+namespace {
+int loss_blocks_for(int HW) {
+  int blocks = ceil_div(HW, 256 * 8);
+  if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
+  return blocks < 1 ? 1 : blocks;
+}
+}  // namespace
+
+extern "C" int unet_dice_wce_loss_shard_stats(const float* logits, const int64_t* target,
+                                              double* stats, void* workspace,
+                                              size_t workspace_bytes, int N, int H, int W,
+                                              float smooth, int ignore_index,
+                                              unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(logits && target && stats && workspace, "loss_shard_stats: null pointer");
+  UNET_REQUIRE(N > 0 && N <= 1024 && H > 0 && W > 0, "loss_shard_stats: bad shape");
+  if (workspace_bytes < loss_ws_layout(N, nullptr, nullptr)) {
+    unet_set_error("loss_shard_stats: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  LossWs ws;
+  loss_ws_layout(N, &ws, reinterpret_cast<char*>(workspace));
+  const int HW = H * W, blocks = loss_blocks_for(HW);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(blocks, N), dim3(256), 0, stream, logits,
+                     reinterpret_cast<const long long*>(target), ws.partial, HW, ignore_index);
+  UNET_CHECK_LAUNCH("loss_reduce");
+  hipLaunchKernelGGL(loss_shard_stats_kernel, dim3(1), dim3(256), 0, stream, ws.partial, N, blocks,
+                     smooth, ws.sums, stats);
+  UNET_CHECK_LAUNCH("loss_shard_stats");
+  return UNET_OK;
+}
+
+extern "C" int unet_dice_wce_loss_shard_apply(const float* logits, const int64_t* target,
+                                              const double* global_stats, int N_global,
+                                              float* loss_out, float* dlogits, void* workspace,
+                                              size_t workspace_bytes, int N, int H, int W,
+                                              float smooth, float w_dice, float w_ce,
+                                              int ignore_index, int dynamic_weights,
+                                              const float* class_weights, float grad_scale,
+                                              unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(logits && target && global_stats && loss_out && workspace,
+               "loss_shard_apply: null pointer");
+  UNET_REQUIRE(N > 0 && N <= 1024 && N_global >= N && H > 0 && W > 0,
+               "loss_shard_apply: bad shape");
+  if (workspace_bytes < loss_ws_layout(N, nullptr, nullptr)) {
+    unet_set_error("loss_shard_apply: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  LossWs ws;
+  loss_ws_layout(N, &ws, reinterpret_cast<char*>(workspace));
+  const int HW = H * W;
+  hipLaunchKernelGGL(loss_shard_apply_kernel, dim3(1), dim3(256), 0, stream, ws.sums, N,
+                     global_stats, N_global, smooth, w_dice, w_ce, dynamic_weights, class_weights,
+                     grad_scale, loss_out, ws.coef, ws.dice_ab);
+  UNET_CHECK_LAUNCH("loss_shard_apply");
+  if (dlogits) {
+    int gblocks = ceil_div(HW, 256 * 4);
+    if (gblocks < 1) gblocks = 1;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(gblocks, N), dim3(256), 0, stream, logits,
+                       reinterpret_cast<const long long*>(target), ws.coef, ws.dice_ab, dlogits, HW,
+                       ignore_index);
+    UNET_CHECK_LAUNCH("loss_grad");
+  }
   return UNET_OK;
 }

@@ -12,7 +12,11 @@ The 1/world averaging is folded into the SGD kernel (`FusedSGD.grad_scale`).
 Loss semantics (`mode`):
   "ddp"          each rank normalises its CE / class weights over its own shard, gradients
                  are averaged (standard DDP; oracle = reference per shard, mean of grads).
-  "global-exact" not needed for throughput; see DESIGN.md.
+  "global-exact" `SimpleLoss(batch_sync="global")` + `GradBucketAllReduce(average=False)`:
+                 class weights, CE denominator and the Dice batch mean are taken over the
+                 concatenated batch (one extra 80-byte all-reduce inside the loss), gradients
+                 are summed; N ranks x batch b then reproduce one process at batch N*b
+                 (oracle = reference on the concatenated batch).
 """
 import torch
 import torch.distributed as dist
@@ -21,7 +25,8 @@ import torch.distributed as dist
 class GradBucketAllReduce:
     """Bucketed, overlapped all-reduce of a UNet's gradient arena."""
 
-    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes=16 << 20):
+    def __init__(self, model, optimizer=None, process_group=None, bucket_bytes=16 << 20,
+                 average=True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend nccl or gloo)")
         self.model = model
@@ -32,7 +37,7 @@ class GradBucketAllReduce:
         self._hi = None
         model.grad_ready_hook = self._on_ready
         if optimizer is not None:
-            optimizer.grad_scale = 1.0 / self.world
+            optimizer.grad_scale = 1.0 / self.world if average else 1.0
 
     # called from UNet backward: every gradient at arena offsets >= lo is final
     def _on_ready(self, lo):

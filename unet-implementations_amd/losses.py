@@ -16,6 +16,18 @@ class _LossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, mod, class_weights):
         want_grad = ctx.needs_input_grad[0]
+        world = mod._world()
+        if world > 1:
+            import torch.distributed as dist
+            stats, ws = ops.dice_wce_loss_shard_stats(logits, target, mod.smooth, mod.ignore_index)
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=mod.process_group)
+            out, dl = ops.dice_wce_loss_shard_apply(
+                logits, target, stats, logits.shape[0] * world, ws, mod.smooth, mod.weight_dice,
+                mod.weight_ce, mod.ignore_index, mod.dynamic_weights, class_weights=class_weights,
+                grad_scale=mod.grad_scale, want_grad=want_grad)
+            ctx.dl = dl
+            mod.last_terms = out
+            return out[0].clone()
         out, dl = ops.dice_wce_loss_fwd_bwd(
             logits, target, mod.smooth, mod.weight_dice, mod.weight_ce, mod.ignore_index,
             mod.dynamic_weights, class_weights=class_weights, grad_scale=mod.grad_scale,
@@ -33,8 +45,17 @@ class _LossFunction(torch.autograd.Function):
 
 class SimpleLoss(nn.Module):
     def __init__(self, weight_dice=1.0, weight_ce=1.0, ignore_index=255, smooth=1e-5,
-                 class_weights=None, dynamic_weights=True):
+                 class_weights=None, dynamic_weights=True, batch_sync="local", process_group=None):
+        """`batch_sync="global"` (data parallel only; not in the reference, which is
+        single-process): every rank evaluates the loss of the CONCATENATED batch - class weights,
+        CE denominator and the Dice batch mean taken over all ranks' images (equal per-rank batch
+        sizes) - so that N ranks x batch b reproduce one process at batch N*b.  Gradients must
+        then be summed, not averaged: `ddp.GradBucketAllReduce(..., average=False)`."""
         super().__init__()
+        if batch_sync not in ("local", "global"):
+            raise ValueError("batch_sync must be 'local' or 'global'")
+        self.batch_sync = batch_sync
+        self.process_group = process_group
         self.weight_dice = weight_dice
         self.weight_ce = weight_ce
         self.ignore_index = ignore_index
@@ -43,6 +64,14 @@ class SimpleLoss(nn.Module):
         self.dynamic_weights = dynamic_weights
         self.grad_scale = 1.0  # data-parallel training pre-scales the gradient by 1/world
         self.last_terms = None
+
+    def _world(self):
+        if self.batch_sync != "global":
+            return 1
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.process_group)
 
     def forward(self, input, target):
         if not input.is_cuda:

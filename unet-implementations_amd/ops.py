@@ -283,6 +283,33 @@ def dice_wce_loss_fwd_bwd(logits, target, smooth, w_dice, w_ce, ignore_index, dy
     return out, dl
 
 
+def dice_wce_loss_shard_stats(logits, target, smooth, ignore_index):
+    """Phase 1 of the sharded-batch loss: (stats float64[10] on the device, workspace)."""
+    N, K, H, W = logits.shape
+    if K != 3:
+        raise ValueError("the fused loss kernel handles exactly 3 classes")
+    stats = torch.empty((10,), dtype=torch.float64, device=logits.device)
+    ws = _ws(lib().unet_dice_wce_loss_workspace_bytes(N, H, W), logits)
+    check(lib().unet_dice_wce_loss_shard_stats(_ptr(logits), _ptr(target), stats.data_ptr(),
+                                               _ptr(ws), ws.numel(), N, H, W, smooth, ignore_index,
+                                               _stream()))
+    return stats, ws
+
+
+def dice_wce_loss_shard_apply(logits, target, global_stats, n_global, ws, smooth, w_dice, w_ce,
+                              ignore_index, dynamic_weights, class_weights=None, grad_scale=1.0,
+                              want_grad=True):
+    """Phase 2: loss of the concatenated batch (out[0]) and this shard's dL/dlogits."""
+    N, K, H, W = logits.shape
+    out = _f32((8,), logits)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(lib().unet_dice_wce_loss_shard_apply(
+        _ptr(logits), _ptr(target), global_stats.data_ptr(), int(n_global), _ptr(out), _ptr(dl),
+        _ptr(ws), ws.numel(), N, H, W, smooth, w_dice, w_ce, ignore_index,
+        1 if dynamic_weights else 0, _ptr(class_weights), grad_scale, _stream()))
+    return out, dl
+
+
 # ---- validation metrics / input pipeline ---------------------------------------------------
 def argmax_dice_counts(logits, target, ignore_index=255, want_preds=True):
     """Returns (preds uint8 [N,H,W] or None, counts int64 [3,3] = per class
