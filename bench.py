@@ -70,8 +70,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--hw", type=int, default=512)
-    ap.add_argument("--matmul", choices=["fp32", "bf16"], default="fp32",
-                    help="bf16 = BASELINE config 4 (bf16 MFMA operands, fp32 accumulate/storage)")
+    ap.add_argument("--matmul", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+                    help="fp32 = fp32 matrix cores; bf16 = BASELINE config 4 (bf16 MFMA operands, "
+                         "fp32 accumulate/storage); bf16x3 = fp32 operands split into three bf16 "
+                         "terms, six products per multiply on the bf16 matrix cores (fp32-class "
+                         "accuracy, see DESIGN.md)")
     ap.add_argument("--clip", action="store_true",
                     help="BASELINE config 5: CLIP_UNet variant with synthetic CLIP features")
     ap.add_argument("--loss-sync", choices=["local", "global"], default="local",
@@ -172,7 +175,9 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.matmul == "fp32" else "bf16 (MFMA operands; f32 accumulate + storage)",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands; f32 accumulate + storage)",
+                      "bf16x3": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMA products per "
+                                "multiply, f32 accumulate + storage)"}[args.matmul],
             "data": "synthetic",
             "config": {"workload": ("CLIP_UNet (synthetic CLIP features [N,512,16,16]) " if args.clip else "") +
                                    f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
@@ -186,10 +191,12 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
-            k = summ.get("conv_igemm") or summ.get("conv_igemm_bf16")
+            k = summ.get("conv_igemm") or summ.get("conv_igemm_bf16") or summ.get("conv_igemm_bf16x3")
             if k:
                 ach = k["flops"] / (k["ms"] * 1e-3) * 1e-12
-                peak = PEAK_F32_MFMA_TFLOPS if args.matmul == "fp32" else PEAK_BF16_MFMA_TFLOPS
+                # bf16x3 issues 6 bf16 MFMA flops per algorithmic flop
+                peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
+                        "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.matmul]
                 result["roofline"] = {
                     "bound": "mfma", "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": hbm_traffic(args),

@@ -111,6 +111,29 @@ int unet_conv3x3_bwd_weight_bf16(const float* x, int Cx, const float* dy, float*
                                  size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
                                  unet_stream_t stream);
 
+/* Split-bf16 ("bf16x3") operand mode: fp32 operands are split on chip into three bf16 terms
+ * (x = h + m + l, residual <= 2^-26 |x|) and every product is evaluated as the six bf16 x bf16
+ * terms of weight >= 2^-16 on the bf16 matrix cores with fp32 accumulation; the dropped terms
+ * are below one fp32 rounding of the product, so results agree with the fp32-MFMA entry points
+ * to fp32 accuracy (tests/test_kernels_gpu.py compares both with fp64).  Arguments as the
+ * plain entry points plus the weights pre-split by unet_pack_conv3x3_weights_bf16x3:
+ * wf3 = [3][9][Cout][Cin] and wd3 = [3][9][Cin][Cout] bf16 (bit patterns as uint16_t), either
+ * may be NULL in the pack call.  The RGB stem and the stride-2 weight gradient run on the fp32
+ * path, which is why the fp32 wf / wd are still passed. */
+int unet_pack_conv3x3_weights_bf16x3(const float* w_oihw, uint16_t* wf3, uint16_t* wd3, int Cout,
+                                     int Cin, unet_stream_t stream);
+int unet_conv3x3_fwd_bf16x3(const float* x0, int C0, const float* x1, int C1, const float* wf,
+                            const uint16_t* wf3, const float* bias, float* y, int N, int H, int W,
+                            int Cout, int stride, unet_stream_t stream);
+int unet_conv3x3_bwd_data_bf16x3(const float* dy, const float* wd, const uint16_t* wd3,
+                                 int Cin_total, int ci_offset, float* dx, int N, int H, int W,
+                                 int Cout, int Ccols, int stride, int accumulate,
+                                 unet_stream_t stream);
+int unet_conv3x3_bwd_weight_bf16x3(const float* x, int Cx, const float* dy, float* dw_oihw,
+                                   int ci_offset, int Cin_total, float* db, void* workspace,
+                                   size_t workspace_bytes, int N, int H, int W, int Cout,
+                                   int stride, unet_stream_t stream);
+
 /* ---- 1x1 convolution (CLIP fusion layer) ---------------------------------- */
 
 /* y = conv1x1(cat(x0, x1)) + bias with w[Cout][C0+C1]; replaces clip_fusion_conv[0] =

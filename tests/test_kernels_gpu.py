@@ -516,6 +516,82 @@ def test_upblock_golden(ua, golden):
             check(v.cpu(), ref, 5e-5, f"UpBlock grad {k}")
 
 
+# ---------------------------------------------------------------- split-bf16 ("bf16x3") mode
+# fp32 operands split into 3 bf16 terms, 6 products, fp32 accumulation: must be as accurate as
+# the fp32 matrix-core kernels.  Both are compared with an fp64 convolution of the same fp32
+# inputs; the split path may not be worse than 2x the fp32 path's error (plus 1e-6 slack).
+def _x3_ok(e_x3, e_32, what):
+    assert e_x3 <= max(2.0 * e_32, 1e-6), f"{what}: bf16x3 {e_x3:.2e} vs fp32-MFMA {e_32:.2e}"
+    assert e_x3 <= 5e-6, f"{what}: bf16x3 error {e_x3:.2e} is not fp32-class"
+
+
+X3_FWD_SHAPES = BF16_SHAPES + [(1, 32, 32, 256, 128, 128, 1), (2, 34, 18, 32, 0, 32, 2),
+                               (2, 8, 64, 32, 0, 32, 1), (1, 4, 32, 64, 32, 64, 1),
+                               (3, 12, 96, 128, 0, 256, 1), (2, 64, 64, 32, 32, 32, 1),
+                               (8, 64, 64, 64, 0, 64, 1), (8, 64, 64, 32, 0, 32, 1)]
+
+
+@pytest.mark.parametrize("shape", X3_FWD_SHAPES)
+def test_conv3x3_fwd_bf16x3_is_fp32_accurate(ua, shape):
+    N, H, W, C0, C1, Cout, s = shape
+    x = rnd(N, C0 + C1, H, W, seed=3)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=4, scale=0.1)
+    b = rnd(Cout, seed=5)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=1)
+    wf, _ = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    wf3, _ = ua.ops.pack_conv3x3_weights_bf16x3(w.to(DEV), want_wd=False)
+    planes = wf3.float().sum(0).cpu()          # h + m + l reproduces the fp32 weight
+    assert relerr(planes, wf.cpu()) <= 2.0 ** -24
+    x0 = to_nhwc(x[:, :C0])
+    x1 = to_nhwc(x[:, C0:]) if C1 else None
+    y3 = ua.ops.conv3x3_fwd(x0, x1, wf, b.to(DEV), s, bf16="bf16x3", wf3=wf3)
+    y32 = ua.ops.conv3x3_fwd(x0, x1, wf, b.to(DEV), s)
+    _x3_ok(relerr(from_nhwc(y3), ref), relerr(from_nhwc(y32), ref), f"fwd {shape}")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 20, 32, 32, 1, (0, 32)), (1, 16, 16, 96, 64, 1, (32, 64)),
+                                   (2, 16, 24, 32, 64, 2, (0, 32)), (2, 4, 4, 512, 512, 2, (0, 512)),
+                                   (1, 64, 64, 64, 64, 1, (0, 64)), (1, 32, 32, 256, 256, 1, (128, 128)),
+                                   (2, 8, 64, 96, 32, 1, (32, 64)), (1, 4, 32, 32, 128, 1, (0, 32)),
+                                   (8, 64, 64, 64, 32, 1, (0, 64)), (8, 64, 64, 32, 64, 1, (0, 32))])
+def test_conv3x3_bwd_data_bf16x3_is_fp32_accurate(ua, shape):
+    N, H, W, Cin, Cout, s, (off, cc) = shape
+    x = rnd(N, Cin, H, W, seed=6).double().requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=7, scale=0.1)
+    y = F.conv2d(x, w.double(), None, stride=s, padding=1)
+    gy = rnd(*y.shape, seed=8)
+    (gx,) = torch.autograd.grad(y, x, gy.double())
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    _, wd3 = ua.ops.pack_conv3x3_weights_bf16x3(w.to(DEV), want_wf=False)
+    d3 = ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, off, cc, H, W, s, bf16="bf16x3", wd3=wd3)
+    d32 = ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, off, cc, H, W, s)
+    ref = gx[:, off:off + cc]
+    _x3_ok(relerr(from_nhwc(d3), ref), relerr(from_nhwc(d32), ref), f"dgrad {shape}")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 64, 32, 0, 32, 32, 1), (1, 16, 16, 64, 0, 64, 64, 1),
+                                   (2, 8, 8, 128, 0, 128, 128, 1), (1, 32, 32, 64, 32, 96, 64, 1),
+                                   (1, 64, 128, 32, 0, 32, 32, 1), (1, 32, 64, 32, 0, 32, 64, 1),
+                                   (2, 16, 24, 32, 0, 32, 64, 2), (3, 34, 70, 32, 0, 32, 32, 1),
+                                   (2, 64, 64, 128, 0, 128, 64, 1)])
+def test_conv3x3_bwd_weight_bf16x3_is_fp32_accurate(ua, shape):
+    N, H, W, Cx, off, Ct, Cout, s = shape
+    x = rnd(N, Ct, H, W, seed=10)
+    w = rnd(Cout, Ct, 3, 3, seed=11, scale=0.1).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, stride=s, padding=1)
+    gy = rnd(*y.shape, seed=12)
+    (gw,) = torch.autograd.grad(y, w, gy.double())
+    ref = gw[:, off:off + Cx]
+    xs, gys = to_nhwc(x[:, off:off + Cx]), to_nhwc(gy)
+    dw3 = torch.zeros((Cout, Ct, 3, 3), device=DEV)
+    dw32 = torch.zeros((Cout, Ct, 3, 3), device=DEV)
+    db3 = torch.zeros(Cout, device=DEV)
+    ua.ops.conv3x3_bwd_weight(xs, gys, dw3, off, s, db=db3, bf16="bf16x3")
+    ua.ops.conv3x3_bwd_weight(xs, gys, dw32, off, s)
+    _x3_ok(relerr(dw3[:, off:off + Cx], ref), relerr(dw32[:, off:off + Cx], ref), f"wgrad {shape}")
+    check(db3, gy.sum(dim=(0, 2, 3)), 2e-5, "bias gradient")
+
+
 # ---------------------------------------------------------------- validation metrics / input
 @pytest.mark.parametrize("n,h,w", [(1, 64, 64), (3, 96, 160), (8, 512, 512)])
 def test_argmax_dice_counts_exact(ua, n, h, w):

@@ -47,8 +47,9 @@ def unpack_argmax(g, shape):
     return (bits[:, 0] * 2 + bits[:, 1]).reshape(shape).astype(np.uint8)
 
 
-def run_golden(ua, g, full):
+def run_golden(ua, g, full, precision="fp32"):
     model, sd0, img, tgt = build(ua, g)
+    model.matmul_precision = precision
     n, hw = int(g["n"]), int(g["hw"])
     names = [str(s) for s in g["param_names"]]
     assert names == [k for k, _ in model.named_parameters()]
@@ -133,6 +134,15 @@ def test_net64_golden(ua, golden):
 
 def test_net512_golden(ua, golden):
     run_golden(ua, golden("net512"), full=False)
+
+
+@pytest.mark.parametrize("fixture,full", [("net64", True), ("net512", False)])
+def test_golden_in_split_bf16_mode(ua, golden, fixture, full):
+    """matmul_precision="bf16x3" (fp32 operands as three bf16 terms, six products on the bf16
+    matrix cores, fp32 accumulation) is held to the SAME reference fixtures and tolerances as
+    the fp32 matrix-core path: 1e-4 on logits, bit-exact argmax off the tie pixels, gradients,
+    loss and first update."""
+    run_golden(ua, golden(fixture), full=full, precision="bf16x3")
 
 
 def test_net_vs_oracle_random_init(ua):

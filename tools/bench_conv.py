@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer timing of the matrix-core kernels (GPU): forward, data gradient and weight gradient
 of every 3x3 conv of Our_UNet at bs=8, 512x512, with HIP events on the launch stream.
-Usage: python tools/bench_conv.py [fwd|dgrad|wgrad|all] [reps]"""
+Usage: python tools/bench_conv.py [fwd|dgrad|wgrad|all] [reps] [fp32|bf16|bf16x3]"""
 import os
 import sys
 
@@ -13,6 +13,7 @@ import unet_implementations_amd as ua
 ops = ua.ops
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 N = 8
 # name, C0, C1, Cout, H(in), stride
 LAYERS = [
@@ -47,21 +48,22 @@ for name, C0, C1, Cout, H, s in LAYERS:
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
     b = torch.zeros(Cout, device="cuda")
     wf, wd = ops.pack_conv3x3_weights(w)
+    wf3, wd3 = ops.pack_conv3x3_weights_bf16x3(w) if prec == "bf16x3" else (None, None)
     dy = torch.randn(N, Ho, Ho, Cout, device="cuda")
     dw = torch.empty_like(w)
     flops = 2.0 * N * Ho * Ho * 9 * Cin * Cout
     line = f"{name:8s} {flops * 1e-9:8.1f} |"
     if which in ("fwd", "all"):
-        t = timeit(lambda: ops.conv3x3_fwd(x0, x1, wf, b, s))
+        t = timeit(lambda: ops.conv3x3_fwd(x0, x1, wf, b, s, bf16=prec, wf3=wf3))
         tot["fwd"][0] += flops; tot["fwd"][1] += t
         line += f" {t * 1e6:8.1f} {flops / t * 1e-12:6.1f} |"
     else:
         line += f" {'-':>8s} {'-':>6s} |"
     if which in ("dgrad", "all"):
         def dg():
-            ops.conv3x3_bwd_data(dy, wd, 0, C0, H, H, s)
+            ops.conv3x3_bwd_data(dy, wd, 0, C0, H, H, s, bf16=prec, wd3=wd3)
             if C1:
-                ops.conv3x3_bwd_data(dy, wd, C0, C1, H, H, s)
+                ops.conv3x3_bwd_data(dy, wd, C0, C1, H, H, s, bf16=prec, wd3=wd3)
         t = timeit(dg)
         tot["dgrad"][0] += flops; tot["dgrad"][1] += t
         line += f" {t * 1e6:8.1f} {flops / t * 1e-12:6.1f} |"
@@ -69,9 +71,9 @@ for name, C0, C1, Cout, H, s in LAYERS:
         line += f" {'-':>8s} {'-':>6s} |"
     if which in ("wgrad", "all"):
         def wg():
-            ops.conv3x3_bwd_weight(x0, dy, dw, 0, s)
+            ops.conv3x3_bwd_weight(x0, dy, dw, 0, s, bf16=prec)
             if C1:
-                ops.conv3x3_bwd_weight(x1, dy, dw, C0, s)
+                ops.conv3x3_bwd_weight(x1, dy, dw, C0, s, bf16=prec)
         t = timeit(wg)
         tot["wgrad"][0] += flops; tot["wgrad"][1] += t
         line += f" {t * 1e6:8.1f} {flops / t * 1e-12:6.1f}"

@@ -40,6 +40,11 @@ SIGNATURES = {
     "unet_conv3x3_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_weight_bf16": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i,
                                           _p]),
+    "unet_pack_conv3x3_weights_bf16x3": (_i, [_p, _p, _p, _i, _i, _p]),
+    "unet_conv3x3_fwd_bf16x3": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_bwd_data_bf16x3": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_bwd_weight_bf16x3": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i,
+                                          _p]),
     "unet_instnorm_workspace_bytes": (_sz, [_i, _i, _i]),
     "unet_instnorm_stats": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _p]),
     "unet_instnorm_lrelu_drop_fwd": (_i, [_p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),

@@ -9,6 +9,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // ---- error reporting -------------------------------------------------------
 void unet_set_error(const char* fmt, ...);
@@ -60,6 +62,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): the three bf16 terms
+// of the split-bf16 ("bf16x3") matrix-core path; |x - h - m - l| <= 2^-26 |x|.
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  f32x4 r1, r2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { h[i] = (__bf16)v[i]; r1[i] = v[i] - (float)h[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m[i] = (__bf16)r1[i]; r2[i] = r1[i] - (float)m[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) l[i] = (__bf16)r2[i];
 }
 
 // Chan/Welford merge of (count, mean, M2) pairs.

@@ -19,8 +19,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmParams {
   const float* src0;
@@ -44,6 +42,10 @@ struct IgemmParams {
   // 4-7 = weight tap index.  Lives in SGPRs: no scalar-memory load per K step.
   unsigned tapw[3];
   int Ncols;
+  // split-bf16 path: the weights as three bf16 planes, each laid out like `w`
+  const __bf16* w3;
+  int w3_plane;       // elements per plane
+  unsigned w3_bytes;
 };
 
 inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
@@ -462,6 +464,429 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
           if (p.accumulate) v += *o;
           *o = v;
         }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant: fp32-class accuracy on the bf16 matrix cores.
+// Every fp32 operand x is split while it is staged into LDS into three bf16 terms
+//   x = h + m + l,  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (|x - h - m - l| <= 2^-26 |x|)
+// and a product a*b is evaluated as the six terms of weight >= 2^-16
+//   a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_m b_m + a_l b_h
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (each bf16 x bf16 product is exact in
+// fp32); the three dropped terms are below 2^-24 |a b|, the size of one fp32 rounding.
+// Six MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32x32x16 block.
+// Same gather-GEMM, tap table, tiles and epilogue as conv_igemm_kernel; BK = 16 so that the
+// three planes of both double-buffered tiles fit twice per CU; the global loads run two K
+// steps ahead of the MFMAs (registers), the split one step ahead (LDS).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const IgemmParams p) {
+  constexpr int BK = 16;
+  constexpr int LDA = BK + 8;          // bf16 elements per LDS row (48 B: conflict-free b128)
+  constexpr int SEGS = BK / 4;         // 16-B fp32 segments per tile row
+  constexpr int ROWS = 256 / SEGS;     // 64 tile rows per loader pass
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  static_assert(BM % ROWS == 0, "BM must be a multiple of 64");
+  constexpr int A_PASSES = BM / ROWS;
+  // weights arrive pre-split (three bf16 planes): slot = (plane, row, 8-element half row)
+  constexpr int B_SLOTS = BN * 6;
+  constexpr int B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* As = smem_h;                    // [buf][plane][BM][LDA]
+  __bf16* Bs = smem_h + 2 * 3 * A_TILE;   // [buf][plane][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+  const int tiles_n = p.Ncols / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int HlWl = p.Hl * p.Wl;
+  const int M = p.N * HlWl;
+  const int Ktot = p.C0 + p.C1;
+
+  const int lrow = tid / SEGS, lseg = tid % SEGS;
+  int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + lrow + ROWS * i;
+    if (m < M) {
+      const int n = m / HlWl;
+      const int r = m - n * HlWl;
+      const int a = r / p.Wl;
+      const int b = r - a * p.Wl;
+      a_nb[i] = n * p.Hin * p.Win;
+      a_iy[i] = a * p.sin;
+      a_ix[i] = b * p.sin;
+    } else {
+      a_nb[i] = 0;
+      a_iy[i] = -(1 << 24);
+      a_ix[i] = 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(p.w3), 0, (int)p.w3_bytes, 0x00020000);
+  // weight slots of this thread (slots past B_SLOTS alias an earlier slot: same bytes, same
+  // destination, so the duplicate store is harmless and the loop needs no predicate)
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int pl = slot / (2 * BN), rem = slot - pl * 2 * BN;
+    const int row = rem >> 1, half = rem & 1;
+    wslot_off[j] = (unsigned)(pl * p.w3_plane + (p.n_off + n0 + row) * Ktot + 8 * half) * 2u;
+    wslot_lds[j] = pl * B_TILE + row * LDA + 8 * half;
+  }
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[A_PASSES];                    // tile ks+1 (loaded one step ago)
+  f32x4 na[A_PASSES];                    // tile ks+2 (in flight)
+  i32x4 rb[B_PASSES], nb[B_PASSES];      // weight planes: raw bf16 bits
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int KS = p.ntaps * (Ktot / BK);
+
+  auto load_tiles = [&](int t, int chunk, f32x4* qa, i32x4* qb) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const int wt = (int)(e >> 4);
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      qa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    const unsigned woff = (unsigned)(wt * p.tap_stride + c) * 2u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      qb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wslot_off[j] + woff, 0, 0);
+  };
+  auto store_tiles = [&](int buf) {
+    __bf16* Ab = As + buf * 3 * A_TILE + lrow * LDA + lseg * 4;
+    __bf16* Bb = Bs + buf * 3 * B_TILE;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      bf16x4 h, m, l;
+      split3(ra[i], h, m, l);
+      *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = h;
+      *reinterpret_cast<bf16x4*>(Ab + A_TILE + ROWS * i * LDA) = m;
+      *reinterpret_cast<bf16x4*>(Ab + 2 * A_TILE + ROWS * i * LDA) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<i32x4*>(Bb + wslot_lds[j]) = rb[j];
+  };
+
+  int t_next = 0, chunk_next = 0, issued = 0;
+  auto advance = [&]() {  // branch-free; past the end it keeps re-staging the last tile
+    const bool on = issued + 1 < KS;
+    const int tn2 = t_next + 1;
+    const bool wrap = tn2 == p.ntaps;
+    t_next = on ? (wrap ? 0 : tn2) : t_next;
+    chunk_next = on ? chunk_next + (wrap ? 1 : 0) : chunk_next;
+    issued += on ? 1 : 0;
+  };
+
+  load_tiles(t_next, chunk_next, ra, rb);
+  advance();
+  store_tiles(0);
+  load_tiles(t_next, chunk_next, ra, rb);
+  advance();
+  __syncthreads();
+
+  const int frag_off = li * LDA + 8 * lh;
+  for (int ks = 0; ks < KS; ++ks) {
+    const int buf = ks & 1;
+    load_tiles(t_next, chunk_next, na, nb);
+    advance();
+    const __bf16* Ab = As + buf * 3 * A_TILE + wm0 * LDA + frag_off;
+    const __bf16* Bb = Bs + buf * 3 * B_TILE + wn0 * LDA + frag_off;
+    bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        a[pl][m] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_TILE + m * 32 * LDA);
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+        b[pl][n] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_TILE + n * 32 * LDA);
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        f32x16 c = acc[m][n];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][m], b[0][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[1][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[2][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[0][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[1][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[0][n], c, 0, 0, 0);
+        acc[m][n] = c;
+      }
+    store_tiles(buf ^ 1);
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) ra[i] = na[i];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) rb[j] = nb[j];
+    __syncthreads();
+  }
+
+  const bool direct = (p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout);
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    const int col = n0 + wn0 + n * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int mg = m0 + row;
+        if (mg < M) {
+          size_t opix;
+          if (direct) {
+            opix = (size_t)mg;
+          } else {
+            const int nn = mg / HlWl;
+            const int rr = mg - nn * HlWl;
+            const int a2 = rr / p.Wl;
+            const int b2 = rr - a2 * p.Wl;
+            opix = ((size_t)nn * p.Hout + (a2 * p.sout + p.py)) * p.Wout + (b2 * p.sout + p.px);
+          }
+          float* o = p.out + opix * p.ldo + col;
+          float v = acc[m][n][r] + bv;
+          if (p.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Patch-staged split-bf16 kernel: stride-1 3x3 convolution (forward and data gradient) whose
+// image tiles as 4 rows x 32 columns.  Per 16-channel chunk the (4+2) x (32+2) input patch is
+// split into its three bf16 planes ONCE and kept in LDS for all nine taps (the gather-GEMM
+// above re-stages and re-splits the A tile for every tap: 9x the loads, VALU and LDS writes);
+// a tap is a constant offset into the patch, an MFMA A-fragment is one 32-pixel patch row.
+// Weights arrive pre-split (unet_pack_conv3x3_weights_bf16x3) and go global -> LDS as raw bits,
+// double-buffered per tap.  LDS: patch 3 x 204 x 48 B + weights 2 x 3 x BN x 48 B (66 KB at
+// BN = 128: two workgroups per CU).
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN, int TH>
+__global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmParams p) {
+  constexpr int LDA = 24;                    // bf16 per LDS row: 16 + 8 pad (48 B)
+  constexpr int TW = 32, PW = TW + 2;
+  constexpr int PPIX = (TH + 2) * PW;        // patch pixels (204 for 4 rows, 340 for 8)
+  constexpr int P_PLANE = PPIX * LDA;
+  constexpr int P_SLOTS = PPIX * 4;          // f32x4 slots: 16 channels per pixel
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = BN * 6, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = BN * LDA;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* Ps = smem_h;                       // [plane][pixel][LDA]
+  __bf16* Bs = smem_h + 3 * P_PLANE;         // [buf][plane][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+
+  const int H = p.Hin, W = p.Win;
+  const int tiles_n = p.Ncols / BN, tiles_x = W / TW, tiles_y = H / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int Ktot = p.C0 + p.C1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(p.w3), 0, (int)p.w3_bytes, 0x00020000);
+
+  // patch slots (slots past P_SLOTS alias an earlier slot: same bytes to the same place)
+  int pp_lin[P_PASSES], pp_lds[P_PASSES];
+  unsigned pp_oob[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = (tid + 256 * i) % P_SLOTS;
+    const int pix = slot >> 2, seg = slot & 3;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    pp_lin[i] = ok ? ((n * H + iy) * W + ix) * 4 : 0;   // x channel count = byte offset
+    pp_oob[i] = (ok ? 0u : 0x80000000u) | (unsigned)(seg * 16);   // + this slot's 4 channels
+    pp_lds[i] = pix * LDA + seg * 4;
+  }
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int pl = slot / (2 * BN), rem = slot - pl * 2 * BN;
+    const int row = rem >> 1, half = rem & 1;
+    wslot_off[j] = (unsigned)(pl * p.w3_plane + (p.n_off + n0 + row) * Ktot + 8 * half) * 2u;
+    wslot_lds[j] = pl * B_TILE + row * LDA + 8 * half;
+  }
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 pr[P_PASSES];
+  i32x4 rb[B_PASSES];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+
+  auto load_patch = [&](int chunk) {
+    const int c = chunk * 16;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const unsigned cbytes = (unsigned)(first ? c : c - p.C0) * 4u;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      // pp_lin = 4 * pixel index, so pp_lin * Cs = byte offset of the pixel's channel 0
+      const unsigned off = ((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i];
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      bf16x4 h, m, l;
+      split3(pr[i], h, m, l);
+      __bf16* d = Ps + pp_lds[i];
+      *reinterpret_cast<bf16x4*>(d) = h;
+      *reinterpret_cast<bf16x4*>(d + P_PLANE) = m;
+      *reinterpret_cast<bf16x4*>(d + 2 * P_PLANE) = l;
+    }
+  };
+  auto load_b = [&](int t, int chunk) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const int wt = (int)(((tw >> ((t & 3) * 8)) & 0xffu) >> 4);
+    const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * 16) * 2u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wslot_off[j] + woff, 0, 0);
+  };
+  auto store_b = [&](int buf) {
+    __bf16* Bb = Bs + buf * 3 * B_TILE;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<i32x4*>(Bb + wslot_lds[j]) = rb[j];
+  };
+
+  const int chunks = Ktot / 16;
+  const int steps = chunks * 9;
+  load_patch(0);
+  load_b(0, 0);
+  store_patch();
+  store_b(0);
+  __syncthreads();
+
+  const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
+  const int b_lane = (wn0 + li) * LDA + 8 * lh;
+  int t = 0, chunk = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    // next step's weights; next chunk's patch rides in registers through the nine taps
+    const int t1 = (t == 8) ? 0 : t + 1;
+    const int chunk1 = (t == 8) ? chunk + 1 : chunk;
+    const bool more = s + 1 < steps;
+    load_b(more ? t1 : t, more ? chunk1 : chunk);
+    if (t == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
+    const __bf16* Bb = Bs + buf * 3 * B_TILE + b_lane;
+    bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        a[pl][m] = *reinterpret_cast<const bf16x8*>(Ab + pl * P_PLANE + m * PW * LDA);
+#pragma unroll
+      for (int nb = 0; nb < TN; ++nb)
+        b[pl][nb] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_TILE + nb * 32 * LDA);
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int nb = 0; nb < TN; ++nb) {
+        f32x16 c = acc[m][nb];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][m], b[0][nb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[1][nb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[2][nb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[0][nb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[1][nb], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[0][nb], c, 0, 0, 0);
+        acc[m][nb] = c;
+      }
+    store_b(buf ^ 1);
+    if (t == 8) {            // every wave is done with this chunk's patch
+      __syncthreads();
+      store_patch();
+    }
+    __syncthreads();
+    t = t1;
+    chunk = chunk1;
+  }
+
+  // ---- epilogue: D row (= pixel column) (reg&3) + 8*(reg>>2) + 4*lh, D column (= channel) li
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      const size_t rowbase = ((size_t)n * H + (y0 + wrow0 + m)) * W + x0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = p.out + (rowbase + x) * p.ldo + col;
+        float v = acc[m][nb][r] + bv;
+        if (p.accumulate) v += *o;
+        *o = v;
       }
     }
   }
@@ -936,6 +1361,78 @@ int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
   return launch_igemm_bf16<128, 32, 32, 32>(p, stream);
 }
 
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_split(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * 3 * (size_t)(BM + BN) * 24 * sizeof(__bf16);
+  static bool attr_set = false;
+  auto kern = conv_igemm_split_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_igemm_split");
+  return UNET_OK;
+}
+
+template <int BN, int WM, int WN, int TH>
+int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds =
+      (3 * (size_t)((TH + 2) * 34) * 24 + 2 * 3 * (size_t)BN * 24) * sizeof(__bf16);
+  static bool attr_set = false;
+  auto kern = conv_patch_split_kernel<BN, WM, WN, TH>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_split");
+  return UNET_OK;
+}
+
+// stride-1 3x3 over an image that tiles as 4 x 32 pixels
+bool patch_applicable(const IgemmParams& p) {
+  static const int off = getenv("UNET_NO_PATCH") ? 1 : 0;
+  return !off && p.ntaps == 9 && p.sin == 1 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
+         p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 && p.Win % 32 == 0 &&
+         p.C0 % 16 == 0 && p.C1 % 16 == 0;
+}
+
+int dispatch_igemm(const IgemmParams& p, hipStream_t stream);
+
+int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  // images narrower than one 32-pixel patch row (the 1/32-resolution stage): too few tiles for
+  // the split kernels to win, the fp32 matrix-core kernel is faster there
+  if (p.Wl < 32 && p.sout == 1) return dispatch_igemm(p, stream);
+  if (patch_applicable(p)) {
+    const long long mt = M / 128;
+    if (nc % 128 == 0 && mt * (nc / 128) >= 512)
+      return launch_patch_split<128, 64, 64, 4>(p, stream);
+    // narrow outputs: taller tiles (two or four patch rows per wave) cut the LDS reads per MFMA
+    static const int th4 = getenv("UNET_PATCH_TH4") ? 1 : 0;
+    const bool tall = !th4 && p.Hin % 8 == 0;
+    if (nc % 64 == 0) {
+      if (tall && (M / 256) * (nc / 64) >= 512) return launch_patch_split<64, 128, 32, 8>(p, stream);
+      return launch_patch_split<64, 64, 32, 4>(p, stream);
+    }
+    if (tall && (M / 256) * (nc / 32) >= 512) return launch_patch_split<32, 64, 32, 8>(p, stream);
+    return launch_patch_split<32, 32, 32, 4>(p, stream);
+  }
+  if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+    return launch_igemm_split<128, 128, 64, 64>(p, stream);
+  if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+    return launch_igemm_split<128, 64, 64, 32>(p, stream);
+  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_split<64, 64, 32, 32>(p, stream);
+  return launch_igemm_split<128, 32, 32, 32>(p, stream);
+}
+
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
@@ -1035,8 +1532,10 @@ void fill_fwd_taps(IgemmParams& p, int stride) {
 
 static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, const float* wf,
                             const float* bias, float* y, int N, int H, int W, int Cout,
-                            int stride, bool bf16, hipStream_t stream) {
+                            int stride, int prec, hipStream_t stream,
+                            const uint16_t* wf3 = nullptr) {
   UNET_REQUIRE(x0 && wf && y, "conv3x3_fwd: null pointer");
+  UNET_REQUIRE(prec != 3 || wf3, "conv3x3_fwd_bf16x3: the pre-split weight planes are null");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_fwd: stride %d unsupported", stride);
   UNET_REQUIRE(N > 0 && H > 0 && W > 0, "conv3x3_fwd: bad shape");
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_fwd: Cout %d must be a multiple of 32", Cout);
@@ -1066,8 +1565,12 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
   p.Hl = p.Hout = (H - 1) / stride + 1;
   p.Wl = p.Wout = (W - 1) / stride + 1;
   p.Ncols = Cout;
+  p.w3 = reinterpret_cast<const __bf16*>(wf3);
+  p.w3_plane = 9 * Cout * (C0 + C1);
+  p.w3_bytes = (unsigned)((long long)3 * p.w3_plane * 2);
   fill_fwd_taps(p, stride);
-  if (bf16) return dispatch_igemm_bf16(p, stream);
+  if (prec == 1) return dispatch_igemm_bf16(p, stream);
+  if (prec == 3) return dispatch_igemm_split(p, stream);
   if (stride == 1 && rf_applicable(p))
     return (C0 + C1 == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 0, stream)
                            : launch_igemm_rf<128, 32, 32, 32, false>(p, 0, stream);
@@ -1077,7 +1580,7 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
 extern "C" int unet_conv3x3_fwd(const float* x0, int C0, const float* x1, int C1, const float* wf,
                                 const float* bias, float* y, int N, int H, int W, int Cout,
                                 int stride, unet_stream_t stream) {
-  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, false,
+  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, 0,
                           (hipStream_t)stream);
 }
 
@@ -1085,16 +1588,27 @@ extern "C" int unet_conv3x3_fwd_bf16(const float* x0, int C0, const float* x1, i
                                      const float* wf, const float* bias, float* y, int N, int H,
                                      int W, int Cout, int stride, unet_stream_t stream) {
   if (C0 == 3)   // the RGB stem is HBM-bound: it stays on the fp32 path
-    return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, false,
+    return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, 0,
                             (hipStream_t)stream);
-  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, true,
+  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, 1,
                           (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_fwd_bf16x3(const float* x0, int C0, const float* x1, int C1,
+                                       const float* wf, const uint16_t* wf3, const float* bias,
+                                       float* y, int N, int H, int W, int Cout, int stride,
+                                       unet_stream_t stream) {
+  // the RGB stem (K = 27, HBM-bound) stays on the fp32 matrix-core path
+  return conv3x3_fwd_impl(x0, C0, x1, C1, wf, bias, y, N, H, W, Cout, stride, C0 == 3 ? 0 : 3,
+                          (hipStream_t)stream, wf3);
 }
 
 static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total, int ci_offset,
                                  float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
-                                 int accumulate, bool bf16, hipStream_t stream) {
+                                 int accumulate, int prec, hipStream_t stream,
+                                 const uint16_t* wd3 = nullptr) {
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
+  UNET_REQUIRE(prec != 3 || wd3, "conv3x3_bwd_data_bf16x3: the pre-split weight planes are null");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_data: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
                    ci_offset + Ccols <= Cin_total,
@@ -1116,13 +1630,17 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   p.N = N; p.Hin = Ho; p.Win = Wo;
   p.Hout = H; p.Wout = W;
   p.Ncols = Ccols;
+  p.w3 = reinterpret_cast<const __bf16*>(wd3);
+  p.w3_plane = 9 * Cout * Cin_total;
+  p.w3_bytes = (unsigned)((long long)3 * p.w3_plane * 2);
   p.sin = 1;
   if (stride == 1) {
     p.Hl = H; p.Wl = W; p.sout = 1; p.py = p.px = 0;
     p.ntaps = 9;
     p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
-    if (bf16) return dispatch_igemm_bf16(p, stream);
+    if (prec == 1) return dispatch_igemm_bf16(p, stream);
+    if (prec == 3) return dispatch_igemm_split(p, stream);
     if (rf_applicable(p))
       return (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream)
                           : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream);
@@ -1134,7 +1652,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
     // one launch for all four parity classes when there are enough tiles to fill the chip
     const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
-    if (!bf16 && !per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
+    if (prec != 1 && !per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
   }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
@@ -1150,7 +1668,8 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
         }
       }
       p.ntaps = nt;
-      int rc = bf16 ? dispatch_igemm_bf16(p, stream) : dispatch_igemm(p, stream);
+      int rc = prec == 1 ? dispatch_igemm_bf16(p, stream)
+                         : (prec == 3 ? dispatch_igemm_split(p, stream) : dispatch_igemm(p, stream));
       if (rc != UNET_OK) return rc;
     }
   return UNET_OK;
@@ -1161,7 +1680,7 @@ extern "C" int unet_conv3x3_bwd_data(const float* dy, const float* wd, int Cin_t
                                      int Ccols, int stride, int accumulate,
                                      unet_stream_t stream) {
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
-                               accumulate, false, (hipStream_t)stream);
+                               accumulate, 0, (hipStream_t)stream);
 }
 
 extern "C" int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int Cin_total,
@@ -1169,7 +1688,15 @@ extern "C" int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int 
                                           int Ccols, int stride, int accumulate,
                                           unet_stream_t stream) {
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
-                               accumulate, true, (hipStream_t)stream);
+                               accumulate, 1, (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_bwd_data_bf16x3(const float* dy, const float* wd,
+                                            const uint16_t* wd3, int Cin_total, int ci_offset,
+                                            float* dx, int N, int H, int W, int Cout, int Ccols,
+                                            int stride, int accumulate, unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
+                               accumulate, 3, (hipStream_t)stream, wd3);
 }
 
 // ---------------------------------------------------------------------------

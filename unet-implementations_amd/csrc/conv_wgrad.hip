@@ -19,8 +19,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct WgradParams {
   const float* x;   // [N][H][W][Cx]
@@ -214,7 +212,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // Lane l: g = l>>4, h = g>>1, q = (l&15)>>2, p = l&3 supplies row 8h + 4*half + q, columns
 // 16*(g&1) + 4p and receives column l&31 of those four rows = operand element k = 8h+4*half+q'.
 // ---------------------------------------------------------------------------
-template <int CI_T, int CO_T, int S>
+//
+// NPL = 3 is the split-bf16 ("bf16x3") form: every operand is staged as three bf16 planes
+// (common.h split3) and each tap accumulates the six products of weight >= 2^-16, which
+// reproduces the fp32 product to one fp32 rounding (see conv_igemm_split_kernel).
+template <int CI_T, int CO_T, int S, int NPL>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradParams p) {
   constexpr int STRIDE = 1;
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
@@ -225,12 +227,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
   constexpr int NP4 = 3 * PW * CI_T / 4;   // float4 slots of the patch
   constexpr int ND4 = S * CO_T / 4;        // float4 slots of the dy segment
   constexpr int PATCH = NP4 * 4;           // elements
-  constexpr int STAGE = PATCH + ND4 * 4;
+  constexpr int PLANE = PATCH + ND4 * 4;   // one bf16 plane of a stage
+  constexpr int STAGE = PLANE * NPL;
   // loader slots: the first NLP slots of every thread are patch slots, the next NLD dy slots
   // (slot kind is a compile-time property: no per-slot select, no branch)
   constexpr int NLP = (NP4 + NT - 1) / NT, NLD = (ND4 + NT - 1) / NT;
   constexpr int NG = (S / 16) / NPP;       // 16-pixel k-groups per wave per segment
   static_assert((S / 16) % NPP == 0 && NG >= 1, "segment must split into whole k-groups");
+  static_assert(NPL == 1 || NPL == 3, "one bf16 plane or the three of the split form");
   extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
   constexpr int PSUB = 3 * PW * 32, DSUB = S * 32;   // elements per 32-channel sub-tile
 
@@ -302,7 +306,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     return h;
   };
-  // LDS element offset of patch slot idx: [sub][pixel][32]; seg = idx % (CI_T/4) -> channel 4*seg
+  // LDS element offset of patch slot idx: [plane][sub][pixel][32]; seg -> channel 4*seg
+  auto put = [&](__bf16* dst, const f32x4 v) {
+    if (NPL == 1) {
+      *reinterpret_cast<bf16x4*>(dst) = to_bf16(v);
+    } else {
+      bf16x4 h, m, l;
+      split3(v, h, m, l);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+    }
+  };
   auto store_stage = [&](int buf) {
     __bf16* base = smem_h + buf * STAGE;
 #pragma unroll
@@ -310,14 +325,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
       const int idx = tid + NT * k;
       const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
       if (NT * (k + 1) <= NP4 || idx < NP4)
-        *reinterpret_cast<bf16x4*>(base + (seg >> 3) * PSUB + pix * 32 + (seg & 7) * 4) = to_bf16(rp[k]);
+        put(base + (seg >> 3) * PSUB + pix * 32 + (seg & 7) * 4, rp[k]);
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int d = tid + NT * k;
       const int dpix = d / (CO_T / 4), seg = d - dpix * (CO_T / 4);
       if (NT * (k + 1) <= ND4 || d < ND4)
-        *reinterpret_cast<bf16x4*>(base + PATCH + (seg >> 3) * DSUB + dpix * 32 + (seg & 7) * 4) = to_bf16(rd[k]);
+        put(base + PATCH + (seg >> 3) * DSUB + dpix * 32 + (seg & 7) * 4, rd[k]);
     }
   };
 
@@ -347,21 +362,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
       for (int gq = 0; gq < NG; ++gq) {
         const int xx0 = 16 * (pp + NPP * gq);          // first pixel of this k-group
         const int r0 = xx0 + 8 * th + tq;              // this lane's row for half 0 (+4 for half 1)
-        bf16x8 b;
-        {
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(D + r0 * 32 + tcol));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(D + (r0 + 4) * 32 + tcol));
-          b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+        auto frag = [&](const __bf16* q) {   // rows r0..r0+3 and r0+4..r0+7 of this lane's group
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = frag(D + (pl < NPL ? pl : 0) * PLANE + r0 * 32 + tcol);
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
           for (int v = 0; v < 3; ++v) {
             const __bf16* pa = P + (u * PW + r0 + v) * 32 + tcol;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)pa);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pa + 4 * 32));
-            const bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[u][v], 0, 0, 0);
+            if (NPL == 1) {
+              acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pa), b[0], acc[u][v], 0, 0, 0);
+            } else {
+              const bf16x8 a0 = frag(pa), a1 = frag(pa + PLANE), a2 = frag(pa + 2 * PLANE);
+              f32x16 c = acc[u][v];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], c, 0, 0, 0);
+              acc[u][v] = c;
+            }
           }
       }
       store_stage(buf ^ 1);
@@ -552,7 +578,7 @@ struct WgradPlan {
 
 int stem_grid(long long stages) { return (int)(stages < 1024 ? stages : 1024); }
 
-WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
+WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec = 0) {
   WgradPlan pl{};
   if (Cx == 3) {
     pl.stem = true;
@@ -573,7 +599,7 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride) {
   pl.npp = 4 / nsb;  // pixel-pair parts per segment, each with a slab of its own
   // segment length: enough pixel pairs per wave per stage, within the LDS budget
   if (Wo <= 16) pl.S = 16;
-  else if (pl.ci_t == 64) pl.S = (stride == 2) ? 16 : 32;
+  else if (pl.ci_t == 64) pl.S = (stride == 2 || prec == 3) ? 16 : 32;  // bf16x3: 3 planes in LDS
   else if (pl.co_t == 64) pl.S = 32;                       // 32x64 tile
   else pl.S = (stride == 1 && Wo >= 64) ? 64 : 32;         // 32x32 tile
   pl.segs_per_row = ceil_div(Wo, pl.S);
@@ -611,12 +637,19 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-template <int CI_T, int CO_T, int S>
+template <int CI_T, int CO_T, int S, int NPL = 1>
 int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = S + 2;
-  constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  constexpr size_t lds = 2 * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  static bool attr_set = false;
+  auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, NPL>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
-  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<CI_T, CO_T, S>), dim3(grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_wgrad_bf16");
   return UNET_OK;
 }
@@ -648,19 +681,22 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, int Cx, int Cout,
                                                           int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cx <= 0 || Cout <= 0) return 0;
-  return make_plan(N, H, W, Cx, Cout, stride).ws_floats * sizeof(float);
+  // one size for every operand mode (the bf16x3 plan uses shorter segments on 64x64 tiles)
+  const size_t a = make_plan(N, H, W, Cx, Cout, stride, 0).ws_floats;
+  const size_t b = make_plan(N, H, W, Cx, Cout, stride, 3).ws_floats;
+  return (a > b ? a : b) * sizeof(float);
 }
 
 static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
                                 int ci_offset, int Cin_total, float* db, void* workspace,
                                 size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
-                                bool center_only, hipStream_t stream, bool bf16 = false) {
+                                bool center_only, hipStream_t stream, int prec = 0) {
   UNET_REQUIRE(x && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
   UNET_REQUIRE(Cx == 3 || (Cx > 0 && Cx % 32 == 0), "conv3x3_bwd_weight: Cx %d unsupported", Cx);
   UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_bwd_weight: bad ci slice");
-  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride);
+  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride, (prec == 3 && stride == 1) ? 3 : 0);
   if (workspace_bytes < pl.ws_floats * sizeof(float)) {
     unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes,
                    pl.ws_floats * sizeof(float));
@@ -706,8 +742,12 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     p.dy_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
     int rc;
     // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
-    const bool use_bf16 = bf16 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
-    if (use_bf16) {
+    const bool use_bf16 = prec != 0 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
+    // bf16x3: the 32x32 tile's three planes only fit once per CU and lose to the fp32 kernel
+    if (use_bf16 && prec == 3 && !(pl.ci_t == 32 && pl.co_t == 32)) {
+      if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
+      else rc = launch_wgrad_bf16<64, 64, 16, 3>(p, stream);
+    } else if (use_bf16 && prec == 1) {
       if (pl.ci_t == 32 && pl.co_t == 32) rc = launch_wgrad_bf16<32, 32, 64>(p, stream);
       else if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32>(p, stream);
       else rc = pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
@@ -808,5 +848,15 @@ extern "C" int unet_conv3x3_bwd_weight_bf16(const float* x, int Cx, const float*
                                             unet_stream_t stream) {
   return conv_bwd_weight_impl(x, Cx, dy, dw_oihw, ci_offset, Cin_total, db, workspace,
                               workspace_bytes, N, H, W, Cout, stride, false, (hipStream_t)stream,
-                              true);
+                              1);
+}
+
+extern "C" int unet_conv3x3_bwd_weight_bf16x3(const float* x, int Cx, const float* dy,
+                                              float* dw_oihw, int ci_offset, int Cin_total,
+                                              float* db, void* workspace, size_t workspace_bytes,
+                                              int N, int H, int W, int Cout, int stride,
+                                              unet_stream_t stream) {
+  return conv_bwd_weight_impl(x, Cx, dy, dw_oihw, ci_offset, Cin_total, db, workspace,
+                              workspace_bytes, N, H, W, Cout, stride, false, (hipStream_t)stream,
+                              3);
 }

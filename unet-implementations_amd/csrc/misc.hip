@@ -115,6 +115,36 @@ __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ w
   }
 }
 
+// bf16x3 form: the same two layouts, every weight split into its three bf16 terms
+// (common.h split3); out = [plane][tap][row][col], planes 9*Cin*Cout elements apart.
+__global__ void pack_w_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wf3,
+                                    __bf16* __restrict__ wd3, int Cout, int Cin) {
+  const long long total = (long long)9 * Cin * Cout;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    if (wd3) {  // i = (t*Cin + ci)*Cout + co
+      const int co = (int)(i % Cout);
+      const long long r = i / Cout;
+      const int ci = (int)(r % Cin), t = (int)(r / Cin);
+      const float v = w[((size_t)co * Cin + ci) * 9 + t];
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      wd3[i] = h; wd3[total + i] = m; wd3[2 * total + i] = (__bf16)(r1 - (float)m);
+    }
+    if (wf3) {  // i = (t*Cout + co)*Cin + ci
+      const int ci = (int)(i % Cin);
+      const long long r = i / Cin;
+      const int co = (int)(r % Cout), t = (int)(r / Cout);
+      const float v = w[((size_t)co * Cin + ci) * 9 + t];
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      wf3[i] = h; wf3[total + i] = m; wf3[2 * total + i] = (__bf16)(r1 - (float)m);
+    }
+  }
+}
+
 // ---- bilinear 2x, align_corners=False ---------------------------------------------
 // out[2i]   = 0.25*in[i-1] + 0.75*in[i]   (i-1 clamped: out[0] = in[0])
 // out[2i+1] = 0.75*in[i]   + 0.25*in[i+1] (i+1 clamped)
@@ -272,6 +302,18 @@ extern "C" int unet_pack_conv3x3_weights(const float* w, float* wf, float* wd, i
   hipLaunchKernelGGL(pack_w_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
                      wf, wd, Cout, Cin);
   UNET_CHECK_LAUNCH("pack_w");
+  return UNET_OK;
+}
+
+extern "C" int unet_pack_conv3x3_weights_bf16x3(const float* w, uint16_t* wf3, uint16_t* wd3,
+                                                int Cout, int Cin, unet_stream_t stream) {
+  UNET_REQUIRE(w && (wf3 || wd3) && Cout > 0 && Cin > 0,
+               "pack_conv3x3_weights_bf16x3: bad argument");
+  const long long total = (long long)9 * Cin * Cout;
+  hipLaunchKernelGGL(pack_w_split_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, w, reinterpret_cast<__bf16*>(wf3),
+                     reinterpret_cast<__bf16*>(wd3), Cout, Cin);
+  UNET_CHECK_LAUNCH("pack_w_split");
   return UNET_OK;
 }
 

@@ -57,7 +57,7 @@ def _ptr(t):
     if not t.is_cuda:
         raise RuntimeError("unet-implementations_amd: the HIP path needs CUDA/ROCm tensors "
                            "(no CPU fallback exists)")
-    if t.dtype not in (torch.float32, torch.int64, torch.uint8):
+    if t.dtype not in (torch.float32, torch.int64, torch.uint8, torch.bfloat16):
         raise TypeError(f"unsupported dtype {t.dtype}")
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
@@ -98,8 +98,36 @@ def pack_conv3x3_weights(w_oihw, wf=None, wd=None, want_wd=True):
     return wf, wd
 
 
+def pack_conv3x3_weights_bf16x3(w_oihw, want_wd=True, want_wf=True):
+    """The two packed layouts as three bf16 planes each (the split-bf16 operand mode):
+    wf3 [3, 9, Cout, Cin], wd3 [3, 9, Cin, Cout]."""
+    Cout, Cin, kh, kw = w_oihw.shape
+    assert kh == 3 and kw == 3
+    wf3 = torch.empty((3, 9, Cout, Cin), dtype=torch.bfloat16, device=w_oihw.device) \
+        if want_wf else None
+    wd3 = torch.empty((3, 9, Cin, Cout), dtype=torch.bfloat16, device=w_oihw.device) \
+        if want_wd else None
+    check(lib().unet_pack_conv3x3_weights_bf16x3(_ptr(w_oihw), _ptr(wf3), _ptr(wd3), Cout, Cin,
+                                                 _stream()))
+    return wf3, wd3
+
+
 # ---- convolution ---------------------------------------------------------------
-def conv3x3_fwd(x0, x1, wf, bias, stride, out=None, bf16=False):
+_PREC = {False: 0, True: 1, 0: 0, 1: 1, 3: 3, "fp32": 0, "bf16": 1, "bf16x3": 3}
+_SUFFIX = {0: "", 1: "_bf16", 3: "_bf16x3"}
+_GROUP = {0: "", 1: "_bf16", 3: "_bf16x3"}
+
+
+def _prec(bf16):
+    """Matrix-core operand mode of a conv call: fp32 MFMA (default), bf16 operands, or the
+    split-bf16 emulation of fp32 ("bf16x3": 3 bf16 terms per operand, 6 products)."""
+    try:
+        return _PREC[bf16]
+    except (KeyError, TypeError):
+        raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'") from None
+
+
+def conv3x3_fwd(x0, x1, wf, bias, stride, out=None, bf16=False, wf3=None):
     N, H, W, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[3]
     if x1 is not None:
@@ -109,17 +137,26 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None, bf16=False):
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = out if out is not None else _f32((N, Ho, Wo, Cout), x0)
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().unet_conv3x3_fwd_bf16 if bf16 else lib().unet_conv3x3_fwd
-    check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(bias), _ptr(y), N, H, W, Cout, stride,
-             _stream()))
+    pr = _prec(bf16)
+    if pr == 3 and C0 == 3:
+        pr = 0                      # the RGB stem has no split form (K = 27, HBM-bound)
+    fn = getattr(lib(), "unet_conv3x3_fwd" + _SUFFIX[pr])
+    if pr == 3:
+        if wf3 is None:
+            raise ValueError("bf16x3 needs wf3 from pack_conv3x3_weights_bf16x3")
+        check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(wf3), _ptr(bias), _ptr(y), N, H, W,
+                 Cout, stride, _stream()))
+    else:
+        check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wf), _ptr(bias), _ptr(y), N, H, W, Cout, stride,
+                 _stream()))
     if t0 is not None:
-        _timer.end("conv_stem_fwd" if C0 == 3 else ("conv_igemm_bf16" if bf16 else "conv_igemm"),
+        _timer.end("conv_stem_fwd" if C0 == 3 else "conv_igemm" + _GROUP[pr],
                    2.0 * N * Ho * Wo * 9 * (C0 + C1) * Cout, 1, t0)
     return y
 
 
 def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False,
-                     bf16=False):
+                     bf16=False, wd3=None):
     """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols)."""
     N, Ho, Wo, Cout = dy.shape
     cin_total = wd.shape[1]
@@ -127,15 +164,22 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().unet_conv3x3_bwd_data_bf16 if bf16 else lib().unet_conv3x3_bwd_data
-    check(fn(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N, H, W, Cout, ccols, stride,
-             1 if accumulate else 0, _stream()))
+    pr = _prec(bf16)
+    fn = getattr(lib(), "unet_conv3x3_bwd_data" + _SUFFIX[pr])
+    if pr == 3:
+        if wd3 is None:
+            raise ValueError("bf16x3 needs wd3 from pack_conv3x3_weights_bf16x3")
+        check(fn(_ptr(dy), _ptr(wd), _ptr(wd3), cin_total, ci_offset, _ptr(dx), N, H, W, Cout,
+                 ccols, stride, 1 if accumulate else 0, _stream()))
+    else:
+        check(fn(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N, H, W, Cout, ccols, stride,
+                 1 if accumulate else 0, _stream()))
     if t0 is not None:
         launches = 1
         if stride == 2:  # fp32: one launch when >= 512 tiles, else one per output parity class
             tiles = -(-(N * Ho * Wo) // 128) * (ccols // 32)
-            launches = 1 if (not bf16 and tiles >= 512) else 4
-        _timer.end("conv_igemm_bf16" if bf16 else "conv_igemm",
+            launches = 1 if (pr == 0 and tiles >= 512) else 4
+        _timer.end("conv_igemm" + _GROUP[pr],
                    2.0 * N * Ho * Wo * 9 * ccols * Cout, launches, t0)
     return dx
 
@@ -148,12 +192,13 @@ def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None, bf16=False):
     nbytes = lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride)
     ws = _ws(nbytes, x)
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().unet_conv3x3_bwd_weight_bf16 if bf16 else lib().unet_conv3x3_bwd_weight
+    pr = _prec(bf16)
+    fn = getattr(lib(), "unet_conv3x3_bwd_weight" + _SUFFIX[pr])
     check(fn(_ptr(x), Cx, _ptr(dy), _ptr(dw_oihw), ci_offset, cin_total, _ptr(db), _ptr(ws),
              ws.numel(), N, H, W, Cout, stride, _stream()))
     if t0 is not None:  # wgrad kernel + slab reduce
         Ho, Wo = dy.shape[1], dy.shape[2]
-        _timer.end("conv_stem_wgrad" if Cx == 3 else ("conv_wgrad_bf16" if bf16 else "conv_wgrad"),
+        _timer.end("conv_stem_wgrad" if Cx == 3 else "conv_wgrad" + _GROUP[pr],
                    2.0 * N * Ho * Wo * 9 * Cx * Cout, 2, t0)
     return dw_oihw
 

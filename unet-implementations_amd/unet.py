@@ -396,9 +396,9 @@ class _UNetFunction(torch.autograd.Function):
         masks = _draw_masks(model, layers, N, x.device) if use_masks else [None] * len(layers)
         mask_of = {id(l): m for l, m in zip(layers, masks)}
         saved = []  # per layer: dict(inputs, y, stats, mask, a)
-        if model.matmul_precision not in ("fp32", "bf16"):
-            raise ValueError("matmul_precision must be 'fp32' or 'bf16'")
-        bf16 = model.matmul_precision == "bf16"
+        if model.matmul_precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("matmul_precision must be 'fp32', 'bf16' or 'bf16x3'")
+        bf16 = model.matmul_precision      # operand mode handed to every conv call
 
         def run_layer(l, x0, x1):
             w = l.conv.weight
@@ -408,12 +408,17 @@ class _UNetFunction(torch.autograd.Function):
                 y = ops.conv1x1_fwd(x0, x1, w2d, l.conv.bias.detach())
             else:
                 wf, wd = ops.pack_conv3x3_weights(w.detach(), want_wd=need_grad)
-                y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride, bf16=bf16)
+                wf3 = wd3 = None
+                if bf16 == "bf16x3" and w.shape[1] != 3:
+                    wf3, wd3 = ops.pack_conv3x3_weights_bf16x3(w.detach(), want_wd=need_grad)
+                y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride, bf16=bf16,
+                                    wf3=wf3)
             st = ops.instnorm_stats(y, l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps)
             m = mask_of[id(l)]
             a = ops.instnorm_lrelu_drop_fwd(y, st[2], st[3], m, l.slope)
             if need_grad:
-                saved.append(dict(layer=l, x0=x0, x1=x1, y=y, st=st, mask=m, a=a, wd=wd))
+                saved.append(dict(layer=l, x0=x0, x1=x1, y=y, st=st, mask=m, a=a, wd=wd,
+                                  wd3=wd3 if l.ksize == 3 else None))
             return a
 
         cur = x          # NHWC image
@@ -515,10 +520,10 @@ class _UNetFunction(torch.autograd.Function):
             N, H, W, C0 = x0.shape
             if need_dx:
                 dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
-                                           accumulate=dx0_acc, bf16=ctx.bf16)
+                                           accumulate=dx0_acc, bf16=ctx.bf16, wd3=rec["wd3"])
             if x1 is not None and need_dx1:
                 dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride,
-                                           bf16=ctx.bf16)
+                                           bf16=ctx.bf16, wd3=rec["wd3"])
             return dx0, dx1
 
         done = False
