@@ -185,9 +185,11 @@ def test_net_vs_oracle_random_init(ua):
     assert (num / den) ** 0.5 <= 5e-3, f"whole-gradient rel err {(num / den) ** 0.5:.3e}"
 
 
-def test_gradient_accuracy_vs_fp64(ua):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_gradient_accuracy_vs_fp64(ua, precision):
     """Principled accuracy check: the whole gradient of the HIP path must be as close to an
-    fp64 run of the oracle as the oracle's own fp32 run is (x3 slack, floor 5e-4)."""
+    fp64 run of the oracle as the oracle's own fp32 run is (x3 slack, floor 5e-4) - in the fp32
+    matrix-core mode and in the split-bf16 mode alike."""
     sd0 = O.fill_state_dict(2024)
     img, tgt = O.synthetic_batch(1234, 2, 64, 64)
     masks = O.draw_dropout_masks(77, 2)
@@ -206,6 +208,7 @@ def test_gradient_accuracy_vs_fp64(ua):
     model = ua.UNet()
     model.load_state_dict(sd0)
     model = model.to(DEV).train()
+    model.matmul_precision = precision
     model.dropout_mask_override = masks
     logits = model(img.to(DEV))
     ua.SimpleLoss()(logits, tgt.to(DEV)).backward()

@@ -53,6 +53,25 @@ inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
   p.tapw[t >> 2] |= e << ((t & 3) * 8);
 }
 
+// Epilogue of one 32x32 accumulator block: o[r] = destination of register r (nullptr = out of
+// range).  With `accumulate` all 16 old values are loaded before the first add, so the reads
+// overlap (a per-element load/add/store chain costs one HBM round trip per register).
+__device__ __forceinline__ void store_block16(float* const (&o)[16], const f32x16& acc, float bv,
+                                              int accumulate) {
+  if (accumulate) {
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = o[r] ? *o[r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (o[r]) *o[r] = acc[r] + bv + old[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (o[r]) *o[r] = acc[r] + bv;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int LDA = BK + 4;  // 144-B (80-B) rows: conflict-free ds_read_b128 across 16 rows
@@ -239,27 +258,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
+      float* o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int mg = m0 + row;
-        if (mg < M) {
-          size_t opix;
-          if (direct) {
-            opix = (size_t)mg;
-          } else {
-            const int nn = mg / HlWl;
-            const int rr = mg - nn * HlWl;
-            const int a = rr / p.Wl;
-            const int b = rr - a * p.Wl;
-            opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
-          }
-          float* o = p.out + opix * p.ldo + col;
-          float v = acc[m][n][r] + bv;
-          if (p.accumulate) v += *o;
-          *o = v;
+        size_t opix = (size_t)mg;
+        if (!direct) {
+          const int nn = mg / HlWl;
+          const int rr = mg - nn * HlWl;
+          const int a = rr / p.Wl;
+          const int b = rr - a * p.Wl;
+          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
         }
+        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
       }
+      store_block16(o, acc[m][n], bv, p.accumulate);
     }
   }
 }
@@ -444,27 +458,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
     const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
+      float* o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int mg = m0 + row;
-        if (mg < M) {
-          size_t opix;
-          if (direct) {
-            opix = (size_t)mg;
-          } else {
-            const int nn = mg / HlWl;
-            const int rr = mg - nn * HlWl;
-            const int a = rr / p.Wl;
-            const int b = rr - a * p.Wl;
-            opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
-          }
-          float* o = p.out + opix * p.ldo + col;
-          float v = acc[m][n][r] + bv;
-          if (p.accumulate) v += *o;
-          *o = v;
+        size_t opix = (size_t)mg;
+        if (!direct) {
+          const int nn = mg / HlWl;
+          const int rr = mg - nn * HlWl;
+          const int a = rr / p.Wl;
+          const int b = rr - a * p.Wl;
+          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
         }
+        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
       }
+      store_block16(o, acc[m][n], bv, p.accumulate);
     }
   }
 }
@@ -666,27 +675,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const IgemmPar
     const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
+      float* o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int mg = m0 + row;
-        if (mg < M) {
-          size_t opix;
-          if (direct) {
-            opix = (size_t)mg;
-          } else {
-            const int nn = mg / HlWl;
-            const int rr = mg - nn * HlWl;
-            const int a2 = rr / p.Wl;
-            const int b2 = rr - a2 * p.Wl;
-            opix = ((size_t)nn * p.Hout + (a2 * p.sout + p.py)) * p.Wout + (b2 * p.sout + p.px);
-          }
-          float* o = p.out + opix * p.ldo + col;
-          float v = acc[m][n][r] + bv;
-          if (p.accumulate) v += *o;
-          *o = v;
+        size_t opix = (size_t)mg;
+        if (!direct) {
+          const int nn = mg / HlWl;
+          const int rr = mg - nn * HlWl;
+          const int a = rr / p.Wl;
+          const int b = rr - a * p.Wl;
+          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
         }
+        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
       }
+      store_block16(o, acc[m][n], bv, p.accumulate);
     }
   }
 }
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const IgemmPar
 // double-buffered per tap.  LDS: patch 3 x 204 x 48 B + weights 2 x 3 x BN x 48 B (66 KB at
 // BN = 128: two workgroups per CU).
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH>
+template <int BN, int WM, int WN, int TH, bool PF>
 __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmParams p) {
   constexpr int LDA = 24;                    // bf16 per LDS row: 16 + 8 pad (48 B)
   constexpr int TW = 32, PW = TW + 2;
@@ -824,7 +828,23 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
 
   const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
+  auto tap_off = [&](int t) {   // patch offset of tap t (elements)
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    return (oy * PW + ox) * LDA;
+  };
+  bf16x8 a[3][TM], an[3][TM], b[3][TN];
+  auto read_a = [&](bf16x8 (&q)[3][TM], int t) {
+    const __bf16* Ab = Ps + a_lane + tap_off(t);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        q[pl][m] = *reinterpret_cast<const bf16x8*>(Ab + pl * P_PLANE + m * PW * LDA);
+  };
   int t = 0, chunk = 0;
+  if (PF) read_a(a, 0);
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
     // next step's weights; next chunk's patch rides in registers through the nine taps
@@ -834,20 +854,18 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
     load_b(more ? t1 : t, more ? chunk1 : chunk);
     if (t == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
 
-    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
-    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
-    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
-    const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
     const __bf16* Bb = Bs + buf * 3 * B_TILE + b_lane;
-    bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-        a[pl][m] = *reinterpret_cast<const bf16x8*>(Ab + pl * P_PLANE + m * PW * LDA);
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int nb = 0; nb < TN; ++nb)
         b[pl][nb] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_TILE + nb * 32 * LDA);
+    // the patch does not change inside a chunk: the next tap's A fragments are fetched under
+    // this tap's MFMAs (after tap 8 the patch is replaced, so tap 0 reads behind the barrier)
+    if (PF) {
+      if (t != 8) read_a(an, t1);
+    } else {
+      read_a(a, t);
     }
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -866,8 +884,17 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
     if (t == 8) {            // every wave is done with this chunk's patch
       __syncthreads();
       store_patch();
+      __syncthreads();
+      if (PF) read_a(a, 0);
+    } else {
+      __syncthreads();
+      if (PF) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int m = 0; m < TM; ++m) a[pl][m] = an[pl][m];
+      }
     }
-    __syncthreads();
     t = t1;
     chunk = chunk1;
   }
@@ -879,14 +906,18 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
     const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-      const size_t rowbase = ((size_t)n * H + (y0 + wrow0 + m)) * W + x0;
+      float* o = p.out + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
+      if (p.accumulate) {        // uniform: all 16 reads in flight before the first add
+        float old[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int x = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float* o = p.out + (rowbase + x) * p.ldo + col;
-        float v = acc[m][nb][r] + bv;
-        if (p.accumulate) v += *o;
-        *o = v;
+        for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv + old[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv;
       }
     }
   }
@@ -1107,15 +1138,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
       const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
+        float* o[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float* o = p.out + (size_t)(m0 + row) * p.ldo + col;
-          float v = acc[m][n][r] + bv;
-          if (p.accumulate) v += *o;
-          *o = v;
-          acc[m][n][r] = 0.f;
+          o[r] = p.out + (size_t)(m0 + row) * p.ldo + col;
         }
+        store_block16(o, acc[m][n], bv, p.accumulate);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
       }
     }
   }
@@ -1303,24 +1334,26 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(const IgemmParams
 
   // epilogue: logical row -> (n, a, b); class c -> dx pixel (2a + c/2, 2b + c%2)
   const int col = n0 + li;
+  size_t base[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     const int mg = m0 + row;
-    if (mg < M) {
-      const int nn = mg / HlWl;
-      const int rr = mg - nn * HlWl;
-      const int a = rr / p.Wl;
-      const int b = rr - a * p.Wl;
+    const int nn = mg / HlWl;
+    const int rr = mg - nn * HlWl;
+    const int a = rr / p.Wl;
+    const int b = rr - a * p.Wl;
+    base[r] = mg < M ? ((size_t)nn * p.Hout + 2 * a) * p.Wout + 2 * b : ~(size_t)0;
+  }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const size_t opix = ((size_t)nn * p.Hout + (2 * a + (c >> 1))) * p.Wout + (2 * b + (c & 1));
-        float* o = p.out + opix * p.ldo + col;
-        float v = acc[c][r];
-        if (p.accumulate) v += *o;
-        *o = v;
-      }
-    }
+  for (int c = 0; c < 4; ++c) {
+    float* o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      o[r] = base[r] != ~(size_t)0
+                 ? p.out + (base[r] + (size_t)(c >> 1) * p.Wout + (c & 1)) * p.ldo + col
+                 : nullptr;
+    store_block16(o, acc[c], 0.f, p.accumulate);
   }
 }
 
@@ -1378,12 +1411,12 @@ int launch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-template <int BN, int WM, int WN, int TH>
-int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
+template <int BN, int WM, int WN, int TH, bool PF>
+int launch_patch_split_pf(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds =
       (3 * (size_t)((TH + 2) * 34) * 24 + 2 * 3 * (size_t)BN * 24) * sizeof(__bf16);
   static bool attr_set = false;
-  auto kern = conv_patch_split_kernel<BN, WM, WN, TH>;
+  auto kern = conv_patch_split_kernel<BN, WM, WN, TH, PF>;
   if (!attr_set) {
     UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1393,6 +1426,13 @@ int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_patch_split");
   return UNET_OK;
+}
+
+template <int BN, int WM, int WN, int TH>
+int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
+  static const int pf = getenv("UNET_PATCH_PF") ? atoi(getenv("UNET_PATCH_PF")) : 0;
+  return pf ? launch_patch_split_pf<BN, WM, WN, TH, true>(p, stream)
+            : launch_patch_split_pf<BN, WM, WN, TH, false>(p, stream);
 }
 
 // stride-1 3x3 over an image that tiles as 4 x 32 pixels
@@ -1413,6 +1453,9 @@ int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   if (p.Wl < 32 && p.sout == 1) return dispatch_igemm(p, stream);
   if (patch_applicable(p)) {
     const long long mt = M / 128;
+    static const int cfg = getenv("UNET_PATCH_CFG") ? atoi(getenv("UNET_PATCH_CFG")) : 0;
+    if (cfg == 1 && nc % 64 == 0) return launch_patch_split<64, 64, 32, 4>(p, stream);
+    if (cfg == 2 && nc % 64 == 0 && p.Hin % 8 == 0) return launch_patch_split<64, 128, 32, 8>(p, stream);
     if (nc % 128 == 0 && mt * (nc / 128) >= 512)
       return launch_patch_split<128, 64, 64, 4>(p, stream);
     // narrow outputs: taller tiles (two or four patch rows per wave) cut the LDS reads per MFMA
