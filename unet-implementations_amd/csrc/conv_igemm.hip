@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const IgemmPar
 // double-buffered per tap.  LDS: patch 3 x 204 x 48 B + weights 2 x 3 x BN x 48 B (66 KB at
 // BN = 128: two workgroups per CU).
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH, bool PF>
+template <int BN, int WM, int WN, int TH>
 __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmParams p) {
   constexpr int LDA = 24;                    // bf16 per LDS row: 16 + 8 pad (48 B)
   constexpr int TW = 32, PW = TW + 2;
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
     const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
     return (oy * PW + ox) * LDA;
   };
-  bf16x8 a[3][TM], an[3][TM], b[3][TN];
+  bf16x8 a[3][TM], b[3][TN];
   auto read_a = [&](bf16x8 (&q)[3][TM], int t) {
     const __bf16* Ab = Ps + a_lane + tap_off(t);
 #pragma unroll
@@ -844,7 +844,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
         q[pl][m] = *reinterpret_cast<const bf16x8*>(Ab + pl * P_PLANE + m * PW * LDA);
   };
   int t = 0, chunk = 0;
-  if (PF) read_a(a, 0);
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
     // next step's weights; next chunk's patch rides in registers through the nine taps
@@ -860,13 +859,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
 #pragma unroll
       for (int nb = 0; nb < TN; ++nb)
         b[pl][nb] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_TILE + nb * 32 * LDA);
-    // the patch does not change inside a chunk: the next tap's A fragments are fetched under
-    // this tap's MFMAs (after tap 8 the patch is replaced, so tap 0 reads behind the barrier)
-    if (PF) {
-      if (t != 8) read_a(an, t1);
-    } else {
-      read_a(a, t);
-    }
+    read_a(a, t);   // (prefetching the next tap's A fragments under the MFMAs gained nothing)
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -884,17 +877,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
     if (t == 8) {            // every wave is done with this chunk's patch
       __syncthreads();
       store_patch();
-      __syncthreads();
-      if (PF) read_a(a, 0);
-    } else {
-      __syncthreads();
-      if (PF) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-          for (int m = 0; m < TM; ++m) a[pl][m] = an[pl][m];
-      }
     }
+    __syncthreads();
     t = t1;
     chunk = chunk1;
   }
@@ -908,6 +892,203 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
     for (int m = 0; m < TM; ++m) {
       float* o = p.out + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
       if (p.accumulate) {        // uniform: all 16 reads in flight before the first add
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv + old[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv;
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Patch-staged fp32 kernel: the layout idea of conv_patch_split_kernel on the fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32).  Stride-1 3x3 convolution (forward / data gradient) over an
+// image that tiles as TH x 32 pixels.  Per 32-channel chunk the (TH+2) x 34 input patch is
+// staged ONCE and serves all nine taps (the gather-GEMM re-stages its A tile per tap: 9x the
+// global loads and LDS writes); only the [BN][32] weight panel is re-staged per tap, double
+// buffered.  One K step = one tap = 16 k-pairs x TM x TN MFMAs per wave between barriers.
+// LDS: patch (TH+2)*34 x 144 B + weights 2 x BN x 144 B (66 KB at TH 4 / BN 128: two
+// workgroups per CU).
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN, int TH>
+__global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParams p) {
+  constexpr int BK = 32, LDA = BK + 4;
+  constexpr int TW = 32, PW = TW + 2;
+  constexpr int PPIX = (TH + 2) * PW;
+  constexpr int P_SLOTS = PPIX * 8;          // f32x4 slots: 32 channels per pixel
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = BN * LDA;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                          // [pixel][LDA]
+  float* Bs = smem + PPIX * LDA;             // [buf][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+
+  const int H = p.Hin, W = p.Win;
+  const int tiles_n = p.Ncols / BN, tiles_x = W / TW, tiles_y = H / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int Ktot = p.C0 + p.C1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  // patch slots (slots past P_SLOTS alias an earlier slot: same bytes to the same place)
+  int pp_lin[P_PASSES], pp_lds[P_PASSES];
+  unsigned pp_oob[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = (tid + 256 * i) % P_SLOTS;
+    const int pix = slot >> 3, seg = slot & 7;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    pp_lin[i] = ok ? ((n * H + iy) * W + ix) * 4 : 0;   // x channel count = byte offset
+    pp_oob[i] = (ok ? 0u : 0x80000000u) | (unsigned)(seg * 16);
+    pp_lds[i] = pix * LDA + seg * 4;
+  }
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int row = slot >> 3, seg = slot & 7;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
+    wslot_lds[j] = row * LDA + seg * 4;
+  }
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 pr[P_PASSES], rb[B_PASSES];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+
+  auto load_patch = [&](int chunk) {
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const unsigned cbytes = (unsigned)(first ? c : c - p.C0) * 4u;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const unsigned off = ((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i];
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) *reinterpret_cast<f32x4*>(Ps + pp_lds[i]) = pr[i];
+  };
+  auto load_b = [&](int t, int chunk) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const int wt = (int)(((tw >> ((t & 3) * 8)) & 0xffu) >> 4);
+    const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsw, wslot_off[j] + woff, 0, 0));
+  };
+  auto store_b = [&](int buf) {
+    float* Bb = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[j];
+  };
+
+  const int chunks = Ktot / BK;
+  const int steps = chunks * 9;
+  load_patch(0);
+  load_b(0, 0);
+  store_patch();
+  store_b(0);
+  __syncthreads();
+
+  // fragment addresses: lane (li, lh) reads 4 consecutive k of its row at k offset 4*lh;
+  // MFMA r of a k-group of 8 multiplies k = 8*kk + 4*lh + r on both operands
+  const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 4 * lh;
+  const int b_lane = (wn0 + li) * LDA + 4 * lh;
+  int t = 0, chunk = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    const int t1 = (t == 8) ? 0 : t + 1;
+    const int chunk1 = (t == 8) ? chunk + 1 : chunk;
+    const bool more = s + 1 < steps;
+    load_b(more ? t1 : t, more ? chunk1 : chunk);
+    if (t == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const float* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
+    const float* Bb = Bs + buf * B_TILE + b_lane;
+    f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * PW * LDA);
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) b[0][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 8) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+          a[nxt][m] = *reinterpret_cast<const f32x4*>(Ab + m * PW * LDA + (kk + 1) * 8);
+#pragma unroll
+        for (int nb = 0; nb < TN; ++nb)
+          b[nxt][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA + (kk + 1) * 8);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][nb][r],
+                                                              acc[m][nb], 0, 0, 0);
+    }
+    store_b(buf ^ 1);
+    if (t == 8) {            // every wave is done with this chunk's patch
+      __syncthreads();
+      store_patch();
+    }
+    __syncthreads();
+    t = t1;
+    chunk = chunk1;
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      float* o = p.out + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
+      if (p.accumulate) {
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
@@ -1411,12 +1592,12 @@ int launch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-template <int BN, int WM, int WN, int TH, bool PF>
-int launch_patch_split_pf(const IgemmParams& p, hipStream_t stream) {
+template <int BN, int WM, int WN, int TH>
+int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds =
       (3 * (size_t)((TH + 2) * 34) * 24 + 2 * 3 * (size_t)BN * 24) * sizeof(__bf16);
   static bool attr_set = false;
-  auto kern = conv_patch_split_kernel<BN, WM, WN, TH, PF>;
+  auto kern = conv_patch_split_kernel<BN, WM, WN, TH>;
   if (!attr_set) {
     UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1426,13 +1607,6 @@ int launch_patch_split_pf(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_patch_split");
   return UNET_OK;
-}
-
-template <int BN, int WM, int WN, int TH>
-int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
-  static const int pf = getenv("UNET_PATCH_PF") ? atoi(getenv("UNET_PATCH_PF")) : 0;
-  return pf ? launch_patch_split_pf<BN, WM, WN, TH, true>(p, stream)
-            : launch_patch_split_pf<BN, WM, WN, TH, false>(p, stream);
 }
 
 // stride-1 3x3 over an image that tiles as 4 x 32 pixels
@@ -1453,14 +1627,10 @@ int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   if (p.Wl < 32 && p.sout == 1) return dispatch_igemm(p, stream);
   if (patch_applicable(p)) {
     const long long mt = M / 128;
-    static const int cfg = getenv("UNET_PATCH_CFG") ? atoi(getenv("UNET_PATCH_CFG")) : 0;
-    if (cfg == 1 && nc % 64 == 0) return launch_patch_split<64, 64, 32, 4>(p, stream);
-    if (cfg == 2 && nc % 64 == 0 && p.Hin % 8 == 0) return launch_patch_split<64, 128, 32, 8>(p, stream);
     if (nc % 128 == 0 && mt * (nc / 128) >= 512)
       return launch_patch_split<128, 64, 64, 4>(p, stream);
     // narrow outputs: taller tiles (two or four patch rows per wave) cut the LDS reads per MFMA
-    static const int th4 = getenv("UNET_PATCH_TH4") ? 1 : 0;
-    const bool tall = !th4 && p.Hin % 8 == 0;
+    const bool tall = p.Hin % 8 == 0;
     if (nc % 64 == 0) {
       if (tall && (M / 256) * (nc / 64) >= 512) return launch_patch_split<64, 128, 32, 8>(p, stream);
       return launch_patch_split<64, 64, 32, 4>(p, stream);
@@ -1476,9 +1646,41 @@ int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   return launch_igemm_split<128, 32, 32, 32>(p, stream);
 }
 
+template <int BN, int WM, int WN, int TH>
+int launch_patch_f32(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((TH + 2) * 34) * 36 + 2 * (size_t)BN * 36) * sizeof(float);
+  static bool attr_set = false;
+  auto kern = conv_patch_f32_kernel<BN, WM, WN, TH>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_f32");
+  return UNET_OK;
+}
+
+bool patch_f32_applicable(const IgemmParams& p) {
+  static const int off = getenv("UNET_NO_PATCH") ? 1 : 0;
+  return !off && p.ntaps == 9 && p.sin == 1 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
+         p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 && p.Win % 32 == 0 &&
+         p.C0 % 32 == 0 && p.C1 % 32 == 0;
+}
+
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
+  if (patch_f32_applicable(p)) {
+    // measured on the net's layers: +5..19 % over the gather-GEMM at 64 and 128 columns, +8 % at
+    // 32 columns when K > 32 (K = 32 stays on the row-fused kernel, which is tried first)
+    const long long mt = M / 128;
+    if (nc % 128 == 0 && mt * (nc / 128) >= 512) return launch_patch_f32<128, 64, 64, 4>(p, stream);
+    if (nc % 64 == 0 && mt * (nc / 64) >= 512) return launch_patch_f32<64, 64, 32, 4>(p, stream);
+    if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 512)
+      return launch_patch_f32<32, 64, 32, 8>(p, stream);
+  }
   // Largest tile that still yields >= 256 workgroups (one per CU); otherwise the
   // small 64x64 tile.
   static const int bk16 = getenv("UNET_IGEMM_BK16") ? 1 : 0;
@@ -1614,7 +1816,9 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
   fill_fwd_taps(p, stride);
   if (prec == 1) return dispatch_igemm_bf16(p, stream);
   if (prec == 3) return dispatch_igemm_split(p, stream);
-  if (stride == 1 && rf_applicable(p))
+  // K = 32: row-fused kernel with the weights resident in LDS; wider K: the patch kernel
+  if (stride == 1 && rf_applicable(p) &&
+      (C0 + C1 == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
     return (C0 + C1 == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 0, stream)
                            : launch_igemm_rf<128, 32, 32, 32, false>(p, 0, stream);
   return dispatch_igemm(p, stream);
@@ -1684,7 +1888,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
     if (prec == 1) return dispatch_igemm_bf16(p, stream);
     if (prec == 3) return dispatch_igemm_split(p, stream);
-    if (rf_applicable(p))
+    if (rf_applicable(p) && (Cout == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
       return (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream)
                           : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream);
     return dispatch_igemm(p, stream);
