@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // NPL = 3 is the split-bf16 ("bf16x3") form: every operand is staged as three bf16 planes
 // (common.h split3) and each tap accumulates the six products of weight >= 2^-16, which
 // reproduces the fp32 product to one fp32 rounding (see conv_igemm_split_kernel).
-template <int CI_T, int CO_T, int S, int NPL>
+// SB = single LDS stage (two barriers per segment) where the double-buffered planes would leave
+// one workgroup per CU (32x32 tile, 64-pixel segments, three planes: 50 KB instead of 100 KB).
+template <int CI_T, int CO_T, int S, int NPL, bool SB = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradParams p) {
   constexpr int STRIDE = 1;
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
     store_stage(0);
     __syncthreads();
     for (int g = g_begin; g < g_end; ++g) {
-      const int buf = (g - g_begin) & 1;
+      const int buf = SB ? 0 : (g - g_begin) & 1;
       // always stage (the last iteration re-stages the final segment into the idle buffer):
       // branch-free, so the compute part of a stage is one scheduling region
       load_stage(min(g + 1, g_end - 1));
@@ -390,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
             }
           }
       }
-      store_stage(buf ^ 1);
+      if (SB) __syncthreads();   // every wave has read the only stage
+      store_stage(SB ? 0 : buf ^ 1);
       __syncthreads();
     }
   }
@@ -637,12 +640,12 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-template <int CI_T, int CO_T, int S, int NPL = 1>
+template <int CI_T, int CO_T, int S, int NPL = 1, bool SB = false>
 int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = S + 2;
-  constexpr size_t lds = 2 * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  constexpr size_t lds = (SB ? 1 : 2) * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
   static bool attr_set = false;
-  auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, NPL>;
+  auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, NPL, SB>;
   if (!attr_set) {
     UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -743,9 +746,9 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int rc;
     // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
     const bool use_bf16 = prec != 0 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
-    // bf16x3: the 32x32 tile's three planes only fit once per CU and lose to the fp32 kernel
-    if (use_bf16 && prec == 3 && !(pl.ci_t == 32 && pl.co_t == 32)) {
-      if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
+    if (use_bf16 && prec == 3) {
+      if (pl.ci_t == 32 && pl.co_t == 32) rc = launch_wgrad_bf16<32, 32, 64, 3, true>(p, stream);
+      else if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
       else rc = launch_wgrad_bf16<64, 64, 16, 3>(p, stream);
     } else if (use_bf16 && prec == 1) {
       if (pl.ci_t == 32 && pl.co_t == 32) rc = launch_wgrad_bf16<32, 32, 64>(p, stream);
