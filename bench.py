@@ -36,7 +36,7 @@ def hbm_traffic(args):
         return json.load(f)["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(steps=3, hw=512, n=2):
+def cpu_baseline(steps=8, hw=512, n=2):
     """The oracle's train step (stock torch CPU ops, verified equal to the reference) timed on
     this box's host cores: the reported CPU baseline, never the thing shipped."""
     from oracle import unet_ref as O
@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--loss-sync", choices=["local", "global"], default="local",
                     help="N>1: per-shard loss + averaged gradients (default) or the loss of the "
                          "concatenated batch + summed gradients")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the second timed loop that reports the bf16x3 operand mode beside "
+                         "the fp32 headline (same model, same K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -167,6 +170,33 @@ def main():
     if not (final_loss == final_loss):
         raise SystemExit("loss is NaN")
 
+    # Beside the fp32-matrix-core headline: the same K steps with the convolutions in the
+    # split-bf16 ("bf16x3") operand mode, which holds the same reference fixtures and tolerances
+    # (tests/test_net_gpu.py, profiles/r01_bf16x3_accuracy_vs_fp64.txt).  Reported, never `value`.
+    alt = None
+    if args.matmul == "fp32" and not args.no_alt:
+        model.matmul_precision = "bf16x3"
+        for _ in range(max(2, args.warmup // 2)):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        dt_alt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_alt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_alt = t.item()
+        alt = {"bf16x3": {
+            "value": args.batch * world * args.steps / dt_alt, "unit": "images/s",
+            "ms_per_step": 1e3 * dt_alt / args.steps,
+            "dtype": "f32 tensors; conv operands split into 3 bf16 terms, 6 bf16 MFMA products "
+                     "per multiply, f32 accumulate",
+            "parity": "same fixtures and tolerances as fp32 (1e-4 logits, bit-exact argmax off "
+                      "ties); per-conv error vs fp64 <= the fp32 MFMA kernels'"}}
+        model.matmul_precision = args.matmul
+
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
@@ -200,8 +230,9 @@ def main():
                 result["roofline"] = {
                     "bound": "mfma", "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": hbm_traffic(args),
-                    "kernel": "conv_igemm_kernel (3x3 conv forward + data gradient, all tile "
-                              "instantiations)",
+                    "kernel": "3x3 conv forward + data gradient group: conv_patch_f32_kernel, "
+                              "conv_igemm_kernel, conv_igemm_rf_kernel, conv_dgrad_s2_kernel "
+                              "(1.366 TFLOP of the step's 2.049)",
                     "launches_per_step": k["launches"] / args.steps,
                     "avg_launch_us": 1e3 * k["ms"] / k["launches"],
                     "flop_per_step": k["flops"] / args.steps,
@@ -210,6 +241,8 @@ def main():
                 t: {"tflops": v["flops"] / (v["ms"] * 1e-3) * 1e-12, "ms_per_step": v["ms"] / args.steps,
                     "launches_per_step": v["launches"] / args.steps}
                 for t, v in summ.items()}
+        if alt is not None:
+            result["alt_modes"] = alt
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
