@@ -106,3 +106,30 @@ def test_single_process_is_a_noop():
         assert torch.all(m.garena == 3.0)
     finally:
         dist.destroy_process_group()
+
+
+def test_frozen_prefix_is_left_out_of_the_exchange():
+    """A frozen encoder prefix (requires_grad=False) is not all-reduced: finish() starts at the
+    first trainable parameter's arena offset."""
+    from unet_implementations_amd import ddp
+
+    class _P:
+        def __init__(self, rg):
+            self.requires_grad = rg
+
+    class _M(_Arena):
+        def __init__(self):
+            super().__init__(100)
+            self._offsets = [0, 40, 70]
+            self._params = [_P(False), _P(False), _P(True)]
+
+        def parameters(self):
+            return iter(self._params)
+
+    sync = ddp.GradBucketAllReduce.__new__(ddp.GradBucketAllReduce)
+    sync.model = _M()
+    assert sync._frozen_prefix() == 70
+    sync.model._params[0].requires_grad = True
+    assert sync._frozen_prefix() == 0
+    sync.model = _Arena(10)          # no parameter table: whole arena
+    assert sync._frozen_prefix() == 0

@@ -56,12 +56,24 @@ class GradBucketAllReduce:
         self._works.append(dist.all_reduce(garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                            async_op=True))
 
+    def _frozen_prefix(self):
+        """Arena offset of the first trainable parameter: a frozen encoder prefix (AE transfer,
+        Our_UNet/src/train.py:800-859) produces no gradient and is left out of the exchange."""
+        self.model.flat_parameters()
+        offsets = getattr(self.model, "_offsets", None)
+        if offsets is None or not hasattr(self.model, "parameters"):
+            return 0
+        for p, off in zip(self.model.parameters(), offsets):
+            if p.requires_grad:
+                return off
+        return 0
+
     def finish(self):
         """Call between backward and optimizer.step(): flushes the tail bucket and makes the
         current stream wait for every outstanding all-reduce."""
         if self._hi is not None and self._hi > 0 and self.world > 1:
             _, garena = self.model.flat_parameters()
-            self._launch(garena, 0, self._hi)
+            self._launch(garena, self._frozen_prefix(), self._hi)
         for w in self._works:
             w.wait()
         self._works = []
