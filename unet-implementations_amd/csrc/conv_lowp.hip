@@ -1,0 +1,483 @@
+// conv_lowp.hip — the gather-GEMM of conv_igemm.hip on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation): bf16 mixed precision (BASELINE config 4) and the
+// split-bf16 form used where the patch-staged kernel does not apply (stride-2 forward, per-class
+// stride-2 data gradient).
+#include "conv_params.h"
+#include <stdlib.h>
+
+namespace unet_conv {
+namespace {
+
+// ---------------------------------------------------------------------------
+// bf16 mixed-precision variant (BASELINE config 4 / SURVEY a15): tensors stay fp32 in HBM,
+// the loader rounds both operands to bf16 (v_cvt_pk_bf16_f32) while staging them into LDS
+// and the contraction runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the fp32
+// matrix rate, so the kernel turns load/L2-bound).  Same gather-GEMM, tap table, tiles and
+// epilogue as conv_igemm_kernel; LDS rows hold 32 bf16 + 8 pad (80 B: conflict-free b128).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmParams p) {
+  constexpr int BK = 32;
+  constexpr int LDA = BK + 8;  // bf16 elements per LDS row
+  constexpr int SEGS = BK / 4;         // 16-B segments per tile row
+  constexpr int ROWS = 256 / SEGS;     // tile rows covered by one loader pass
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  constexpr int A_PASSES = BM / ROWS;
+  constexpr int B_PASSES = BN / ROWS;
+  constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* As = smem_h;
+  __bf16* Bs = smem_h + 2 * A_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+  const int tiles_n = p.Ncols / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int HlWl = p.Hl * p.Wl;
+  const int M = p.N * HlWl;
+  const int Ktot = p.C0 + p.C1;
+
+  // ---- loaders: thread -> (row lrow + 32*i, 16-B segment lseg) for both tiles ----
+  const int lrow = tid / SEGS, lseg = tid % SEGS;
+  int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + lrow + ROWS * i;
+    if (m < M) {
+      const int n = m / HlWl;
+      const int r = m - n * HlWl;
+      const int a = r / p.Wl;
+      const int b = r - a * p.Wl;
+      a_nb[i] = n * p.Hin * p.Win;
+      a_iy[i] = a * p.sin;
+      a_ix[i] = b * p.sin;
+    } else {
+      a_nb[i] = 0;
+      a_iy[i] = -(1 << 24);
+      a_ix[i] = 0;
+    }
+  }
+  // Buffer descriptors: out-of-range lanes (zero padding, rows past M) get an offset beyond
+  // num_records and read 0 with no branch, so the K loop is one basic block.
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  // weight rows of this thread: ((n_off + n0 + lrow + 32*j) * Ktot + lseg*4) floats
+  const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[A_PASSES], rb[B_PASSES];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int KS = p.ntaps * (Ktot / BK);
+
+  auto load_tiles = [&](int t, int chunk) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const int wt = (int)(e >> 4);
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      // invalid lanes get bit 31 set: beyond num_records (< 2 GiB), the load returns 0
+      const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
+    }
+    const unsigned woff = wrow_off + (unsigned)(wt * p.tap_stride + c) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (unsigned)(ROWS * j * Ktot) * 4u, 0, 0);
+      rb[j] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto to_bf16 = [](const f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    return h;
+  };
+  auto store_tiles = [&](int buf) {
+    __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
+    __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[i]);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<bf16x4*>(Bb + ROWS * j * LDA) = to_bf16(rb[j]);
+  };
+
+  int t_next = 0, chunk_next = 0;
+  auto advance = [&](bool on) {  // branch-free: keeps the K step a single basic block
+    const int tn = t_next + 1;
+    const bool wrap = tn == p.ntaps;
+    t_next = on ? (wrap ? 0 : tn) : t_next;
+    chunk_next = on ? chunk_next + (wrap ? 1 : 0) : chunk_next;
+  };
+
+  load_tiles(t_next, chunk_next);
+  advance(KS > 1);
+  store_tiles(0);
+  __syncthreads();
+
+  // fragment addresses: lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of row li
+  // (the natural A/B operand map of v_mfma_f32_32x32x16_bf16)
+  const int frag_off = li * LDA + 8 * lh;
+  for (int ks = 0; ks < KS; ++ks) {
+    const int buf = ks & 1;
+    load_tiles(t_next, chunk_next);
+    advance(ks + 2 < KS);
+    const __bf16* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
+    const __bf16* Bb = Bs + buf * B_TILE + wn0 * LDA + frag_off;
+    bf16x8 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const bf16x8*>(Ab + m * 32 * LDA);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) b[0][n] = *reinterpret_cast<const bf16x8*>(Bb + n * 32 * LDA);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 16) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+          a[nxt][m] = *reinterpret_cast<const bf16x8*>(Ab + m * 32 * LDA + (kk + 1) * 16);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          b[nxt][n] = *reinterpret_cast<const bf16x8*>(Bb + n * 32 * LDA + (kk + 1) * 16);
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m], b[cur][n], acc[m][n], 0, 0, 0);
+    }
+    store_tiles(buf ^ 1);
+    // buffer loads first (they are the critical path here), fragment reads ahead of the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D row = (reg&3) + 8*(reg>>2) + 4*lh, column = li ----
+  const bool direct = (p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout);
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    const int col = n0 + wn0 + n * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      float* o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int mg = m0 + row;
+        size_t opix = (size_t)mg;
+        if (!direct) {
+          const int nn = mg / HlWl;
+          const int rr = mg - nn * HlWl;
+          const int a = rr / p.Wl;
+          const int b = rr - a * p.Wl;
+          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
+        }
+        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
+      }
+      store_block16(o, acc[m][n], bv, p.accumulate);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant: fp32-class accuracy on the bf16 matrix cores.
+// Every fp32 operand x is split while it is staged into LDS into three bf16 terms
+//   x = h + m + l,  h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (|x - h - m - l| <= 2^-26 |x|)
+// and a product a*b is evaluated as the six terms of weight >= 2^-16
+//   a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_m b_m + a_l b_h
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (each bf16 x bf16 product is exact in
+// fp32); the three dropped terms are below 2^-24 |a b|, the size of one fp32 rounding.
+// Six MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32x32x16 block.
+// Same gather-GEMM, tap table, tiles and epilogue as conv_igemm_kernel; BK = 16 so that the
+// three planes of both double-buffered tiles fit twice per CU; the global loads run two K
+// steps ahead of the MFMAs (registers), the split one step ahead (LDS).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const IgemmParams p) {
+  constexpr int BK = 16;
+  constexpr int LDA = BK + 8;          // bf16 elements per LDS row (48 B: conflict-free b128)
+  constexpr int SEGS = BK / 4;         // 16-B fp32 segments per tile row
+  constexpr int ROWS = 256 / SEGS;     // 64 tile rows per loader pass
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  static_assert(BM % ROWS == 0, "BM must be a multiple of 64");
+  constexpr int A_PASSES = BM / ROWS;
+  // weights arrive pre-split (three bf16 planes): slot = (plane, row, 8-element half row)
+  constexpr int B_SLOTS = BN * 6;
+  constexpr int B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* As = smem_h;                    // [buf][plane][BM][LDA]
+  __bf16* Bs = smem_h + 2 * 3 * A_TILE;   // [buf][plane][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+  const int tiles_n = p.Ncols / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int HlWl = p.Hl * p.Wl;
+  const int M = p.N * HlWl;
+  const int Ktot = p.C0 + p.C1;
+
+  const int lrow = tid / SEGS, lseg = tid % SEGS;
+  int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + lrow + ROWS * i;
+    if (m < M) {
+      const int n = m / HlWl;
+      const int r = m - n * HlWl;
+      const int a = r / p.Wl;
+      const int b = r - a * p.Wl;
+      a_nb[i] = n * p.Hin * p.Win;
+      a_iy[i] = a * p.sin;
+      a_ix[i] = b * p.sin;
+    } else {
+      a_nb[i] = 0;
+      a_iy[i] = -(1 << 24);
+      a_ix[i] = 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(p.w3), 0, (int)p.w3_bytes, 0x00020000);
+  // weight slots of this thread (slots past B_SLOTS alias an earlier slot: same bytes, same
+  // destination, so the duplicate store is harmless and the loop needs no predicate)
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int pl = slot / (2 * BN), rem = slot - pl * 2 * BN;
+    const int row = rem >> 1, half = rem & 1;
+    wslot_off[j] = (unsigned)(pl * p.w3_plane + (p.n_off + n0 + row) * Ktot + 8 * half) * 2u;
+    wslot_lds[j] = pl * B_TILE + row * LDA + 8 * half;
+  }
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[A_PASSES];                    // tile ks+1 (loaded one step ago)
+  f32x4 na[A_PASSES];                    // tile ks+2 (in flight)
+  i32x4 rb[B_PASSES], nb[B_PASSES];      // weight planes: raw bf16 bits
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int KS = p.ntaps * (Ktot / BK);
+
+  auto load_tiles = [&](int t, int chunk, f32x4* qa, i32x4* qb) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const int wt = (int)(e >> 4);
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
+      const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
+                           (ok ? 0u : 0x80000000u);
+      qa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    const unsigned woff = (unsigned)(wt * p.tap_stride + c) * 2u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      qb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wslot_off[j] + woff, 0, 0);
+  };
+  auto store_tiles = [&](int buf) {
+    __bf16* Ab = As + buf * 3 * A_TILE + lrow * LDA + lseg * 4;
+    __bf16* Bb = Bs + buf * 3 * B_TILE;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      bf16x4 h, m, l;
+      split3(ra[i], h, m, l);
+      *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = h;
+      *reinterpret_cast<bf16x4*>(Ab + A_TILE + ROWS * i * LDA) = m;
+      *reinterpret_cast<bf16x4*>(Ab + 2 * A_TILE + ROWS * i * LDA) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<i32x4*>(Bb + wslot_lds[j]) = rb[j];
+  };
+
+  int t_next = 0, chunk_next = 0, issued = 0;
+  auto advance = [&]() {  // branch-free; past the end it keeps re-staging the last tile
+    const bool on = issued + 1 < KS;
+    const int tn2 = t_next + 1;
+    const bool wrap = tn2 == p.ntaps;
+    t_next = on ? (wrap ? 0 : tn2) : t_next;
+    chunk_next = on ? chunk_next + (wrap ? 1 : 0) : chunk_next;
+    issued += on ? 1 : 0;
+  };
+
+  load_tiles(t_next, chunk_next, ra, rb);
+  advance();
+  store_tiles(0);
+  load_tiles(t_next, chunk_next, ra, rb);
+  advance();
+  __syncthreads();
+
+  const int frag_off = li * LDA + 8 * lh;
+  for (int ks = 0; ks < KS; ++ks) {
+    const int buf = ks & 1;
+    load_tiles(t_next, chunk_next, na, nb);
+    advance();
+    const __bf16* Ab = As + buf * 3 * A_TILE + wm0 * LDA + frag_off;
+    const __bf16* Bb = Bs + buf * 3 * B_TILE + wn0 * LDA + frag_off;
+    bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        a[pl][m] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_TILE + m * 32 * LDA);
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+        b[pl][n] = *reinterpret_cast<const bf16x8*>(Bb + pl * B_TILE + n * 32 * LDA);
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        f32x16 c = acc[m][n];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][m], b[0][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[1][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[2][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[0][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[1][n], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[0][n], c, 0, 0, 0);
+        acc[m][n] = c;
+      }
+    store_tiles(buf ^ 1);
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) ra[i] = na[i];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) rb[j] = nb[j];
+    __syncthreads();
+  }
+
+  const bool direct = (p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout);
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+    const int col = n0 + wn0 + n * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      float* o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int mg = m0 + row;
+        size_t opix = (size_t)mg;
+        if (!direct) {
+          const int nn = mg / HlWl;
+          const int rr = mg - nn * HlWl;
+          const int a = rr / p.Wl;
+          const int b = rr - a * p.Wl;
+          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
+        }
+        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
+      }
+      store_block16(o, acc[m][n], bv, p.accumulate);
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 40 * sizeof(__bf16);
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles), dim3(256), lds,
+                     stream, p);
+  UNET_CHECK_LAUNCH("conv_igemm_bf16");
+  return UNET_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_split(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * 3 * (size_t)(BM + BN) * 24 * sizeof(__bf16);
+  static bool attr_set = false;
+  auto kern = conv_igemm_split_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_igemm_split");
+  return UNET_OK;
+}
+
+}  // namespace
+
+int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+    return launch_igemm_bf16<128, 128, 64, 64>(p, stream);
+  if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+    return launch_igemm_bf16<128, 64, 64, 32>(p, stream);
+  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_bf16<64, 64, 32, 32>(p, stream);
+  return launch_igemm_bf16<128, 32, 32, 32>(p, stream);
+}
+
+int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  // images narrower than one 32-pixel patch row (the 1/32-resolution stage): too few tiles for
+  // the split kernels to win, the fp32 matrix-core kernel is faster there
+  if (p.Wl < 32 && p.sout == 1) return dispatch_igemm(p, stream);
+  if (patch_split_applicable(p)) return launch_patch_split_auto(p, stream);
+  if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+    return launch_igemm_split<128, 128, 64, 64>(p, stream);
+  if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+    return launch_igemm_split<128, 64, 64, 32>(p, stream);
+  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_split<64, 64, 32, 32>(p, stream);
+  return launch_igemm_split<128, 32, 32, 32>(p, stream);
+}
+
+}  // namespace unet_conv
