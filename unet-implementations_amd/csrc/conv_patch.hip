@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
   for (int j = 0; j < B_PASSES; ++j) {
     const int slot = (tid + 256 * j) % B_SLOTS;
     const int pl = slot / (2 * BN), rem = slot - pl * 2 * BN;
-    const int row = rem >> 1, half = rem & 1;
+    // 16 consecutive lanes = 8 rows x 2 halves, row fastest: the 8 lanes of one ds_write_b128
+    // group hit 8 different rows (conflict-free at the 48-B row stride) and lanes k, k+8
+    // read the two halves of one 32-B global segment
+    const int row = (rem >> 4) * 8 + (rem & 7), half = (rem >> 3) & 1;
     wslot_off[j] = (unsigned)(pl * p.w3_plane + (p.n_off + n0 + row) * Ktot + 8 * half) * 2u;
     wslot_lds[j] = pl * B_TILE + row * LDA + 8 * half;
   }
