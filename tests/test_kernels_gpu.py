@@ -700,3 +700,32 @@ def test_sharded_loss_equals_loss_of_concatenated_batch(ua, dynamic):
         rg = all_lg.grad[n0:n0 + lg.shape[0]]
         assert ((dl.cpu() - rg).abs().max() / rg.abs().max()).item() <= 2e-5
         n0 += lg.shape[0]
+
+
+# ---------------------------------------------------------------- bench-size tiles
+# The widest tile instantiations (128 output columns) are only selected when a launch has
+# >= 512 tiles, i.e. at the bench's batch: check them on one real layer (enc2.4 at bs 8:
+# 128 -> 128 channels, 128 x 128) against a CPU fp32 convolution, forward and data gradient,
+# in the fp32 and the split-bf16 operand modes.
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_conv3x3_bench_size_layer(ua, mode):
+    N, C, H = 8, 128, 128
+    x = rnd(N, C, H, H, seed=21).requires_grad_(True)
+    w = rnd(C, C, 3, 3, seed=22, scale=0.03)
+    b = rnd(C, seed=23)
+    y = F.conv2d(x, w, b, padding=1)
+    gy = rnd(N, C, H, H, seed=24)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    wf, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    kw_f, kw_d = {}, {}
+    if mode == "bf16x3":
+        wf3, wd3 = ua.ops.pack_conv3x3_weights_bf16x3(w.to(DEV))
+        kw_f, kw_d = {"wf3": wf3}, {"wd3": wd3}
+    got = ua.ops.conv3x3_fwd(to_nhwc(x.detach()), None, wf, b.to(DEV), 1, bf16=mode, **kw_f)
+    check(from_nhwc(got), y.detach(), 2e-5, f"{mode} fwd 8x128x128x128")
+    dx = ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, 0, C, H, H, 1, bf16=mode, **kw_d)
+    check(from_nhwc(dx), gx, 2e-5, f"{mode} dgrad 8x128x128x128")
+    acc = torch.ones(N, H, H, C, device=DEV)          # accumulate flag of the same tile shape
+    ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, 0, C, H, H, 1, out=acc, accumulate=True, bf16=mode,
+                            **kw_d)
+    check(from_nhwc(acc), gx + 1.0, 2e-5, f"{mode} dgrad accumulate")
