@@ -15,6 +15,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,6 +35,22 @@ def hbm_traffic(args):
         return None
     with open(path) as f:
         return json.load(f)["hbm_bytes_per_launch"]
+
+
+def synthetic_batch(seed, n, h, w):
+    """The bench workload: images ~ N(0,1) (ImageNet-standardised pixels), int64
+    masks with background 0, one blob of class 1 or 2 per image and a ring of 255 around it."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = torch.from_numpy(rng.standard_normal((n, 3, h, w)).astype(np.float32))
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = np.zeros((n, h, w), dtype=np.int64)
+    for i in range(n):
+        cy, cx = h * (0.4 + 0.2 * rng.random()), w * (0.4 + 0.2 * rng.random())
+        ry, rx = h * (0.22 + 0.1 * rng.random()), w * (0.25 + 0.1 * rng.random())
+        d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+        mask[i][d < 1.0] = 1 + (i % 2)
+        mask[i][(d >= 1.0) & (d < 1.0 + 8.0 / min(ry, rx))] = 255
+    return img, torch.from_numpy(mask)
 
 
 def cpu_baseline(steps=8, hw=512, n=2):
@@ -99,7 +116,6 @@ def main():
 
     import torch.distributed as dist
     import unet_implementations_amd as ua
-    from oracle import unet_ref as O   # synthetic batch generator only (input data, not compute)
     from unet_implementations_amd import ddp
 
     if world > 1:
@@ -124,7 +140,7 @@ def main():
     if world > 1:
         ddp.broadcast_parameters(model)
         sync = ddp.GradBucketAllReduce(model, opt, average=args.loss_sync != "global")
-    img, tgt = O.synthetic_batch(1234 + rank, args.batch, args.hw, args.hw)
+    img, tgt = synthetic_batch(1234 + rank, args.batch, args.hw, args.hw)
     img, tgt = img.to(dev), tgt.to(dev)
     torch.manual_seed(99 + rank)     # dropout stream differs per rank
 
