@@ -6,7 +6,7 @@ functionally over a plain `state_dict`.  Each function cites the reference
 file:line it follows (paths relative to the reference checkout).
 
 Pinned: `tests/test_oracle_golden.py` checks this file against the fixtures in
-`tests/golden/`, which `tools/make_golden.py` generated in the build container by
+`tests/golden/`, which `tests/tools/make_golden.py` generated in the build container by
 importing the reference's own `Our_UNet/models/unet.py` and `losses.py`.
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg use it.
 """

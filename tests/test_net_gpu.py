@@ -263,7 +263,7 @@ def test_bf16_matmul_mode_tracks_fp32(ua):
     test_kernels_gpu.py.  End to end this 23-layer InstanceNorm/LeakyReLU stack amplifies
     operand rounding: fp32 vs fp64 logits already differ by ~1e-5 at eps 6e-8, and bf16
     (eps 2^-9) measured 5 % rms on logits, loss within 0.1 %, gradient cosine 0.95 at
-    256x256 and 512x512 (tools/debug_bf16.py)."""
+    256x256 and 512x512 (tests/tools/debug_bf16.py)."""
     sd0 = O.fill_state_dict(2024)
     img, tgt = O.synthetic_batch(1234, 2, 256, 256)
     masks = O.draw_dropout_masks(77, 2)

@@ -1,5 +1,5 @@
 """CPU (-m "not gpu"): pins the ORACLE (oracle/unet_ref.py) against the fixtures that
-tools/make_golden.py recorded from the reference's own Our_UNet/models/{unet,losses}.py.
+tests/tools/make_golden.py recorded from the reference's own Our_UNet/models/{unet,losses}.py.
 
 The fixtures were produced on the build container's CPU; another host may pick different
 oneDNN kernels, so comparisons allow fp32 summation-order noise (1e-5 relative on forward

@@ -5,11 +5,11 @@ For the whole network (logits and the full gradient vector, oracle in fp64 on th
 and for single convolutions at the bench sizes (fp64 conv on the GPU as truth) this prints the
 error of  (a) the oracle's own fp32 CPU run,  (b) the fp32 matrix-core kernels,  (c) the
 split-bf16 ("bf16x3") kernels.  Output kept under profiles/ as evidence that bf16x3 is an
-fp32-accurate mode.   Usage: python tools/accuracy_vs_fp64.py [hw=64]"""
+fp32-accurate mode.   Usage: python tests/tools/accuracy_vs_fp64.py [hw=64]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 

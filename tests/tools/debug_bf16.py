@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 HW = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 import unet_implementations_amd as ua

@@ -1,6 +1,6 @@
 """Debug helper (GPU): per-parameter gradient error of the HIP net vs the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 torch.set_num_threads(16)
 import unet_implementations_amd as ua

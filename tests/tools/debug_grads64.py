@@ -1,7 +1,7 @@
 """Debug helper (GPU): gradient error of the HIP net and of the fp32 oracle, both measured
 against an fp64 run of the oracle (is the HIP path as accurate as the reference's own fp32?)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 torch.set_num_threads(16)
 import unet_implementations_amd as ua

@@ -1,6 +1,6 @@
 """Debug helper (GPU): multi-step trajectory of the HIP path vs the oracle (fp32 and fp64)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 torch.set_num_threads(16)
 import unet_implementations_amd as ua

@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference).  Imports the reference
 local files `Our_UNet/models/unet.py` and `Our_UNet/models/losses.py` (torch-only),
 loads the deterministic weights of `oracle.unet_ref.fill_state_dict`, and records
 small input/output vectors.  The fixtures are data only; nothing from the
-reference's source travels.  Usage: python tools/make_golden.py [--skip-512]
+reference's source travels.  Usage: python tests/tools/make_golden.py [--skip-512]
 """
 import argparse
 import hashlib
@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/Our_UNet")
 
