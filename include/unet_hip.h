@@ -243,7 +243,8 @@ int unet_dice_wce_loss_shard_apply(const float* logits_nchw, const int64_t* targ
 
 /* preds[N][H][W] (uint8, optional) = argmax over the class planes; counts[9] (uint64, device) =
  * per class {intersection, predicted, labelled} over the batch, ignore_index pixels excluded:
- * the integers behind the Dice scores of validate() (Our_UNet/src/train.py:556-577). */
+ * the integers behind the Dice scores of validate() (Our_UNet/src/train.py:556-577).
+ * target == NULL and counts == NULL: prediction only (the argmax of src/evaluate.py:185-207). */
 int unet_argmax_dice_counts(const float* logits_nchw, const int64_t* target, uint8_t* preds,
                             uint64_t* counts, int N, int H, int W, int ignore_index,
                             unet_stream_t stream);

@@ -610,6 +610,19 @@ def test_argmax_dice_counts_exact(ua, n, h, w):
         assert counts[c].tolist() == [int((pc & mc).sum()), int(pc.sum()), int(mc.sum())]
 
 
+def test_predict_masks_is_argmax_of_eval_forward(ua):
+    from oracle import unet_ref as O
+    model = ua.create_model().train()
+    model.load_state_dict(O.fill_state_dict(9, trained_like=True))
+    img, _ = O.synthetic_batch(3, 2, 64, 64)
+    preds = ua.predict_masks(model, img.cuda())
+    assert model.training and preds.dtype == torch.uint8 and preds.shape == (2, 64, 64)
+    model.eval()
+    with torch.no_grad():
+        ref = model(img.cuda()).argmax(dim=1)
+    assert torch.equal(preds.long(), ref)
+
+
 def test_argmax_dice_counts_absent_class_and_all_ignored(ua):
     logits = torch.zeros(2, 3, 64, 64)
     logits[:, 1] = 1.0

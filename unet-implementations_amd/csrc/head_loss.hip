@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restr
     if (z1 > best) { best = z1; am = 1; }
     if (z2 > best) { best = z2; am = 2; }
     if (preds) preds[(size_t)n * HW + p] = (unsigned char)am;
+    if (!target) continue;           // prediction only (inference)
     const long long t = tg[p];
     if (t != (long long)ignore_index) {
 #pragma unroll
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restr
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 9) {
+  if (target && threadIdx.x < 9) {
     const unsigned int s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
                            red[3][threadIdx.x];
     if (s) atomicAdd(&counts[threadIdx.x], (unsigned long long)s);   // integer: order-independent
@@ -552,10 +553,11 @@ extern "C" int unet_argmax_dice_counts(const float* logits_nchw, const int64_t* 
                                        uint8_t* preds, uint64_t* counts, int N, int H, int W,
                                        int ignore_index, unet_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  UNET_REQUIRE(logits_nchw && target && counts, "argmax_dice_counts: null pointer");
+  UNET_REQUIRE(logits_nchw && ((target && counts) || (!target && preds)),
+               "argmax_dice_counts: needs target + counts, or preds alone");
   UNET_REQUIRE(N > 0 && H > 0 && W > 0, "argmax_dice_counts: bad shape");
   const int HW = H * W;
-  UNET_HIP_CALL(hipMemsetAsync(counts, 0, 9 * sizeof(uint64_t), stream));
+  if (counts) UNET_HIP_CALL(hipMemsetAsync(counts, 0, 9 * sizeof(uint64_t), stream));
   int blocks = ceil_div(HW, 256 * 4);
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(argmax_counts_kernel, dim3(blocks, N), dim3(256), 0, stream, logits_nchw,

@@ -372,6 +372,18 @@ def argmax_dice_counts(logits, target, ignore_index=255, want_preds=True):
     return preds, counts
 
 
+def argmax_classes(logits):
+    """uint8 [N,H,W] class map of fp32 logits [N,3,H,W] (first maximum wins, like torch.argmax)."""
+    N, K, H, W = logits.shape
+    if K != 3 or logits.dtype != torch.float32:
+        raise TypeError("argmax_classes takes fp32 logits with 3 classes")
+    logits = logits.contiguous()
+    preds = torch.empty((N, H, W), dtype=torch.uint8, device=logits.device)
+    check(lib().unet_argmax_dice_counts(_ptr(logits), None, _ptr(preds), None, N, H, W, 255,
+                                        _stream()))
+    return preds
+
+
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 

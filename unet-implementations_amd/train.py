@@ -87,6 +87,18 @@ def validate(model, val_loader, loss_function, device, ignore_label=255):
     return (val_loss / n).item(), scores
 
 
+@torch.no_grad()
+def predict_masks(model, images):
+    """Inference as in Our_UNet/src/evaluate.py:185-207: eval-mode forward and per-pixel argmax,
+    returned as a uint8 class map on the device (the reference resizes on the CPU afterwards)."""
+    was_training = model.training
+    model.eval()
+    try:
+        return ops.argmax_classes(model(images))
+    finally:
+        model.train(was_training)
+
+
 def save_checkpoint(model, optimizer, scheduler, epoch, best_dice, output_dir, is_best=False):
     """Same files and dictionary keys as Our_UNet/src/train.py:683-739 (the reference's embedded
     `config` block describes an 8-stage net that is not the model it saves; here it records the
