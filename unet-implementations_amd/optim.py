@@ -79,13 +79,11 @@ class FusedSGD(torch.optim.Optimizer):
                     first = "momentum_buffer" not in st or st["momentum_buffer"] is None
                     if first:
                         st["momentum_buffer"] = torch.zeros_like(p)
-                    n4 = p.numel()
                     if p.data_ptr() % 16 or p.grad.data_ptr() % 16 or not p.is_contiguous() \
                             or not p.grad.is_contiguous():
                         raise RuntimeError("FusedSGD needs contiguous, 16-byte aligned tensors")
                     ops.sgd_nesterov_step(p.data.view(-1), p.grad.view(-1),
                                           st["momentum_buffer"].view(-1), g["lr"], g["momentum"],
                                           g["weight_decay"], first, self.grad_scale)
-                    del n4
         self._steps += 1
         return loss
