@@ -122,6 +122,23 @@ int unet_conv3x3_bwd_weight_bf16(const float* x, int Cx, const float* dy, float*
  * path, which is why the fp32 wf / wd are still passed. */
 int unet_pack_conv3x3_weights_bf16x3(const float* w_oihw, uint16_t* wf3, uint16_t* wd3, int Cout,
                                      int Cin, unet_stream_t stream);
+
+/* Every layer's packing in ONE launch (the per-layer form costs 22 small launches per step).
+ * `table_device` is an array of n entries in DEVICE memory, built once by the caller; all
+ * pointers are device pointers, any destination may be NULL; Cout must be a multiple of 32.
+ * A workgroup packs one 32 (co) x 32 (ci) x 9 tile: entry k owns the tiles
+ * [tile_begin, tile_begin + (Cout/32) * ceil(Cin/32)), total_tiles = their sum.  Layouts as above. */
+typedef struct unet_pack_entry {
+  const float* w;   /* OIHW source [Cout][Cin][3][3] */
+  float* wf;        /* [9][Cout][Cin] */
+  float* wd;        /* [9][Cin][Cout] */
+  uint16_t* wf3;    /* [3][9][Cout][Cin] bf16 planes */
+  uint16_t* wd3;    /* [3][9][Cin][Cout] bf16 planes */
+  int Cout, Cin;
+  int tile_begin, reserved;
+} unet_pack_entry;
+int unet_pack_conv3x3_weights_batched(const unet_pack_entry* table_device, int n, int total_tiles,
+                                      unet_stream_t stream);
 int unet_conv3x3_fwd_bf16x3(const float* x0, int C0, const float* x1, int C1, const float* wf,
                             const uint16_t* wf3, const float* bias, float* y, int N, int H, int W,
                             int Cout, int stride, unet_stream_t stream);

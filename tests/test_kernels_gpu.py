@@ -53,6 +53,23 @@ def test_pack_weights(ua):
     assert torch.equal(wd.cpu(), w.permute(2, 3, 1, 0).reshape(9, 32, 64))   # [tap][ci][co]
 
 
+def test_pack_weights_batched_matches_per_layer(ua):
+    ws = [rnd(32, 3, 3, 3, seed=1).to(DEV), rnd(64, 32, 3, 3, seed=2).to(DEV),
+          rnd(128, 96, 3, 3, seed=3).to(DEV), rnd(32, 64, 3, 3, seed=4).to(DEV)]
+    for planes in (False, True):
+        tab = ua.ops.PackTable(ws, planes)
+        tab.run()
+        for i, w in enumerate(ws):
+            wf, wd = ua.ops.pack_conv3x3_weights(w)
+            assert torch.equal(tab.wf[i], wf) and torch.equal(tab.wd[i], wd)
+            if planes and w.shape[1] != 3:
+                wf3, wd3 = ua.ops.pack_conv3x3_weights_bf16x3(w)
+                assert torch.equal(tab.wf3[i], wf3) and torch.equal(tab.wd3[i], wd3)
+            else:
+                assert tab.wf3[i] is None
+        assert tab.matches(ws, planes) and not tab.matches(ws[:2], planes)
+
+
 # --------------------------------------------------------------------------- conv forward
 CONV_SHAPES = [
     # N, H, W, C0, C1, Cout, stride

@@ -41,6 +41,7 @@ SIGNATURES = {
     "unet_conv3x3_bwd_weight_bf16": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i,
                                           _p]),
     "unet_pack_conv3x3_weights_bf16x3": (_i, [_p, _p, _p, _i, _i, _p]),
+    "unet_pack_conv3x3_weights_batched": (_i, [_p, _i, _i, _p]),
     "unet_conv3x3_fwd_bf16x3": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_data_bf16x3": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_weight_bf16x3": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _sz, _i, _i, _i, _i, _i,

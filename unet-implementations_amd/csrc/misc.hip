@@ -145,6 +145,52 @@ __global__ void pack_w_split_kernel(const float* __restrict__ w, __bf16* __restr
   }
 }
 
+// All layers in one launch.  A workgroup moves one [32 co][32 ci][9 taps] tile through LDS:
+// the OIHW source is read as 32 runs of 288 contiguous floats, both packed layouts (and, on
+// request, their three bf16 planes) are written in 128-byte segments.  `tile_begin` of the
+// device table maps blockIdx.x to (layer, tile).
+__global__ __launch_bounds__(256) void pack_w_batched_kernel(const unet_pack_entry* __restrict__ tab,
+                                                             int n) {
+  __shared__ float tile[32][289];   // [co][ci*9 + t]; 289 = 1 mod 32: conflict-free both ways
+  int k = 0;
+  for (int q = 1; q < n; ++q)
+    if (tab[q].tile_begin <= (int)blockIdx.x) k = q;
+  const unet_pack_entry e = tab[k];
+  const int id = blockIdx.x - e.tile_begin;
+  const int tiles_ci = (e.Cin + 31) / 32;
+  const int co0 = (id / tiles_ci) * 32, ci0 = (id % tiles_ci) * 32;
+  const int nci = min(32, e.Cin - ci0), run = nci * 9;
+  const long long total = (long long)9 * e.Cin * e.Cout;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int co = idx / run, jj = idx - co * run;
+    tile[co][jj] = e.w[((size_t)(co0 + co) * e.Cin + ci0) * 9 + jj];
+  }
+  __syncthreads();
+  __bf16* wf3 = reinterpret_cast<__bf16*>(e.wf3);
+  __bf16* wd3 = reinterpret_cast<__bf16*>(e.wd3);
+  auto put = [&](float* d, __bf16* d3, size_t i, float v) {
+    if (d) d[i] = v;
+    if (d3) {
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 md = (__bf16)r1;
+      d3[i] = h; d3[total + i] = md; d3[2 * total + i] = (__bf16)(r1 - (float)md);
+    }
+  };
+  if (e.wf || wf3)     // [t][co][ci]: consecutive lanes = consecutive ci
+    for (int idx = threadIdx.x; idx < 9 * 32 * nci; idx += 256) {
+      const int tp = idx / (32 * nci), rem = idx - tp * 32 * nci;
+      const int co = rem / nci, ci = rem - co * nci;
+      put(e.wf, wf3, ((size_t)tp * e.Cout + co0 + co) * e.Cin + ci0 + ci, tile[co][ci * 9 + tp]);
+    }
+  if (e.wd || wd3)     // [t][ci][co]: consecutive lanes = consecutive co
+    for (int idx = threadIdx.x; idx < 9 * nci * 32; idx += 256) {
+      const int tp = idx / (nci * 32), rem = idx - tp * nci * 32;
+      const int ci = rem >> 5, co = rem & 31;
+      put(e.wd, wd3, ((size_t)tp * e.Cin + ci0 + ci) * e.Cout + co0 + co, tile[co][ci * 9 + tp]);
+    }
+}
+
 // ---- bilinear 2x, align_corners=False ---------------------------------------------
 // out[2i]   = 0.25*in[i-1] + 0.75*in[i]   (i-1 clamped: out[0] = in[0])
 // out[2i+1] = 0.75*in[i]   + 0.25*in[i+1] (i+1 clamped)
@@ -314,6 +360,16 @@ extern "C" int unet_pack_conv3x3_weights_bf16x3(const float* w, uint16_t* wf3, u
                      (hipStream_t)stream, w, reinterpret_cast<__bf16*>(wf3),
                      reinterpret_cast<__bf16*>(wd3), Cout, Cin);
   UNET_CHECK_LAUNCH("pack_w_split");
+  return UNET_OK;
+}
+
+extern "C" int unet_pack_conv3x3_weights_batched(const unet_pack_entry* table_device, int n,
+                                                 int total_tiles, unet_stream_t stream) {
+  UNET_REQUIRE(table_device && n > 0 && n <= 256 && total_tiles > 0,
+               "pack_conv3x3_weights_batched: bad argument");
+  hipLaunchKernelGGL(pack_w_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0,
+                     (hipStream_t)stream, table_device, n);
+  UNET_CHECK_LAUNCH("pack_w_batched");
   return UNET_OK;
 }
 

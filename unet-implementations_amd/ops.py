@@ -112,6 +112,44 @@ def pack_conv3x3_weights_bf16x3(w_oihw, want_wd=True, want_wf=True):
     return wf3, wd3
 
 
+class PackTable:
+    """Device table for `unet_pack_conv3x3_weights_batched`: one entry per 3x3 layer with
+    persistent destination buffers (fp32 layouts always, bf16x3 planes on request)."""
+
+    def __init__(self, weights, planes):
+        import struct
+        self.wf, self.wd, self.wf3, self.wd3 = [], [], [], []
+        self.src_ptrs = [w.data_ptr() for w in weights]
+        self.planes = planes
+        raw = b""
+        tiles = 0
+        for w in weights:
+            cout, cin = w.shape[0], w.shape[1]
+            if cout % 32:
+                raise ValueError("batched packing needs Cout to be a multiple of 32")
+            wf = _f32((9, cout, cin), w)
+            wd = _f32((9, cin, cout), w)
+            wf3 = wd3 = None
+            if planes and cin != 3:
+                wf3 = torch.empty((3, 9, cout, cin), dtype=torch.bfloat16, device=w.device)
+                wd3 = torch.empty((3, 9, cin, cout), dtype=torch.bfloat16, device=w.device)
+            self.wf.append(wf); self.wd.append(wd); self.wf3.append(wf3); self.wd3.append(wd3)
+            raw += struct.pack("<5Q4i", w.data_ptr(), wf.data_ptr(), wd.data_ptr(),
+                               0 if wf3 is None else wf3.data_ptr(),
+                               0 if wd3 is None else wd3.data_ptr(), cout, cin, tiles, 0)
+            tiles += (cout // 32) * ((cin + 31) // 32)
+        self.n, self.tiles = len(weights), tiles
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(weights[0].device)
+
+    def matches(self, weights, planes):
+        return planes == self.planes and len(weights) == self.n and \
+            all(w.data_ptr() == p for w, p in zip(weights, self.src_ptrs))
+
+    def run(self):
+        check(lib().unet_pack_conv3x3_weights_batched(self.table.data_ptr(), self.n, self.tiles,
+                                                      _stream()))
+
+
 # ---- convolution ---------------------------------------------------------------
 _PREC = {False: 0, True: 1, 0: 0, 1: 1, 3: 3, "fp32": 0, "bf16": 1, "bf16x3": 3}
 _SUFFIX = {0: "", 1: "_bf16", 3: "_bf16x3"}

@@ -400,6 +400,14 @@ class _UNetFunction(torch.autograd.Function):
             raise ValueError("matmul_precision must be 'fp32', 'bf16' or 'bf16x3'")
         bf16 = model.matmul_precision      # operand mode handed to every conv call
 
+        # one launch packs every 3x3 weight into the kernels' layouts (persistent buffers)
+        convs = [l.conv.weight for l in layers if l.ksize == 3]
+        table = model.__dict__.get("_pack_table")
+        if table is None or not table.matches(convs, bf16 == "bf16x3"):
+            table = model.__dict__["_pack_table"] = ops.PackTable(convs, bf16 == "bf16x3")
+        table.run()
+        packed = {id(w): k for k, w in enumerate(convs)}
+
         def run_layer(l, x0, x1):
             w = l.conv.weight
             if l.ksize == 1:
@@ -407,10 +415,8 @@ class _UNetFunction(torch.autograd.Function):
                 wd = ops.transpose2d(w2d) if need_grad else None
                 y = ops.conv1x1_fwd(x0, x1, w2d, l.conv.bias.detach())
             else:
-                wf, wd = ops.pack_conv3x3_weights(w.detach(), want_wd=need_grad)
-                wf3 = wd3 = None
-                if bf16 == "bf16x3" and w.shape[1] != 3:
-                    wf3, wd3 = ops.pack_conv3x3_weights_bf16x3(w.detach(), want_wd=need_grad)
+                k = packed[id(w)]
+                wf, wd, wf3, wd3 = table.wf[k], table.wd[k], table.wf3[k], table.wd3[k]
                 y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride, bf16=bf16,
                                     wf3=wf3)
             st = ops.instnorm_stats(y, l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps)
