@@ -79,6 +79,8 @@ CONV_SHAPES = [
     (2, 8, 8, 128, 0, 128, 1),
     (1, 24, 40, 3, 0, 32, 1),
     (3, 10, 6, 3, 0, 64, 1),
+    (2, 6, 128, 3, 0, 32, 1),       # RGB stem, raw-row form (W % 128 == 0)
+    (1, 3, 256, 3, 0, 64, 1),
     (2, 64, 64, 64, 0, 64, 1),
     (1, 16, 16, 512, 0, 512, 1),
     (2, 2, 2, 512, 0, 512, 1),
@@ -253,6 +255,8 @@ WGRAD_SHAPES = [
     (2, 8, 8, 64, 0, 64, 128, 2),
     (1, 32, 32, 64, 32, 96, 32, 1),
     (1, 24, 40, 3, 0, 3, 32, 1),
+    (2, 6, 128, 3, 0, 3, 32, 1),       # RGB stem, raw-row form (W % 128 == 0)
+    (1, 5, 256, 3, 0, 3, 64, 1),
     (2, 2, 2, 512, 0, 512, 512, 1),
     (2, 4, 4, 512, 0, 512, 512, 2),
     (1, 64, 64, 64, 0, 64, 64, 1),

@@ -771,6 +771,60 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const float* __restr
     }
 }
 
+// Row form of the stem for images whose width is a multiple of 128: a block's 128 pixels lie in
+// one image row, so the three input rows are copied raw (coalesced) as R[ky][3*(col+1) + ci]
+// and the im2col element k = 9*ky + (3*kx + ci) of pixel px is R[ky][3*px + 3*kx + ci] - no
+// per-element gather.  Lanes run along pixels at a stride of 3 words (conflict-free).
+constexpr int STEM_ROW_PIX = 128;
+constexpr int STEM_ROW_PITCH = 393;
+
+__global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ wf,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int N,
+                                                                 int H, int W, int Cout) {
+  __shared__ float Rw[3 * STEM_ROW_PITCH];
+  __shared__ float B[28 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int HW = H * W;
+  const long long m0 = (long long)blockIdx.x * STEM_ROW_PIX;
+  const int co0 = blockIdx.y * 32;
+  const int n = (int)(m0 / HW);
+  const int rem = (int)(m0 - (long long)n * HW);
+  const int yy = rem / W, x0 = rem - yy * W;
+  for (int i = tid; i < 28 * 32; i += 256) {
+    const int k = i >> 5, c = i & 31;  // k = tap*3 + ci; wf is [tap][co][ci]
+    B[i] = (k < 27) ? wf[((k / 3) * Cout + co0 + c) * 3 + (k % 3)] : 0.f;
+  }
+  for (int i = tid; i < 3 * 390; i += 256) {
+    const int ky = i / 390, j = i - ky * 390;
+    const int iy = yy + ky - 1, ix = x0 - 1 + j / 3;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      v = x[((size_t)n * HW + (size_t)iy * W + x0 - 1) * 3 + j];
+    Rw[ky * STEM_ROW_PITCH + j] = v;
+  }
+  __syncthreads();
+  const int px = wave * 32 + li;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int k2 = 0; k2 < 28; k2 += 2) {
+    const int k = k2 + lh;
+    const int kc = k < 27 ? k : 26;          // row 27 of B is zero: any finite a will do
+    const float a = Rw[(kc / 9) * STEM_ROW_PITCH + (kc % 9) + 3 * px];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B[k * 32 + li], acc, 0, 0, 0);
+  }
+  const float bv = bias ? bias[co0 + li] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    y[(size_t)(m0 + row) * Cout + co0 + li] = acc[r] + bv;
+  }
+}
+
 void fill_fwd_taps(IgemmParams& p, int stride) {
   p.ntaps = 9;
   p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
@@ -797,9 +851,15 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
   if (C0 == 3) {
     UNET_REQUIRE(C1 == 0 && stride == 1, "conv3x3_fwd: RGB stem is stride-1, single source");
     const long long M = (long long)N * H * W;
-    dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
-    hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N, H, W,
-                       Cout);
+    if (W % STEM_ROW_PIX == 0) {
+      dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
+      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N,
+                         H, W, Cout);
+    } else {
+      dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
+      hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N, H,
+                         W, Cout);
+    }
     UNET_CHECK_LAUNCH("conv_stem_fwd");
     return UNET_OK;
   }

@@ -558,6 +558,79 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const float* __res
   }
 }
 
+// Row form of the stem weight gradient for images whose width is a multiple of the 128-pixel
+// stage: a stage lies in ONE image row, so instead of gathering 27 im2col values per pixel
+// (scalar loads and index divisions per element) the three input rows y-1, y, y+1 are copied
+// raw (coalesced) as R[ky][3*(col+1) + ci] and the im2col element k = 9*ky + (3*kx + ci) of
+// pixel px is simply R[ky][3*px + (3*kx + ci)]: lane k of the A operand reads one word at a
+// lane-constant offset plus 3*pixel.  Row pitch 393 = 9 mod 32 puts the 27 offsets on 27
+// different banks.  Same stages, partial layout and reductions as conv_stem_wgrad_kernel.
+constexpr int SWR_PITCH = 393;
+
+__global__ __launch_bounds__(256) void conv_stem_wgrad_rows_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
+    int H, int W, int Cout, int stages_per_block, long long total_stages) {
+  __shared__ float Rw[3 * SWR_PITCH];
+  __shared__ float D[SW_PIX * 32];      // [pix][co]
+  __shared__ float R[4][32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int HW = H * W;
+  const int co0 = blockIdx.y * 32;
+  const long long st_begin = (long long)blockIdx.x * stages_per_block;
+  const long long st_end = min(st_begin + (long long)stages_per_block, total_stages);
+  // A-operand lane: row k = li of the 32 x 2 block; k >= 27 contributes zero
+  const int kk = li < 27 ? li : 0;
+  const int a_off = (kk / 9) * SWR_PITCH + (kk % 9) + 3 * lh;
+  const float a_on = li < 27 ? 1.f : 0.f;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (long long st = st_begin; st < st_end; ++st) {
+    const long long m0 = st * SW_PIX;
+    const int n = (int)(m0 / HW);
+    const int rem = (int)(m0 - (long long)n * HW);
+    const int yy = rem / W, x0 = rem - yy * W;
+    // raw rows: word j of row ky = x[n][yy+ky-1][x0-1 + j/3][j%3], j < 3*130
+    for (int i = tid; i < 3 * 390; i += 256) {
+      const int ky = i / 390, j = i - ky * 390;
+      const int iy = yy + ky - 1, ix = x0 - 1 + j / 3;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = x[((size_t)n * HW + (size_t)iy * W + x0 - 1) * 3 + j];
+      Rw[ky * SWR_PITCH + j] = v;
+    }
+    for (int i = tid; i < SW_PIX * 8; i += 256) {
+      const int pix = i >> 3, seg = i & 7;
+      *reinterpret_cast<f32x4*>(D + pix * 32 + seg * 4) =
+          *reinterpret_cast<const f32x4*>(dy + (size_t)(m0 + pix) * Cout + co0 + seg * 4);
+    }
+    __syncthreads();
+    // wave handles pixels [wave*32, wave*32+32): 16 pixel pairs
+#pragma unroll 4
+    for (int q = 0; q < 32; q += 2) {
+      const int px = wave * 32 + q;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Rw[a_off + 3 * px] * a_on,
+                                                 D[(px + lh) * 32 + li], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // cross-wave reduce in fixed order
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    R[wave][row * 32 + li] = acc[r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 27 * 32; i += 256) {
+    const float sm = (R[0][i] + R[1][i]) + (R[2][i] + R[3][i]);
+    const int k = i >> 5, c = i & 31;
+    partial[((size_t)blockIdx.x * 27 + k) * Cout + co0 + c] = sm;
+  }
+}
+
 // stem reduce: dw_oihw[co][ci][tap] (Cin_total = 3) = sum_b partial[b][tap*3+ci][co]
 __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                          int nblocks, int Cout) {
@@ -710,8 +783,12 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   if (pl.stem) {
     UNET_REQUIRE(stride == 1 && Cin_total == 3 && ci_offset == 0, "conv3x3_bwd_weight: stem shape");
     dim3 grid(pl.stem_blocks, Cout / 32);
-    hipLaunchKernelGGL(conv_stem_wgrad_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H, W,
-                       Cout, pl.stem_spb, pl.stem_stages);
+    if (W % SW_PIX == 0)   // a 128-pixel stage never straddles image rows: raw-row form
+      hipLaunchKernelGGL(conv_stem_wgrad_rows_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H,
+                         W, Cout, pl.stem_spb, pl.stem_stages);
+    else
+      hipLaunchKernelGGL(conv_stem_wgrad_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H, W,
+                         Cout, pl.stem_spb, pl.stem_stages);
     UNET_CHECK_LAUNCH("conv_stem_wgrad");
     const int n = 27 * Cout;
     const float* cur = ws;
