@@ -99,19 +99,20 @@ __global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restr
   }
 }
 
-// block = 32 channels x 8 lanes, grid (C/32, N): lane l merges slabs l, l+8, ... in order,
-// then the 8 lane results are merged in lane order (fixed order => deterministic).
-__global__ __launch_bounds__(256) void in_stats_finalize_kernel(
+// block = 32 channels x FL lanes, grid (C/32, N): lane l merges slabs l, l+FL, ... in order,
+// then the FL lane results are merged by a fixed pairwise tree (deterministic).
+constexpr int FL = 32;
+__global__ __launch_bounds__(32 * FL) void in_stats_finalize_kernel(
     const float2* __restrict__ partial, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ mean, float* __restrict__ rstd,
     float* __restrict__ alpha, float* __restrict__ beta2, int N, int HW, int C, int split) {
-  __shared__ float sn[8][33], sm[8][33], sq[8][33];
+  __shared__ float sn[FL][33], sm[FL][33], sq[FL][33];
   const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
   const int per = (HW + split - 1) / split;
   float cnt = 0.f, mu = 0.f, q = 0.f;
   if (c < C) {
-    for (int s = l; s < split; s += 8) {
+    for (int s = l; s < split; s += FL) {
       const int pb = s * per;
       int pe = pb + per;
       if (pe > HW) pe = HW;
@@ -123,10 +124,16 @@ __global__ __launch_bounds__(256) void in_stats_finalize_kernel(
   }
   sn[l][cl] = cnt; sm[l][cl] = mu; sq[l][cl] = q;
   __syncthreads();
-  if (l == 0 && c < C) {
-    cnt = 0.f; mu = 0.f; q = 0.f;
+  // fixed pairwise tree over the FL lane results: (l, l + stride)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) wf_merge(cnt, mu, q, sn[k][cl], sm[k][cl], sq[k][cl]);
+  for (int stride = FL / 2; stride >= 1; stride >>= 1) {
+    if (l < stride) {
+      wf_merge(cnt, mu, q, sn[l + stride][cl], sm[l + stride][cl], sq[l + stride][cl]);
+      sn[l][cl] = cnt; sm[l][cl] = mu; sq[l][cl] = q;
+    }
+    __syncthreads();
+  }
+  if (l == 0 && c < C) {
     const int i = n * C + c;
     const float var = q / (float)HW;  // biased, like F.instance_norm
     const float rs = 1.0f / sqrtf(var + eps);
@@ -224,16 +231,16 @@ __global__ __launch_bounds__(kThreads) void in_bwd_reduce_kernel(
 
 // finalize 1: block = 32 channels x 8 lanes, grid (C/32, N): sums[n][c] = (S1, S2),
 // coef[n][c] = (S1/HW, S2/HW).
-__global__ __launch_bounds__(256) void in_bwd_finalize1_kernel(const float2* __restrict__ partial,
+__global__ __launch_bounds__(32 * FL) void in_bwd_finalize1_kernel(const float2* __restrict__ partial,
                                                                float2* __restrict__ coef,
                                                                float2* __restrict__ sums, int HW,
                                                                int C, int split) {
-  __shared__ float sa[8][33], sb[8][33];
+  __shared__ float sa[FL][33], sb[FL][33];
   const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
   float a = 0.f, b = 0.f;
   if (c < C)
-    for (int s = l; s < split; s += 8) {
+    for (int s = l; s < split; s += FL) {
       const float2 v = partial[((size_t)n * split + s) * C + c];
       a += v.x;
       b += v.y;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void in_bwd_finalize1_kernel(const float2* __r
   if (l == 0 && c < C) {
     a = 0.f; b = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+    for (int k = 0; k < FL; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
     const float inv = 1.f / (float)HW;
     coef[(size_t)n * C + c] = float2{a * inv, b * inv};
     sums[(size_t)n * C + c] = float2{a, b};
@@ -383,7 +390,7 @@ extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const flo
   hipLaunchKernelGGL(in_stats_kernel, dim3(split, N), dim3(kThreads), lds, stream, y, partial, HW,
                      C, split);
   UNET_CHECK_LAUNCH("in_stats");
-  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(256), 0, stream,
+  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
                      partial, gamma, beta, eps, mean, rstd, alpha, beta2, N, HW, C, split);
   UNET_CHECK_LAUNCH("in_stats_finalize");
   return UNET_OK;
@@ -435,7 +442,7 @@ extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, con
   hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(split, N), dim3(kThreads), lds2, stream, ga, y,
                      mean, rstd, gamma, beta, mask, slope, partial, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_reduce");
-  hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(256), 0, stream,
+  hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
                      partial, coef, sums, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_finalize1");
   hipLaunchKernelGGL(in_bwd_finalize2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, sums,
