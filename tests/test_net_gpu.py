@@ -185,40 +185,55 @@ def test_net_vs_oracle_random_init(ua):
     assert (num / den) ** 0.5 <= 5e-3, f"whole-gradient rel err {(num / den) ** 0.5:.3e}"
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_gradient_accuracy_vs_fp64(ua, precision):
-    """Principled accuracy check: the whole gradient of the HIP path must be as close to an
-    fp64 run of the oracle as the oracle's own fp32 run is (x3 slack, floor 5e-4) - in the fp32
-    matrix-core mode and in the split-bf16 mode alike."""
+def test_gradient_accuracy_vs_fp64(ua):
+    """Principled accuracy check: the whole gradient of the HIP path - fp32 matrix cores and
+    split-bf16 mode - must be as close to an fp64 run of the oracle as the oracle's own fp32
+    run is.  A single sample is a lottery: the error is dominated by which LeakyReLU inputs
+    change sign under fp32 rounding (a handful of elements, each worth an O(1) change of its
+    gradient); over 12 batches all three fp32 paths range over 1e-5 ... 1e-2 with medians
+    1.4e-3 / 1.4e-3 / 1.7e-3 (profiles/r01_d_tie_flip_lottery_vs_fp64.txt).  So seven batches
+    are compared by their medians (x3 slack over the reference's, floor 3e-3 = twice the
+    reference's own median), no sample may exceed 3e-2 (a wrong kernel gives O(0.1 - 1)), and
+    the logits - which have no such lottery - must stay within 4x the reference's error."""
     sd0 = O.fill_state_dict(2024)
-    img, tgt = O.synthetic_batch(1234, 2, 64, 64)
-    masks = O.draw_dropout_masks(77, 2)
+    errs = {"ref32": [], "fp32": [], "bf16x3": []}
+    lerr = {"ref32": [], "fp32": [], "bf16x3": []}
+    for trial in range(7):
+        img, tgt = O.synthetic_batch(1234 + trial, 2, 64, 64)
+        masks = O.draw_dropout_masks(77 + trial, 2)
 
-    def run(dtype):
-        osd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd0.items()}
-        lg = O.unet_forward(osd, img.to(dtype), [m.to(dtype) for m in masks])
-        w = O.class_weights(tgt).to(dtype)
-        loss = torch.nn.functional.cross_entropy(lg, tgt, weight=w, ignore_index=255) \
-            + O.dice_loss(lg, tgt)
-        loss.backward()
-        return lg.detach(), torch.cat([v.grad.reshape(-1).double() for v in osd.values()])
+        def run(dtype):
+            osd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd0.items()}
+            lg = O.unet_forward(osd, img.to(dtype), [m.to(dtype) for m in masks])
+            w = O.class_weights(tgt).to(dtype)
+            loss = torch.nn.functional.cross_entropy(lg, tgt, weight=w, ignore_index=255) \
+                + O.dice_loss(lg, tgt)
+            loss.backward()
+            return lg.detach(), torch.cat([v.grad.reshape(-1).double() for v in osd.values()])
 
-    l64, g64 = run(torch.float64)
-    l32, g32 = run(torch.float32)
-    model = ua.UNet()
-    model.load_state_dict(sd0)
-    model = model.to(DEV).train()
-    model.matmul_precision = precision
-    model.dropout_mask_override = masks
-    logits = model(img.to(DEV))
-    ua.SimpleLoss()(logits, tgt.to(DEV)).backward()
-    gh = torch.cat([p.grad.reshape(-1).double().cpu() for p in model.parameters()])
-    e_hip = ((gh - g64).norm() / g64.norm()).item()
-    e_ref = ((g32 - g64).norm() / g64.norm()).item()
-    assert e_hip <= max(3 * e_ref, 5e-4), f"gradient error vs fp64: hip {e_hip:.3e}, ref32 {e_ref:.3e}"
-    l_hip = relerr(logits, l64)
-    l_ref = relerr(l32, l64)
-    assert l_hip <= max(4 * l_ref, 2e-5), f"logits error vs fp64: hip {l_hip:.3e}, ref32 {l_ref:.3e}"
+        def hip(precision):
+            model = ua.UNet()
+            model.load_state_dict(sd0)
+            model = model.to(DEV).train()
+            model.matmul_precision = precision
+            model.dropout_mask_override = masks
+            logits = model(img.to(DEV))
+            ua.SimpleLoss()(logits, tgt.to(DEV)).backward()
+            return logits.detach(), torch.cat([p.grad.reshape(-1).double().cpu()
+                                               for p in model.parameters()])
+
+        l64, g64 = run(torch.float64)
+        for name, (lg, g) in (("ref32", run(torch.float32)), ("fp32", hip("fp32")),
+                              ("bf16x3", hip("bf16x3"))):
+            errs[name].append(((g.double() - g64).norm() / g64.norm()).item())
+            lerr[name].append(relerr(lg, l64))
+    med = lambda v: sorted(v)[len(v) // 2]
+    for mode in ("fp32", "bf16x3"):
+        msg = f"{mode}: gradient error vs fp64 {errs[mode]}, reference fp32 {errs['ref32']}"
+        assert med(errs[mode]) <= max(3 * med(errs["ref32"]), 3e-3), msg
+        assert max(errs[mode]) <= 3e-2, msg
+        assert med(lerr[mode]) <= max(4 * med(lerr["ref32"]), 2e-5), \
+            f"{mode}: logits error vs fp64 {lerr[mode]}, reference fp32 {lerr['ref32']}"
 
 
 def test_state_dict_roundtrip_and_eval_determinism(ua):
