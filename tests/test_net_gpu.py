@@ -494,3 +494,29 @@ def test_full_size_batch_split_invariance(ua, precision):
     n_head = 96 + 4          # arena tail: head weight [3,32,1,1] + bias [3] padded to 4 floats
     eh = ((full_grad[-n_head:] - part_grad[-n_head:]).norm() / part_grad[-n_head:].norm()).item()
     assert eh <= 1e-4, f"head gradient: {eh:.2e}"
+
+
+def test_drawn_dropout_masks_have_the_reference_distribution(ua):
+    """Train mode without an override: one bernoulli draw covers all 16 SpatialDropout2d modules;
+    every mask is [N, C] with values {0, 1/(1-p)} and keep rate 1-p (models/unet.py:22-35)."""
+    from unet_implementations_amd import unet as U
+    model = ua.create_model().train()
+    enc, dec = model._build_plan() if model._plan is None else model._plan
+    layers = [l for blk in enc for l in blk] + [l for blk in dec for l in blk]
+    torch.manual_seed(0)
+    n = 64
+    masks = U._draw_masks(model, layers, n, torch.device(DEV))
+    drops = [(l, m) for l, m in zip(layers, masks) if l.drop is not None and l.drop.drop_prob > 0]
+    assert len(drops) == 16 and all(m is None for l, m in zip(layers, masks)
+                                    if l.drop is None or l.drop.drop_prob == 0)
+    for l, m in drops:
+        p = l.drop.drop_prob
+        assert m.shape == (n, l.conv.out_channels) and m.is_contiguous()
+        vals = m.unique().tolist()
+        assert all(abs(v) < 1e-6 or abs(v - 1 / (1 - p)) < 1e-5 for v in vals)
+        keep = (m > 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 0.03, (l.name, keep)
+    again = U._draw_masks(model, layers, n, torch.device(DEV))
+    assert not torch.equal(again[layers.index(drops[0][0])], drops[0][1])      # fresh draw
+    model.eval()
+    assert all(m is None for m in U._draw_masks(model, layers, n, torch.device(DEV)))

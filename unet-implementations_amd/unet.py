@@ -374,12 +374,29 @@ def _draw_masks(model, layers, n, device):
         it = iter(model.dropout_mask_override)
         return [next(it).to(device=device, dtype=torch.float32).contiguous()
                 if (l.drop is not None and l.drop.drop_prob > 0) else None for l in layers]
-    out = []
-    for l in layers:
-        if model.training and l.drop is not None and l.drop.drop_prob > 0:
-            out.append(l.drop.draw_mask(n, l.conv.out_channels, device))
-        else:
-            out.append(None)
+    if not model.training:
+        return [None] * len(layers)
+    # every SpatialDropout2d's [N, C] mask from ONE bernoulli draw over a cached vector of keep
+    # probabilities (2 launches instead of 2 per module; same distribution as the per-module
+    # `new_empty(N, C, 1, 1).bernoulli_(1 - p).div_(1 - p)` of the reference)
+    sizes = [n * l.conv.out_channels if (l.drop is not None and l.drop.drop_prob > 0) else 0
+             for l in layers]
+    total = sum(sizes)
+    if total == 0:
+        return [None] * len(layers)
+    key = (n, str(device), tuple(sizes), tuple(l.drop.drop_prob if s else 0.0
+                                               for l, s in zip(layers, sizes)))
+    cache = model.__dict__.get("_keep_cache")
+    if cache is None or cache[0] != key:
+        keep = torch.cat([torch.full((s,), 1.0 - l.drop.drop_prob) for l, s in zip(layers, sizes)
+                          if s]).to(device)
+        cache = model.__dict__["_keep_cache"] = (key, keep)
+    keep = cache[1]
+    flat = torch.bernoulli(keep).div_(keep)
+    out, pos = [], 0
+    for l, s in zip(layers, sizes):
+        out.append(flat[pos:pos + s].view(n, l.conv.out_channels) if s else None)
+        pos += s
     return out
 
 
