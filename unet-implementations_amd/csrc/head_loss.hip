@@ -13,41 +13,49 @@ constexpr int HT = 256;  // pixels per head tile
 constexpr int HLD = 33;
 
 // ------------------------------------------------------------------ head forward
+// 8 lanes per pixel, 4 channels per lane: a wave's load instruction reads 8 whole pixels
+// (1 KB contiguous), the 32-channel dot products are finished with three xor-shuffles inside
+// each 8-lane group; no LDS.  Lane 0 of a group writes the pixel's K logits (NCHW planes).
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ logits, long long M,
                                                        int HW, int K) {
-  __shared__ float sA[HT * HLD];
-  __shared__ float sW[4 * 32 + 4];
   const int tid = threadIdx.x;
-  if (tid < K * 32) sW[tid] = w[tid];
-  if (tid < K) sW[128 + tid] = b ? b[tid] : 0.f;
+  const int seg = tid & 7;                       // channels 4*seg .. 4*seg+3
+  f32x4 wk[4];
+  float bk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    wk[k] = k < K ? *reinterpret_cast<const f32x4*>(w + k * 32 + seg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bk[k] = (k < K && b) ? b[k] : 0.f;
+  }
   const long long m0 = (long long)blockIdx.x * HT;
-  for (int i = tid; i < HT * 8; i += 256) {
-    const int pix = i >> 3, seg = i & 7;
+#pragma unroll
+  for (int it = 0; it < HT / 32; ++it) {          // 32 pixels per pass of the 256 threads
+    const long long m = m0 + it * 32 + (tid >> 3);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m0 + pix < M) v = *reinterpret_cast<const f32x4*>(a + (size_t)(m0 + pix) * 32 + seg * 4);
-    float* d = sA + pix * HLD + seg * 4;
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    if (m < M) v = *reinterpret_cast<const f32x4*>(a + (size_t)m * 32 + seg * 4);
+    float acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // same accumulation order inside a lane as the scalar loop: c = 4*seg .. 4*seg+3
+      float s = v[0] * wk[k][0];
+      s = fmaf(v[1], wk[k][1], s);
+      s = fmaf(v[2], wk[k][2], s);
+      s = fmaf(v[3], wk[k][3], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      acc[k] = s + bk[k];
+    }
+    if (seg == 0 && m < M) {
+      const long long n = m / HW, pp = m - n * HW;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < K) logits[((size_t)n * K + k) * HW + pp] = acc[k];
+    }
   }
-  __syncthreads();
-  const long long m = m0 + tid;
-  if (m >= M) return;
-  float acc[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) acc[k] = sW[128 + k];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float x = sA[tid * HLD + c];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < K) acc[k] = fmaf(x, sW[k * 32 + c], acc[k]);
-  }
-  const long long n = m / HW, p = m - n * HW;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < K) logits[((size_t)n * K + k) * HW + p] = acc[k];
 }
 
 // ------------------------------------------------------------------ head backward
@@ -58,62 +66,68 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ da,
                                                        float* __restrict__ partial, long long M,
                                                        int HW, int K, long long tiles) {
-  __shared__ float sA[HT * HLD];
-  __shared__ float sD[4 * HT];
-  __shared__ float sW[4 * 32];
+  // 8 lanes per pixel, 4 channels per lane (as head_fwd_kernel): a and da move as whole pixels
+  // (1 KB per wave instruction), the K logit gradients of a pixel are broadcast loads; every
+  // lane keeps its own dw[k][4 channels] partial sums over the pixels it sees, merged per block
+  // through LDS in fixed order.
+  __shared__ float red[32][4 * 32 + 4];
   const int tid = threadIdx.x;
-  if (tid < K * 32) sW[tid] = w[tid];
-  float wacc = 0.f;  // threads < K*32: dw[k][c]; threads K*32..K*32+K-1: db[k]
-  const int wk = tid >> 5, wc = tid & 31;
+  const int seg = tid & 7, grp = tid >> 3;
+  f32x4 wk[4], dwacc[4];
+  float dbacc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    wk[k] = k < K ? *reinterpret_cast<const f32x4*>(w + k * 32 + seg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dwacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dbacc[k] = 0.f;
+  }
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long long m0 = t * HT;
-    __syncthreads();  // previous tile fully consumed (also orders the sW fill)
-    for (int i = tid; i < HT * 8; i += 256) {
-      const int pix = i >> 3, seg = i & 7;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + pix < M) v = *reinterpret_cast<const f32x4*>(a + (size_t)(m0 + pix) * 32 + seg * 4);
-      float* d = sA + pix * HLD + seg * 4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-    const long long m = m0 + tid;
-    float dv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (m < M) {
-      const long long n = m / HW, p = m - n * HW;
+    // all loads of the tile first (rows past M are clamped and masked: no branch, so the eight
+    // pixel loads and 8 x K gradient loads are in flight together)
+    f32x4 av[HT / 32];
+    float dv[HT / 32][4];
+#pragma unroll
+    for (int it = 0; it < HT / 32; ++it) {
+      const long long m = m0 + it * 32 + grp;
+      const long long mc = m < M ? m : M - 1;
+      av[it] = *reinterpret_cast<const f32x4*>(a + (size_t)mc * 32 + seg * 4);
+      const long long n = mc / HW, pp = mc - n * HW;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (k < K) dv[k] = dl[((size_t)n * K + k) * HW + p];
+        dv[it][k] = (k < K && m < M) ? dl[((size_t)n * K + k) * HW + pp] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sD[k * HT + tid] = dv[k];
-    __syncthreads();
-    if (m < M) {
-      float* o = da + (size_t)m * 32;
+    for (int it = 0; it < HT / 32; ++it) {
+      const long long m = m0 + it * 32 + grp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        f32x4 v;
+      for (int k = 0; k < 4; ++k)
+        if (k < K) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float x = 0.f;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < K) x = fmaf(dv[k], sW[k * 32 + s * 4 + j], x);
-          v[j] = x;
+          for (int jj = 0; jj < 4; ++jj) {
+            v[jj] = fmaf(dv[it][k], wk[k][jj], v[jj]);
+            dwacc[k][jj] = fmaf(dv[it][k], av[it][jj], dwacc[k][jj]);
+          }
+          dbacc[k] += dv[it][k];
         }
-        *reinterpret_cast<f32x4*>(o + s * 4) = v;
-      }
-    }
-    if (tid < K * 32) {
-      float s = 0.f;
-      for (int pix = 0; pix < HT; ++pix) s = fmaf(sD[wk * HT + pix], sA[pix * HLD + wc], s);
-      wacc += s;
-    } else if (tid < K * 32 + K) {
-      const int k = tid - K * 32;
-      float s = 0.f;
-      for (int pix = 0; pix < HT; ++pix) s += sD[k * HT + pix];
-      wacc += s;
+      if (m < M) *reinterpret_cast<f32x4*>(da + (size_t)m * 32 + seg * 4) = v;
     }
   }
-  if (tid < K * 32 + K) partial[(size_t)blockIdx.x * (K * 32 + K) + tid] = wacc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) red[grp][k * 32 + seg * 4 + jj] = dwacc[k][jj];
+    if (seg == 0) red[grp][128 + k] = dbacc[k];
+  }
+  __syncthreads();
+  if (tid < K * 32 + K) {
+    const int col = tid < K * 32 ? tid : 128 + (tid - K * 32);
+    float sm = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) sm += red[g][col];
+    partial[(size_t)blockIdx.x * (K * 32 + K) + tid] = sm;
+  }
 }
 
 // one block per output column (K*32 weights then K biases): 256 threads stride the slabs,
