@@ -333,12 +333,26 @@ __global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
 }
 
 // out[chunk][c] = sum of rows [chunk*rpc, (chunk+1)*rpc) of partial[.][c]; block = 32 c x 8 lanes
+// With `sums` (the last stage of the dbias reduction only): lanes 1 and 2 of each channel also
+// produce dgamma[c] = sum_n S2[n][c] and dbeta[c] = sum_n S1[n][c], which saves a launch per layer.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial,
                                                      float* __restrict__ out, int rows, int C,
-                                                     int rows_per_chunk) {
+                                                     int rows_per_chunk,
+                                                     const float2* __restrict__ sums, int N,
+                                                     float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
   __shared__ float sa[8][33];
   const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
+  if (sums && c < C && (l == 1 || l == 2)) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float2 v = sums[(size_t)n * C + c];
+      acc += (l == 1) ? v.y : v.x;
+    }
+    if (l == 1 && dgamma) dgamma[c] = acc;
+    if (l == 2 && dbeta) dbeta[c] = acc;
+  }
   const int r0 = blockIdx.y * rows_per_chunk;
   const int r1 = min(r0 + rows_per_chunk, rows);
   float a = 0.f;
@@ -445,9 +459,11 @@ extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, con
   hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
                      partial, coef, sums, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_finalize1");
-  hipLaunchKernelGGL(in_bwd_finalize2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, sums,
-                     dgamma, dbeta, N, C);
-  UNET_CHECK_LAUNCH("in_bwd_finalize2");
+  if (!dbias) {   // with dbias the last column-sum launch below also emits dgamma / dbeta
+    hipLaunchKernelGGL(in_bwd_finalize2_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, sums,
+                       dgamma, dbeta, N, C);
+    UNET_CHECK_LAUNCH("in_bwd_finalize2");
+  }
   const size_t lds1 = (size_t)groups * C * sizeof(float);
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(split, N), dim3(kThreads), lds1, stream, ga, y, mean,
                      rstd, gamma, beta, mask, slope, coef, dy, dbias ? dbp : nullptr, HW, C, split);
@@ -456,15 +472,16 @@ extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, con
     const int rows = N * split;
     if (rows <= 64) {
       hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32), 1), dim3(256), 0, stream, dbp, dbias,
-                         rows, C, rows);
+                         rows, C, rows, sums, N, dgamma, dbeta);
     } else {
       const int rpc = ceil_div(rows, kColsumChunks);
       const int chunks = ceil_div(rows, rpc);
       hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32), chunks), dim3(256), 0, stream, dbp,
-                         dbstage, rows, C, rpc);
+                         dbstage, rows, C, rpc, (const float2*)nullptr, 0, (float*)nullptr,
+                         (float*)nullptr);
       UNET_CHECK_LAUNCH("dbias_colsum(stage)");
       hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(C, 32), 1), dim3(256), 0, stream, dbstage,
-                         dbias, chunks, C, chunks);
+                         dbias, chunks, C, chunks, sums, N, dgamma, dbeta);
     }
     UNET_CHECK_LAUNCH("dbias_colsum");
   }
