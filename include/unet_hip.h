@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 1
+#define UNET_ABI_VERSION 2
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -284,6 +284,90 @@ int unet_sgd_nesterov_step(float* params, const float* grads, float* momentum, i
 
 /* out[i] = a[i] + b[i] (gradient accumulation of skip tensors, test helper) */
 int unet_add_inplace(float* a, const float* b, int64_t n, unet_stream_t stream);
+
+/* ---- fused layer pipeline -------------------------------------------------- */
+/*
+ * One ConvBlock unit of the reference is conv -> InstanceNorm2d -> LeakyReLU -> SpatialDropout2d
+ * (Our_UNet/models/unet.py:101-134).  The stand-alone entry points above run it as four passes
+ * over the layer tensor (conv, statistics, apply, next conv).  The fused pipeline keeps only
+ * the RAW convolution output y_l of every layer in HBM:
+ *   - the convolution that produces y_l emits the InstanceNorm statistics of y_l from its
+ *     epilogue (per-tile (mean, M2) summaries, merged by a tiny finalize launch), and
+ *   - every consumer of the activated tensor a_l = dropout(lrelu(IN(y_l))) -- the next
+ *     convolution, the weight gradient of the next convolution, the bilinear up-sampling, the
+ *     1x1 head -- applies  a = lrelu(y * alpha[n][c] + beta[n][c], slope)  to the operand while
+ *     it stages it on chip (zero padding is applied after the activation).
+ * alpha / beta are the folded coefficients the statistics finalize writes:
+ *   alpha[n][c] = gamma[c] * rstd[n][c] * mask[n][c],
+ *   beta [n][c] = (beta[c] - mean[n][c] * gamma[c] * rstd[n][c]) * mask[n][c]
+ * (mask = the SpatialDropout2d factor 0 or 1/(1-p), folded in because lrelu(z)*m == lrelu(z*m)
+ * for m >= 0).  a_l itself is never written.
+ */
+typedef struct unet_act_src {
+  const float* x;     /* [N][H][W][C] raw convolution output, or a plain tensor (alpha == NULL) */
+  int C;              /* channels: 3 (RGB image, plain only) or a multiple of 32 */
+  const float* alpha; /* [N][C] folded InstanceNorm scale x dropout mask; NULL = use x as stored */
+  const float* beta;  /* [N][C] folded shift; ignored when alpha == NULL */
+} unet_act_src;
+
+/* y[N][Ho][Wo][Cout] = conv_kxk(cat(act(s0), act(s1))) + bias  (ksize 3: pad 1, stride 1|2,
+ * w = wf[9][Cout][Cin]; ksize 1: stride 1, w = [Cout][Cin]; s1 may be NULL), plus the
+ * InstanceNorm statistics of y and the folded coefficients for ITS consumers:
+ * mean, rstd, alpha_out, beta_out [N][Cout] (gamma/beta = the norm's affine parameters,
+ * mask [N][Cout] = this layer's dropout factors or NULL).
+ * Replaces Conv2d + InstanceNorm2d statistics (+ the previous unit's IN apply / LeakyReLU /
+ * dropout) of ConvBlock (Our_UNet/models/unet.py:101-134) and the torch.cat of UpBlock (:228).
+ * H, W = input spatial size. */
+size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout, int stride);
+int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope, const float* w,
+                     const float* bias, int ksize, int stride, float* y, const float* gamma,
+                     const float* beta, float eps, const float* mask, float* mean, float* rstd,
+                     float* alpha_out, float* beta_out, void* workspace, size_t workspace_bytes,
+                     int N, int H, int W, int Cout, unet_stream_t stream);
+
+/* Weight gradient with the activation applied to the input operand on load:
+ * dw_oihw[Cout][Cin_total][k][k] (columns ci_offset .. +x->C) = sum_pixels act(x) (x) dy.
+ * Same workspace query as unet_conv3x3_bwd_weight.  ksize 1 keeps the centre tap. */
+int unet_conv_in_bwd_weight(const unet_act_src* x, float slope, const float* dy, float* dw_oihw,
+                            int ci_offset, int Cin_total, int ksize, int stride, void* workspace,
+                            size_t workspace_bytes, int N, int H, int W, int Cout,
+                            unet_stream_t stream);
+
+/* up[N][2h][2w][C] = bilinear2x(act(x)) (the activation is applied to each of the four taps;
+ * UpBlock.forward, Our_UNet/models/unet.py:219-225). */
+int unet_upsample2x_in_fwd(const unet_act_src* x, float slope, float* up, int N, int h, int w,
+                           unet_stream_t stream);
+
+/* Backward of conv3x3(upsample2x(a)) at LOW resolution.  The bilinear up-sampling U is linear:
+ *   dW[tap]  = sum_p (U a)[p + tap] (x) dy[p]   =  sum_q a[q] (x) D_tap[q]
+ *   dL/da[q] = (U^T sum_tap W_tap^T shift_tap dy)[q]  =  sum_tap W_tap^T D_tap[q]
+ * with D_tap = U^T shift_tap(dy): both gradients of the up-sampled operand of UpBlock's first
+ * convolution (Our_UNet/models/unet.py:219-231) become GEMMs over the low-resolution pixels q --
+ * a quarter of the positions, so a quarter of the FLOPs of the 3x3 weight / data gradient on
+ * the up-sampled grid, no up-sampled tensor and no upsample2x_bwd pass.
+ *   unet_upsample2x_bwd_taps:   D[N][h][w][9*C] (tap-major channels) from dy[N][2h][2w][C]
+ *   unet_conv3x3_up_bwd_weight: dw_oihw[Cout][Cin_total][3][3] (columns ci_offset .. +x->C)
+ *                               from act(x)[N][h][w][Cx] and D
+ *   unet_conv3x3_up_bwd_data:   g[N][h][w][Ccols] (+)= sum_tap D_tap . wd[tap][ci_offset..][:]
+ */
+int unet_upsample2x_bwd_taps(const float* dy, float* D, int N, int h, int w, int C,
+                             unet_stream_t stream);
+size_t unet_conv3x3_up_bwd_weight_workspace_bytes(int N, int h, int w, int Cx, int Cout);
+int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, const float* D, float* dw_oihw,
+                               int ci_offset, int Cin_total, void* workspace,
+                               size_t workspace_bytes, int N, int h, int w, int Cout,
+                               unet_stream_t stream);
+int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin_total, int ci_offset,
+                             float* g, int N, int h, int w, int Cout, int Ccols, int accumulate,
+                             unet_stream_t stream);
+
+/* Head on an activated-on-load operand: logits = act(x) . w + b, and its backward
+ * (da = dL/d act(x), dw, db); x->C == 32. */
+int unet_head1x1_in_fwd(const unet_act_src* x, float slope, const float* w, const float* b,
+                        float* logits_nchw, int N, int HW, int K, unet_stream_t stream);
+int unet_head1x1_in_bwd(const unet_act_src* x, float slope, const float* dlogits_nchw,
+                        const float* w, float* da, float* dw, float* db, void* workspace,
+                        size_t workspace_bytes, int N, int HW, int K, unet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -129,7 +129,7 @@ def draw_dropout_masks(seed, n):
 
 
 # --------------------------------------------------------------------------- per-op
-def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None):
+def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None, slope=NEG_SLOPE):
     """Conv2d(3x3, pad 1) -> InstanceNorm2d(eps, affine) -> LeakyReLU(0.01) -> channel mask
     (models/unet.py:101-134; SpatialDropout2d.forward :22-35).  `record` (debug): list that
     receives the raw conv output with retain_grad set."""
@@ -139,7 +139,7 @@ def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None):
             y.retain_grad()
         record.append(y)
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=EPS)
-    y = F.leaky_relu(y, NEG_SLOPE)
+    y = F.leaky_relu(y, slope)   # `slope` = nonlin_kwargs["negative_slope"] of the reference ctor
     if mask is not None:
         y = y * mask.view(mask.shape[0], mask.shape[1], 1, 1)
     return y
@@ -153,7 +153,7 @@ def upsample_concat(x, skip):
 
 
 # --------------------------------------------------------------------------- network
-def unet_forward(sd, x, masks=None, record=None, clip_features=None):
+def unet_forward(sd, x, masks=None, record=None, clip_features=None, slope=NEG_SLOPE):
     """UNet.forward (models/unet.py:399-432).  `masks`: list from draw_dropout_masks (train
     mode) or None (eval / rates 0).  `record` (debug): collects each conv's raw output.
     `clip_features` [N,clip_dim,h/32,w/32]: the CLIP_UNet bottleneck fusion
@@ -169,13 +169,13 @@ def unet_forward(sd, x, masks=None, record=None, clip_features=None):
             cur = F.conv2d(cur, sd["clip_fusion_conv.0.weight"], sd["clip_fusion_conv.0.bias"])
             cur = F.instance_norm(cur, weight=sd["clip_fusion_conv.1.weight"],
                                   bias=sd["clip_fusion_conv.1.bias"], eps=EPS)
-            cur = F.leaky_relu(cur, NEG_SLOPE)
+            cur = F.leaky_relu(cur, slope)
         if kind == "dec_first":
             cur = upsample_concat(cur, skips.pop())
         m = next(mi) if (mi is not None and p > 0) else None
         cur = conv_in_lrelu_drop(cur, sd[f"{prefix}.{ci}.weight"], sd[f"{prefix}.{ci}.bias"],
                                  sd[f"{prefix}.{ni}.weight"], sd[f"{prefix}.{ni}.bias"], stride, m,
-                                 record)
+                                 record, slope)
         if kind == "enc" and li % 2 == 1 and li < n_enc - 1:
             skips.append(cur)
     return F.conv2d(cur, sd["segmentation_output.weight"], sd["segmentation_output.bias"])
@@ -231,13 +231,13 @@ def sgd_nesterov_(params, grads, bufs, lr=0.005, momentum=0.99, weight_decay=1e-
 
 
 def train_step(sd, bufs, images, target, masks=None, lr=0.005, momentum=0.99, weight_decay=1e-4,
-               clip_features=None):
+               clip_features=None, slope=NEG_SLOPE):
     """One step in the order of train_one_epoch (src/train.py:634-664).  `sd` values must be
     leaf tensors with requires_grad=True; returns (loss, {name: grad})."""
     names = list(sd.keys())
     for v in sd.values():
         v.grad = None
-    logits = unet_forward(sd, images, masks, clip_features=clip_features)
+    logits = unet_forward(sd, images, masks, clip_features=clip_features, slope=slope)
     loss = simple_loss(logits, target)
     loss.backward()
     grads = {k: sd[k].grad.detach().clone() for k in names}

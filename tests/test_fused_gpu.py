@@ -1,0 +1,319 @@
+"""Fused layer pipeline (-m gpu): the C-ABI entry points `unet_conv_in_fwd`,
+`unet_conv_in_bwd_weight`, `unet_upsample2x_in_fwd`, `unet_head1x1_in_fwd/_bwd` against stock
+torch CPU ops on seeded inputs, and against the reference's ConvBlock / UpBlock fixtures
+(tests/golden/ops_small.npz).  The shapes are chosen so that every kernel instantiation behind
+the entry points (patch-staged 128/64/32 columns, row-fused with and without resident weights,
+gather-GEMM tiles, RGB stem rows / gather, 1x1) runs with activation-on-load and its
+statistics epilogue (or the stand-alone statistics fallback).
+
+Reference lines: Our_UNet/models/unet.py:101-134 (conv -> InstanceNorm2d -> LeakyReLU ->
+SpatialDropout2d), :215-231 (interpolate + cat), :374-381 (head).
+Tolerances are relative to the tensor's max magnitude (fp32, different summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SLOPE = 0.01
+
+
+def to_nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def from_nhwc(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def check(a, b, tol, what=""):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def coeffs(n, c, seed, dropped=True):
+    """Folded coefficients as a producing layer would leave them: alpha > 0 mostly, some
+    channels dropped (alpha = beta = 0), some negative scales."""
+    al = rnd(n, c, seed=seed) * 0.5 + 1.0
+    be = rnd(n, c, seed=seed + 1) * 0.7
+    if dropped:
+        drop = torch.rand(n, c, generator=torch.Generator().manual_seed(seed + 2)) < 0.15
+        al = torch.where(drop, torch.zeros_like(al), al)
+        be = torch.where(drop, torch.zeros_like(be), be)
+    return al, be
+
+
+def act_ref(x_nchw, al, be):
+    """a = lrelu(x * alpha[n, c] + beta[n, c]) on an NCHW tensor (fp64)."""
+    z = x_nchw.double() * al.double()[:, :, None, None] + be.double()[:, :, None, None]
+    return F.leaky_relu(z, SLOPE)
+
+
+def make_src(ua, x_nchw, coef):
+    if coef is None:
+        return ua.ops.Act(to_nhwc(x_nchw))
+    return ua.ops.Act(to_nhwc(x_nchw), coef[0].to(DEV).contiguous(), coef[1].to(DEV).contiguous())
+
+
+# (N, H, W, C0, C1, Cout, stride, ksize, act0, act1): which kernel it reaches is in the comment
+FWD_CASES = [
+    (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # patch-staged, 128 columns (two sources)
+    (1, 256, 256, 64, 0, 64, 1, 3, True, False),     # patch-staged, 64 columns
+    (2, 256, 256, 32, 32, 32, 1, 3, False, True),    # patch-staged, 32 columns x 8 rows; plain src0
+    (1, 128, 128, 32, 0, 32, 1, 3, True, False),     # row-fused, weights resident (K = 32)
+    (1, 12, 128, 64, 0, 32, 1, 3, True, False),      # row-fused, streamed weights
+    (2, 256, 256, 32, 0, 128, 2, 3, True, False),    # gather-GEMM 128x128, stride 2
+    (2, 256, 256, 32, 0, 64, 2, 3, True, False),     # gather-GEMM 128x64 tiles, stride 2
+    (2, 16, 16, 64, 0, 64, 1, 3, True, False),       # gather-GEMM 64x64
+    (3, 4, 4, 32, 32, 32, 1, 3, True, True),         # tiles span images: per-row coefficients
+    (2, 2, 2, 64, 0, 64, 2, 3, True, False),         # 2x2 -> 1x1 grid, stand-alone statistics
+    (2, 12, 20, 32, 0, 32, 1, 3, True, False),       # ragged grid (240 positions)
+    (2, 16, 16, 64, 32, 64, 1, 1, True, False),      # 1x1 (CLIP fusion layer), plain second source
+    (2, 8, 128, 3, 0, 32, 1, 3, False, False),       # RGB stem, row form + statistics epilogue
+    (2, 12, 20, 3, 0, 32, 1, 3, False, False),       # RGB stem, gather form
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_conv_in_fwd(ua, case, with_mask):
+    N, H, W, C0, C1, Cout, stride, ks, act0, act1 = case
+    x0 = rnd(N, C0, H, W, seed=1)
+    x1 = rnd(N, C1, H, W, seed=2) if C1 else None
+    c0 = coeffs(N, C0, 10) if act0 else None
+    c1 = coeffs(N, C1, 20) if (act1 and C1) else None
+    w = rnd(Cout, C0 + C1, ks, ks, seed=3, scale=(2.0 / (ks * ks * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma = rnd(Cout, seed=5) * 0.2 + 1.0
+    beta = rnd(Cout, seed=6) * 0.2
+    mask = None
+    if with_mask:
+        keep = torch.rand(N, Cout, generator=torch.Generator().manual_seed(7)) < 0.7
+        mask = keep.float() / 0.7
+    # reference (fp64)
+    a0 = act_ref(x0, *c0) if c0 else x0.double()
+    parts = [a0]
+    if C1:
+        parts.append(act_ref(x1, *c1) if c1 else x1.double())
+    y_ref = F.conv2d(torch.cat(parts, 1), w.double(), b.double(), stride=stride, padding=ks // 2)
+    mean_ref = y_ref.mean(dim=(2, 3))
+    var_ref = y_ref.var(dim=(2, 3), unbiased=False)
+    rstd_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+    mk = mask.double() if mask is not None else torch.ones(N, Cout, dtype=torch.double)
+    alpha_ref = gamma.double()[None] * rstd_ref * mk
+    beta_ref = (beta.double()[None] - mean_ref * gamma.double()[None] * rstd_ref) * mk
+    # HIP
+    if ks == 3:
+        wk, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    else:
+        wk = w.view(Cout, C0 + C1).to(DEV).contiguous()
+    s0 = make_src(ua, x0, c0)
+    s1 = make_src(ua, x1, c1) if C1 else None
+    y, st = ua.ops.conv_in_fwd(s0, s1, SLOPE, wk, b.to(DEV), ks, stride, gamma.to(DEV),
+                               beta.to(DEV), 1e-5, None if mask is None else mask.to(DEV))
+    check(from_nhwc(y), y_ref, 2e-5, "y")
+    assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), rstd_ref, 5e-5, "rstd")
+    check(st[2].cpu(), alpha_ref, 5e-5, "alpha")
+    # beta is a difference of O(1) terms: absolute scale of |beta| + |mean * alpha|
+    scale = (beta.abs().max() + (mean_ref * gamma[None] * rstd_ref).abs().max()).item() / 0.7
+    assert (st[3].cpu().double() - beta_ref).abs().max() <= 5e-5 * scale
+
+
+WGRAD_CASES = [  # (N, H, W, Cx, Cout, stride, ksize, act)
+    (2, 12, 64, 32, 32, 1, 3, True),     # 32x32 tile
+    (1, 16, 32, 64, 64, 1, 3, True),     # 64x64 tile
+    (1, 16, 16, 32, 64, 1, 3, True),     # 32x64 tile
+    (2, 16, 32, 64, 64, 2, 3, True),     # stride 2
+    (2, 32, 64, 32, 32, 2, 3, True),
+    (3, 4, 4, 64, 128, 1, 3, True),      # several images per block
+    (2, 2, 2, 512, 512, 1, 1, True),     # 1x1 (centre tap)
+    (1, 16, 16, 64, 64, 1, 3, False),    # plain operand through the same entry point
+    (2, 8, 128, 3, 32, 1, 3, False),     # RGB stem
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_in_bwd_weight(ua, case):
+    N, H, W, Cx, Cout, stride, ks, act = case
+    x = rnd(N, Cx, H, W, seed=1)
+    coef = coeffs(N, Cx, 30) if act else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = rnd(N, Cout, Ho, Wo, seed=2)
+    a = (act_ref(x, *coef) if coef else x.double()).requires_grad_(False)
+    wz = torch.zeros(Cout, Cx, ks, ks, dtype=torch.double, requires_grad=True)
+    F.conv2d(a, wz, None, stride=stride, padding=ks // 2).backward(dy.double())
+    # embed in a wider gradient tensor at a channel offset, like the second source of a concat
+    off, total = 32, Cx + 64
+    if Cx == 3:
+        off, total = 0, 3
+    dw = torch.full((Cout, total, ks, ks), 7.0, device=DEV)
+    ua.ops.conv_in_bwd_weight(make_src(ua, x, coef), SLOPE, to_nhwc(dy), dw, off, ks, stride)
+    check(dw[:, off:off + Cx].cpu(), wz.grad, 3e-5, "dw")
+    if total > Cx:
+        assert torch.all(dw[:, :off] == 7.0) and torch.all(dw[:, off + Cx:] == 7.0)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (1, 1, 1, 32), (2, 2, 2, 512), (1, 16, 16, 32)])
+def test_upsample2x_in_fwd(ua, shape):
+    N, h, w, C = shape
+    x = rnd(N, C, h, w, seed=1)
+    coef = coeffs(N, C, 40)
+    ref = F.interpolate(act_ref(x, *coef), scale_factor=2, mode="bilinear", align_corners=False)
+    up = ua.ops.upsample2x_in_fwd(make_src(ua, x, coef), SLOPE)
+    check(from_nhwc(up), ref, 1e-6, "upsample(act(x))")
+    # plain operand: the stand-alone kernel's result
+    up2 = ua.ops.upsample2x_in_fwd(ua.ops.Act(to_nhwc(x)), SLOPE)
+    assert torch.equal(up2, ua.ops.upsample2x_fwd(to_nhwc(x)))
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 20), (1, 64, 64), (3, 17, 9)])
+def test_head1x1_in(ua, shape):
+    N, H, W = shape
+    x = rnd(N, 32, H, W, seed=1)
+    coef = coeffs(N, 32, 50)
+    w = rnd(3, 32, seed=2, scale=0.2)
+    b = rnd(3, seed=3, scale=0.1)
+    a = act_ref(x, *coef).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    logits_ref = F.conv2d(a, wr[:, :, None, None], br)
+    dl = rnd(N, 3, H, W, seed=4)
+    logits_ref.backward(dl.double())
+    src = make_src(ua, x, coef)
+    logits = ua.ops.head1x1_in_fwd(src, SLOPE, w.to(DEV), b.to(DEV))
+    check(logits.cpu(), logits_ref.detach(), 2e-5, "logits")
+    dw, db = torch.empty(3, 32, device=DEV), torch.empty(3, device=DEV)
+    da = ua.ops.head1x1_in_bwd(src, SLOPE, dl.to(DEV), w.to(DEV), dw, db)
+    check(from_nhwc(da), a.grad, 2e-5, "da")
+    check(dw.cpu(), wr.grad, 3e-5, "dw")
+    check(db.cpu(), br.grad, 3e-5, "db")
+
+
+# --------------------------------------------------------------------------- composed blocks (golden)
+def _run_block_fused(ua, s0, s1, p, idx, stride, masks):
+    """The two conv units of a reference ConvBlock state_dict `p` on the fused pipeline."""
+    recs = []
+    for k, (ci, ni) in enumerate(idx):
+        w = p[f"block.{ci}.weight"].to(DEV)
+        wf, wd = ua.ops.pack_conv3x3_weights(w)
+        gm, bt = p[f"block.{ni}.weight"].to(DEV), p[f"block.{ni}.bias"].to(DEV)
+        m = masks[k].to(DEV) if masks is not None else None
+        y, st = ua.ops.conv_in_fwd(s0, s1, SLOPE, wf, p[f"block.{ci}.bias"].to(DEV), 3,
+                                   stride if k == 0 else 1, gm, bt, 1e-5, m)
+        recs.append(dict(x0=s0, x1=s1, y=y, st=st, m=m, wd=wd, gm=gm, bt=bt, ci=ci, ni=ni,
+                         stride=stride if k == 0 else 1, w=w))
+        s0, s1 = ua.ops.Act(y, st[2], st[3]), None
+    return recs, s0
+
+
+def _block_backward_fused(ua, recs, g):
+    grads = {}
+    dx1 = None
+    for r in reversed(recs):
+        C = r["y"].shape[3]
+        dg, dbt, dbias = (torch.empty(C, device=DEV) for _ in range(3))
+        dy = ua.ops.instnorm_lrelu_drop_bwd(g, r["y"], r["st"][0], r["st"][1], r["gm"], r["bt"],
+                                            r["m"], SLOPE, dg, dbt, dbias)
+        dw = torch.empty_like(r["w"])
+        ua.ops.conv_in_bwd_weight(r["x0"], SLOPE, dy, dw, 0, 3, r["stride"])
+        N, H, W, C0 = r["x0"].shape
+        if r["x1"] is not None:
+            ua.ops.conv_in_bwd_weight(r["x1"], SLOPE, dy, dw, C0, 3, r["stride"])
+            dx1 = ua.ops.conv3x3_bwd_data(dy, r["wd"], C0, r["x1"].shape[3], H, W, r["stride"])
+        g = ua.ops.conv3x3_bwd_data(dy, r["wd"], 0, C0, H, W, r["stride"])
+        grads[f"block.{r['ci']}.weight"] = dw
+        grads[f"block.{r['ci']}.bias"] = dbias
+        grads[f"block.{r['ni']}.weight"] = dg
+        grads[f"block.{r['ni']}.bias"] = dbt
+    return g, dx1, grads
+
+
+def _materialise(ua, act):
+    """a = lrelu(y * alpha + beta) through the stand-alone apply kernel (test helper)."""
+    return ua.ops.instnorm_lrelu_drop_fwd(act.x, act.alpha, act.beta, None, SLOPE)
+
+
+def _check_grads(grads, g, prefix, what):
+    for k, v in grads.items():
+        ref = torch.from_numpy(g[prefix + k])
+        if k.endswith("bias") and ref.abs().max() < 1e-4:   # conv bias under IN: ~0 +- rounding
+            assert (v.cpu() - ref).abs().max() < 1e-4
+        else:
+            check(v.cpu(), ref, 5e-5, f"{what} grad {k}")
+
+
+def test_convblock_golden_fused(ua, golden):
+    """Reference ConvBlock(32->64, stride 2, dropout 0.2) in train mode, forward + backward."""
+    g = golden("ops_small")
+    p = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cb_p_")}
+    masks = [torch.from_numpy(g["cb_mask0"]), torch.from_numpy(g["cb_mask1"])]
+    recs, out = _run_block_fused(ua, ua.ops.Act(to_nhwc(torch.from_numpy(g["cb_x"]))), None, p,
+                                 [(0, 1), (4, 5)], 2, masks)
+    check(from_nhwc(_materialise(ua, out)), torch.from_numpy(g["cb_y"]), 2e-5, "ConvBlock fwd")
+    gx, _, grads = _block_backward_fused(ua, recs, to_nhwc(torch.from_numpy(g["cb_gy"])))
+    check(from_nhwc(gx), torch.from_numpy(g["cb_gx"]), 5e-5, "ConvBlock gx")
+    _check_grads(grads, g, "cb_g_", "ConvBlock")
+
+
+def test_upblock_golden_fused(ua, golden):
+    """Reference UpBlock(64 up + 32 skip -> 32), eval mode, forward + backward."""
+    g = golden("ops_small")
+    p = {k[16:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ub_p_conv_block.")}
+    up = ua.ops.Act(ua.ops.upsample2x_in_fwd(ua.ops.Act(to_nhwc(torch.from_numpy(g["ub_x"]))), SLOPE))
+    recs, out = _run_block_fused(ua, up, ua.ops.Act(to_nhwc(torch.from_numpy(g["ub_skip"]))), p,
+                                 [(0, 1), (3, 4)], 1, None)
+    check(from_nhwc(_materialise(ua, out)), torch.from_numpy(g["ub_y"]), 2e-5, "UpBlock fwd")
+    g_up, g_skip, grads = _block_backward_fused(ua, recs, to_nhwc(torch.from_numpy(g["ub_gy"])))
+    gx = ua.ops.upsample2x_bwd(g_up)
+    check(from_nhwc(gx), torch.from_numpy(g["ub_gx"]), 5e-5, "UpBlock gx")
+    check(from_nhwc(g_skip), torch.from_numpy(g["ub_gskip"]), 5e-5, "UpBlock gskip")
+    _check_grads(grads, g, "ub_g_conv_block.", "UpBlock")
+
+
+# --------------------------------------------------------------------------- low-resolution backward
+UP_CASES = [  # (N, h, w, Cx, Cout, act)
+    (2, 8, 16, 64, 64, True),      # 64x64 channel tiles
+    (1, 16, 16, 32, 64, True),     # 32x64
+    (2, 8, 8, 64, 32, True),       # 32x32
+    (3, 2, 2, 64, 64, True),       # 2x2 maps: a segment spans images, every border case
+    (2, 1, 3, 32, 32, False),      # single row, plain operand
+    (1, 16, 32, 128, 64, True),
+]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv3x3_up_backward_at_low_resolution(ua, case):
+    """dW and dL/da of conv3x3(upsample2x(act(x))) through D = upsample2x_bwd_taps(dy) against
+    torch autograd of the composed ops (Our_UNet/models/unet.py:219-231)."""
+    N, h, w, Cx, Cout, act = case
+    x = rnd(N, Cx, h, w, seed=1)
+    coef = coeffs(N, Cx, 60) if act else None
+    dy = rnd(N, Cout, 2 * h, 2 * w, seed=2)
+    wt = rnd(Cout, Cx + 32, 3, 3, seed=3, scale=0.1)     # the up operand is the first Cx channels
+    a = (act_ref(x, *coef) if coef else x.double()).requires_grad_(True)
+    wr = wt[:, :Cx].double().requires_grad_(True)
+    up = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=False)
+    F.conv2d(up, wr, None, padding=1).backward(dy.double())
+    D = ua.ops.upsample2x_bwd_taps(to_nhwc(dy))
+    assert D.shape == (N, h, w, 9 * Cout)
+    dw = torch.full((Cout, Cx + 32, 3, 3), 7.0, device=DEV)
+    ua.ops.conv3x3_up_bwd_weight(make_src(ua, x, coef), SLOPE, D, dw, 0)
+    check(dw[:, :Cx].cpu(), wr.grad, 3e-5, "dw (up operand)")
+    assert torch.all(dw[:, Cx:] == 7.0)
+    _, wd = ua.ops.pack_conv3x3_weights(wt.to(DEV))
+    g = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx)
+    check(from_nhwc(g), a.grad, 3e-5, "dL/da (low resolution)")
+    g2 = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx, out=g.clone(), accumulate=True)
+    check(from_nhwc(g2), 2 * a.grad, 3e-5, "accumulate")

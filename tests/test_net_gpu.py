@@ -47,9 +47,10 @@ def unpack_argmax(g, shape):
     return (bits[:, 0] * 2 + bits[:, 1]).reshape(shape).astype(np.uint8)
 
 
-def run_golden(ua, g, full, precision="fp32"):
+def run_golden(ua, g, full, precision="fp32", fused=True):
     model, sd0, img, tgt = build(ua, g)
     model.matmul_precision = precision
+    model.fused_pipeline = fused
     n, hw = int(g["n"]), int(g["hw"])
     names = [str(s) for s in g["param_names"]]
     assert names == [k for k, _ in model.named_parameters()]
@@ -105,7 +106,9 @@ def run_golden(ua, g, full, precision="fp32"):
                 # the reference's own fp32 run deviates from fp64 by 1e-3..1.5e-2 of max|g| at
                 # 512x512 (profiles/r01_grad_accuracy_vs_fp64_512.txt): LeakyReLU tie flips
                 tol = 1e-2 * max(ref_s.abs().max().item(), ref_norm / gk.numel() ** 0.5)
-                if (err > tol).sum().item() > 3 or err.max().item() > 20 * tol:
+                # at most 10 % of the samples beyond tol (tie flips), none beyond 5 tol; the
+                # element-by-element check is test_tie_free_network_gradients_per_element
+                if (err > tol).sum().item() > 0.1 * err.numel() or err.max().item() > 5 * tol:
                     bad.append(f"{k}: sampled grad err {err.max().item():.3e} (tol {tol:.3e})")
             assert not bad, "\n".join(bad)
             opt.step()
@@ -137,12 +140,61 @@ def test_net512_golden(ua, golden):
 
 
 @pytest.mark.parametrize("fixture,full", [("net64", True), ("net512", False)])
+def test_golden_on_the_standalone_pipeline(ua, golden, fixture, full):
+    """`fused_pipeline = False`: separate statistics / apply passes, activated tensors in HBM
+    (the pipeline the bf16 / bf16x3 operand modes use) against the same reference fixtures."""
+    run_golden(ua, golden(fixture), full=full, fused=False)
+
+
+@pytest.mark.parametrize("fixture,full", [("net64", True), ("net512", False)])
 def test_golden_in_split_bf16_mode(ua, golden, fixture, full):
     """matmul_precision="bf16x3" (fp32 operands as three bf16 terms, six products on the bf16
     matrix cores, fp32 accumulation) is held to the SAME reference fixtures and tolerances as
     the fp32 matrix-core path: 1e-4 on logits, bit-exact argmax off the tie pixels, gradients,
     loss and first update."""
     run_golden(ua, golden(fixture), full=full, precision="bf16x3")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_tie_free_network_gradients_per_element(ua, golden, fused):
+    """Whole-network gradients held element by element.  With nonlin_kwargs negative_slope = 1.0
+    the reference's LeakyReLU is the identity, so there are no activation ties whose fp32 branch
+    could flip: every one of the 90 gradient tensors must agree with the reference fixture
+    (tests/golden/net64_slope1.npz, recorded from Our_UNet/models/unet.py) on its 256 recorded
+    entries and with the oracle on EVERY entry to 1e-4 of the tensor's max magnitude.  (The
+    LeakyReLU branch itself is covered by the kernel tests and the default-slope goldens.)"""
+    g = golden("net64_slope1")
+    n, hw = int(g["n"]), int(g["hw"])
+    sd0 = O.fill_state_dict(int(g["seed_w"]))
+    model = ua.UNet(nonlin_kwargs={"negative_slope": 1.0, "inplace": True})
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    model.fused_pipeline = fused
+    img, tgt = O.synthetic_batch(int(g["seed_x"]), n, hw, hw)
+    masks = O.draw_dropout_masks(int(g["seed_drop"]), n)
+    model.dropout_mask_override = masks
+    logits = model(img.to(DEV))
+    loss = ua.get_loss_function()(logits, tgt.to(DEV))
+    loss.backward()
+    assert relerr(logits, torch.from_numpy(g["train_logits"])) <= 1e-4
+    assert abs(loss.item() - float(g["loss_0"])) <= 2e-4 * abs(float(g["loss_0"]))
+    osd = O.leaf_state_dict(sd0)
+    _, _, ograds = O.train_step(osd, [None] * len(osd), img, tgt, masks, slope=1.0)
+    bad = []
+    for i, (k, p) in enumerate(model.named_parameters()):
+        ref_norm = float(g[f"gnorm_{i}"])
+        gk = p.grad.reshape(-1).cpu()
+        if ref_norm < 1e-4:      # conv biases under InstanceNorm: exact 0 up to rounding
+            if gk.double().norm().item() >= 1e-3:
+                bad.append(f"{k}: should be ~0")
+            continue
+        scale = ograds[k].abs().max().item()
+        e_all = (gk - ograds[k].reshape(-1)).abs().max().item() / scale
+        idx = torch.from_numpy(sample_idx(gk.numel(), k=256))
+        e_fix = (gk[idx] - torch.from_numpy(g[f"gsamp_{i}"])).abs().max().item() / scale
+        if e_all > 1e-4 or e_fix > 1e-4 or abs(gk.double().norm().item() - ref_norm) > 1e-4 * ref_norm:
+            bad.append(f"{k}: every-element err {e_all:.2e}, fixture entries {e_fix:.2e}")
+    assert not bad, "\n".join(bad)
 
 
 def test_net_vs_oracle_random_init(ua):
@@ -352,7 +404,7 @@ def test_clip_unet_golden(ua, golden):
         ref_s = torch.from_numpy(g[f"gsamp_{i}"])
         err = (gk[idx].cpu() - ref_s).abs()
         tol = 1e-2 * max(ref_s.abs().max().item(), ref_norm / gk.numel() ** 0.5)
-        if (err > tol).sum().item() > 3 or err.max().item() > 20 * tol:
+        if (err > tol).sum().item() > 0.1 * err.numel() or err.max().item() > 5 * tol:
             bad.append(f"{k}: sampled grad err {err.max().item():.3e} (tol {tol:.3e})")
     assert not bad, "\n".join(bad)
     # one optimizer step through the flat arena (94 tensors)

@@ -245,14 +245,51 @@ def clip_run():
     print("clip64.npz written, loss", loss.item())
 
 
+def slope1_run():
+    """The reference UNet built with nonlin_kwargs = {negative_slope: 1.0} (LeakyReLU becomes the
+    identity): a network without activation ties, whose gradients every fp32 implementation
+    reproduces element by element.  One train-mode step at 64x64: logits, loss, gradient norms
+    and 256 sampled entries per tensor (tests hold them to 1e-4, not to the tie-flip noise)."""
+    n, hw = 2, 64
+    sd0 = O.fill_state_dict(SEED_W)
+    img, tgt = O.synthetic_batch(SEED_X, n, hw, hw)
+    model = RefUNet(nonlin_kwargs={"negative_slope": 1.0, "inplace": True})
+    model.load_state_dict(sd0)
+    model.train()
+    torch.manual_seed(SEED_DROP)
+    logits = model(img)
+    loss = RefLoss()(logits, tgt)
+    loss.backward()
+    masks = O.draw_dropout_masks(SEED_DROP, n)
+    osd = O.leaf_state_dict(sd0)
+    oloss, ologits, ograds = O.train_step(osd, [None] * len(osd), img, tgt, masks, slope=1.0)
+    assert torch.equal(ologits, logits.detach()), "oracle slope-1 logits != reference"
+    assert torch.equal(oloss, loss.detach()), "oracle slope-1 loss != reference"
+    out = dict(seed_w=SEED_W, seed_x=SEED_X, seed_drop=SEED_DROP, n=n, hw=hw,
+               train_logits=npf(logits), loss_0=npf(loss))
+    names = [k for k, _ in model.named_parameters()]
+    for i, (k, p) in enumerate(model.named_parameters()):
+        assert torch.equal(ograds[k], p.grad), f"oracle slope-1 grad {k} != reference"
+        gk = p.grad.reshape(-1)
+        out[f"gnorm_{i}"] = np.float64(gk.double().norm().item())
+        out[f"gsamp_{i}"] = npf(gk[torch.from_numpy(sample_idx(gk.numel(), k=256))])
+    out["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "net64_slope1.npz"), **out)
+    print("net64_slope1.npz written, loss", loss.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-slope1", action="store_true")
     ap.add_argument("--skip-512", action="store_true")
     ap.add_argument("--only-clip", action="store_true")
     args = ap.parse_args()
     if args.only_clip:
         os.makedirs(OUT, exist_ok=True)
         clip_run()
+        return
+    if args.only_slope1:
+        slope1_run()
         return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -261,6 +298,7 @@ def main():
     if not args.skip_512:
         net_run(512, 2, 3, "net512", full_logits=False)
     clip_run()
+    slope1_run()
 
 
 if __name__ == "__main__":

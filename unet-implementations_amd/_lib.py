@@ -20,6 +20,15 @@ _f = _c.c_float
 _sz = _c.c_size_t
 _i64 = _c.c_int64
 
+
+
+class ActSrc(ctypes.Structure):
+    """`unet_act_src` of include/unet_hip.h: an operand activated on load."""
+    _fields_ = [("x", _p), ("C", _i), ("alpha", _p), ("beta", _p)]
+
+
+_ps = _c.POINTER(ActSrc)
+
 # name -> (restype, argtypes); mirrors include/unet_hip.h one to one
 SIGNATURES = {
     "unet_last_error": (_c.c_char_p, []),
@@ -66,6 +75,17 @@ SIGNATURES = {
     "unet_preprocess_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _p]),
     "unet_sgd_nesterov_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
     "unet_add_inplace": (_i, [_p, _p, _i64, _p]),
+    "unet_conv_in_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "unet_conv_in_fwd": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
+                              _sz, _i, _i, _i, _i, _p]),
+    "unet_conv_in_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
+    "unet_upsample2x_bwd_taps": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_up_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "unet_conv3x3_up_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_up_bwd_data": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_head1x1_in_fwd": (_i, [_ps, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "unet_head1x1_in_bwd": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _p]),
 }
 
 _lib = None
@@ -104,7 +124,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.unet_abi_version() != 1:
+    if handle.unet_abi_version() != 2:
         raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

@@ -41,6 +41,37 @@ void unet_set_error(const char* fmt, ...);
     }                                                                          \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device setting: remember it per (kernel
+// instantiation, device).  `done` is a function-local static of the launcher; setting the
+// attribute twice from two threads is harmless.
+#include <atomic>
+static inline hipError_t unet_set_max_dyn_lds(const void* kern, size_t bytes,
+                                              std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  return e;
+}
+#define UNET_SET_DYN_LDS(kern, bytes)                                                   \
+  do {                                                                                  \
+    static std::atomic<unsigned long long> done__{0};                                   \
+    UNET_HIP_CALL(unet_set_max_dyn_lds(reinterpret_cast<const void*>(kern), bytes, done__)); \
+  } while (0)
+
+// ---- library-internal entry points shared between translation units (instnorm.hip) ----------
+int unet_in_finalize_tiles(const void* partial, int tiles, int px_per_tile, const float* gamma,
+                           const float* beta, float eps, const float* mask, float* mean,
+                           float* rstd, float* alpha, float* beta2, int N, int HW, int C,
+                           hipStream_t stream);
+int unet_in_stats_masked(const float* y, const float* gamma, const float* beta, float eps,
+                         const float* mask, float* mean, float* rstd, float* alpha, float* beta2,
+                         void* workspace, size_t workspace_bytes, int N, int HW, int C,
+                         hipStream_t stream);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }

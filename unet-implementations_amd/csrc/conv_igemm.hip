@@ -23,7 +23,13 @@ namespace unet_conv {
 namespace {
 
 
-template <int BM, int BN, int WM, int WN, int BK>
+// FUSED (the fused layer pipeline, see IgemmParams): the A rows are raw convolution outputs and
+// the producing layer's InstanceNorm + LeakyReLU + dropout is applied between the buffer load
+// and the LDS write (per tap: a pixel is re-activated for each tap that stages it); with
+// p.stats the epilogue emits the tile's per-column (mean, M2); the statistics need every tile
+// inside ONE image (Hl*Wl % BM == 0, checked by the dispatcher), the activation does not (each
+// staged row carries its own image's coefficients).
+template <int BM, int BN, int WM, int WN, int BK, bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int LDA = BK + 4;  // 144-B (80-B) rows: conflict-free ds_read_b128 across 16 rows
   constexpr int SEGS = BK / 4;         // 16-B segments per tile row
@@ -53,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   // ---- loaders: thread -> (row lrow + 32*i, 16-B segment lseg) for both tiles ----
   const int lrow = tid / SEGS, lseg = tid % SEGS;
   int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
+  int a_img[FUSED ? A_PASSES : 1];   // FUSED: image of each staged row (its coefficient row)
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + lrow + ROWS * i;
@@ -64,10 +71,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
       a_nb[i] = n * p.Hin * p.Win;
       a_iy[i] = a * p.sin;
       a_ix[i] = b * p.sin;
+      if (FUSED) a_img[i] = n;
     } else {
       a_nb[i] = 0;
       a_iy[i] = -(1 << 24);
       a_ix[i] = 0;
+      if (FUSED) a_img[i] = 0;
     }
   }
   // Buffer descriptors: out-of-range lanes (zero padding, rows past M) get an offset beyond
@@ -93,6 +102,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
 
   const int KS = p.ntaps * (Ktot / BK);
 
+  // FUSED: coefficients of this thread's four channels per staged row, in-image flags
+  constexpr int CP = FUSED ? A_PASSES : 1;
+  f32x4 ca[CP], cb[CP];
+  float cs = 1.f;
+  unsigned okm = 0;
   auto load_tiles = [&](int t, int chunk) {
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
@@ -101,12 +115,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     const int c = chunk * BK;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
-    const int Cs = first ? p.C0 : p.C1;
-    const int coff = (first ? c : c - p.C0) + lseg * 4;
+    const int Cs = first ? (p.src0_pitch ? p.src0_pitch : p.C0) : p.C1;
+    const int coff = (first ? c : c - p.C0) + lseg * 4 + wt * p.tap_cstride;
+    if (FUSED) {
+      const float* al = first ? p.act0_alpha : p.act1_alpha;
+      const float* be = first ? p.act0_beta : p.act1_beta;
+      if (al) {   // uniform
+#pragma unroll
+        for (int i = 0; i < CP; ++i) {
+          ca[i] = *reinterpret_cast<const f32x4*>(al + (size_t)a_img[i] * Cs + coff);
+          cb[i] = *reinterpret_cast<const f32x4*>(be + (size_t)a_img[i] * Cs + coff);
+        }
+        cs = p.slope;
+      } else {    // plain source: z = v, slope 1 = identity
+#pragma unroll
+        for (int i = 0; i < CP; ++i) {
+          ca[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+          cb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        cs = 1.f;
+      }
+      okm = 0;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
       const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      if (FUSED) okm |= (ok ? 1u : 0u) << i;
       // invalid lanes get bit 31 set: beyond num_records (< 2 GiB), the load returns 0
       const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
                            (ok ? 0u : 0x80000000u);
@@ -124,7 +159,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
     float* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
     float* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[i];
+    for (int i = 0; i < A_PASSES; ++i) {
+      if (FUSED) ra[i] = act4(ra[i], ca[i], cb[i], cs, (okm >> i) & 1u);
+      *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[i];
+    }
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + ROWS * j * LDA) = rb[j];
   };
@@ -227,19 +265,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
       store_block16(o, acc[m][n], bv, p.accumulate);
     }
   }
+  if (FUSED && p.stats) {   // uniform; the K loop ended on a barrier: the A tiles are free scratch
+    constexpr int WAVES_M = BM / WM;
+    float2* red = reinterpret_cast<float2*>(As);
+    static_assert(WAVES_M * BN * 2 <= 2 * A_TILE, "stats scratch fits in the A tiles");
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = n0 + wn0 + n * 32 + li;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][n][r] + bv; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
+    {
+      const int img = m0 / HlWl;   // the whole tile lies in this image (dispatcher check)
+      p.stats[((size_t)img * p.stats_tiles + (m0 - img * HlWl) / BM) * p.Ncols + n0 + tid] = out;
+    }
+  }
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32>
+template <int BM, int BN, int WM, int WN, int BK = 32, bool FUSED = false>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDA = BK + 4;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * LDA * sizeof(float);
-  static bool attr_set = false;
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, FUSED>;
+  UNET_SET_DYN_LDS(kern, lds);
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
@@ -256,7 +307,8 @@ int launch_igemm(const IgemmParams& p, hipStream_t stream) {
 // taps kx through row shifts 0/1/2 of the fragment reads; three [BN][32] weight tiles ride
 // along.  3x less A traffic and 3x fewer barriers per MFMA than the per-tap K loop.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool PW>
+// FUSED: activation on load + statistics epilogue of the fused layer pipeline (IgemmParams).
+template <int BM, int BN, int WM, int WN, bool PW, bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams p, int ntiles) {
   // PW (persistent weights): Ktot == 32, so all nine [BN][32] weight tiles are loaded into LDS
   // once per workgroup and only the A rows stream through the double buffer.
@@ -271,6 +323,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * A_TILE;   // PW: [3 ky][3 shifts][BN][LDA], else 2 x [3 shifts][BN][LDA]
+  // FUSED: scratch of the statistics epilogue behind the pipeline buffers
+  float2* red = reinterpret_cast<float2*>(Bs + (PW ? 3 : 2) * B_TILE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -325,6 +379,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
   }
 
   f32x4 ra[A_PASSES], rb[BP];
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};   // FUSED: this thread's channels
+  float cs = 1.f;
+  unsigned okm = 0;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -348,11 +405,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
     const int y = y0 + (flip ? 1 - ky : ky - 1);
     const bool yok = (unsigned)y < (unsigned)p.Hin;
     const int rowbase = (img * p.Hin + y) * p.Win;
+    if (FUSED) {
+      const float* al = first ? p.act0_alpha : p.act1_alpha;
+      const float* be = first ? p.act0_beta : p.act1_beta;
+      if (al) {   // uniform
+        ca = *reinterpret_cast<const f32x4*>(al + (size_t)img * Cs + coff);
+        cb = *reinterpret_cast<const f32x4*>(be + (size_t)img * Cs + coff);
+        cs = p.slope;
+      } else {    // plain source: z = v, slope 1 = identity
+        ca = f32x4{1.f, 1.f, 1.f, 1.f};
+        cb = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = 1.f;
+      }
+      okm = 0;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int r = lrow + 32 * i;
       const int x = x0 - 1 + r;
       const bool ok = yok && r < AR && (unsigned)x < (unsigned)p.Win;
+      if (FUSED) okm |= (ok ? 1u : 0u) << i;
       const unsigned off = ((unsigned)((rowbase + x) * Cs + coff) * 4u) | (ok ? 0u : 0x80000000u);
       ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
@@ -366,8 +438,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
     float* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
     float* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i)
+    for (int i = 0; i < A_PASSES; ++i) {
+      if (FUSED) ra[i] = act4(ra[i], ca, cb, cs, (okm >> i) & 1u);
       if (32 * (i + 1) <= AR || lrow + 32 * i < AR) *reinterpret_cast<f32x4*>(Ab + 32 * i * LDA) = ra[i];
+    }
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + 32 * j * LDA) = rb[j];
   };
@@ -437,6 +511,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
     }
     // tile epilogue (stores drain while the next tile's K steps run)
     const int m0 = tile * BM;
+    if (FUSED && p.stats) {   // uniform.  `red` is rewritten one tile (>= 3 barriers) later
+      constexpr int WAVES_M = BM / WM;
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const float bv = p.bias ? p.bias[wn0 + n * 32 + li] : 0.f;
+        const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][n][r] + bv; });
+        if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+      }
+      float2 out;
+      if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out)) {
+        const int img = m0 / HW;
+        p.stats[((size_t)img * p.stats_tiles + (m0 - img * HW) / BM) * p.Ncols + tid] = out;
+      }
+    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = wn0 + n * 32 + li;
@@ -457,20 +545,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool PW>
-int launch_igemm_rf(const IgemmParams& p, int flip, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, bool PW, bool FUSED = false>
+int launch_igemm_rf(const IgemmParams& p, int flip, hipStream_t stream, int* stats_px = nullptr) {
   constexpr int LDA = 36;
-  constexpr size_t lds = PW ? (size_t)(2 * (BM + 2) + 9 * BN) * LDA * sizeof(float)
-                            : 2 * (size_t)((BM + 2) + 3 * BN) * LDA * sizeof(float);
-  static bool attr_set = false;
-  auto kern = conv_igemm_rf_kernel<BM, BN, WM, WN, PW>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  constexpr size_t lds = (PW ? (size_t)(2 * (BM + 2) + 9 * BN) * LDA * sizeof(float)
+                             : 2 * (size_t)((BM + 2) + 3 * BN) * LDA * sizeof(float)) +
+                         (FUSED ? (size_t)(BM / WM) * BN * sizeof(float2) : 0);
+  auto kern = conv_igemm_rf_kernel<BM, BN, WM, WN, PW, FUSED>;
+  UNET_SET_DYN_LDS(kern, lds);
   IgemmParams q = p;
   q.sin = flip;
+  if (FUSED && stats_px) {
+    if (q.stats) { *stats_px = BM; q.stats_tiles = p.Hin * p.Win / BM; }
+    else *stats_px = 0;
+  }
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int ntiles = (int)(M / BM);
   const int resident = 256 * (int)((160 * 1024) / lds);   // CUs x workgroups that fit in LDS
@@ -664,12 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(const IgemmParams
 
 int launch_dgrad_s2(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)(128 + 4 * 32) * 36 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  UNET_SET_DYN_LDS(conv_dgrad_s2_kernel, lds);
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, 128) * (p.Ncols / 32);
   hipLaunchKernelGGL(conv_dgrad_s2_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, p);
@@ -679,12 +762,32 @@ int launch_dgrad_s2(const IgemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int dispatch_igemm(const IgemmParams& p, hipStream_t stream) {
+// stats_px != nullptr: the fused-layer call (activation on load; statistics epilogue into
+// p.stats when every tile lies inside one image, reported as *stats_px = pixels per statistics
+// tile, else *stats_px = 0 and the caller runs the stand-alone statistics kernel).
+template <int BM, int BN, int WM, int WN>
+static int launch_igemm_fused(IgemmParams p, hipStream_t stream, int* stats_px) {
+  const int HlWl = p.Hl * p.Wl;
+  const bool direct = p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout;
+  if (direct && p.stats && HlWl % BM == 0) { *stats_px = BM; p.stats_tiles = HlWl / BM; }
+  else { *stats_px = 0; p.stats = nullptr; }
+  return launch_igemm<BM, BN, WM, WN, 32, true>(p, stream);
+}
+
+int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   if (patch_f32_applicable(p)) {   // conv_patch.hip; 1 = no tile shape fits this launch
-    const int rc = launch_patch_f32_auto(p, stream);
+    const int rc = launch_patch_f32_auto(p, stream, stats_px);
     if (rc != 1) return rc;
+  }
+  if (stats_px) {
+    if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+      return launch_igemm_fused<128, 128, 64, 64>(p, stream, stats_px);
+    if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+      return launch_igemm_fused<128, 64, 64, 32>(p, stream, stats_px);
+    if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_fused<64, 64, 32, 32>(p, stream, stats_px);
+    return launch_igemm_fused<128, 32, 32, 32>(p, stream, stats_px);
   }
   // Largest tile that still yields >= 256 workgroups (one per CU); otherwise the
   // small 64x64 tile.
@@ -782,9 +885,11 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const float* __
                                                                  const float* __restrict__ wf,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ y, int N,
-                                                                 int H, int W, int Cout) {
+                                                                 int H, int W, int Cout,
+                                                                 float2* __restrict__ stats) {
   __shared__ float Rw[3 * STEM_ROW_PITCH];
   __shared__ float B[28 * 32];
+  __shared__ float2 red[4 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int HW = H * W;
@@ -823,6 +928,13 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const float* __
     const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     y[(size_t)(m0 + row) * Cout + co0 + li] = acc[r] + bv;
   }
+  if (stats) {   // fused layer pipeline: (mean, M2) of this 128-pixel tile per output column
+    const float2 mine = wave_col_stats<1>([&](int, int r) { return acc[r] + bv; });
+    if (lh == 0) red[wave * 32 + li] = mine;
+    float2 out;
+    if (block_col_stats<32, 4>(red, 0, 0, false, float2{0.f, 0.f}, 32.f, out))
+      stats[((size_t)n * (HW / STEM_ROW_PIX) + rem / STEM_ROW_PIX) * Cout + co0 + tid] = out;
+  }
 }
 
 void fill_fwd_taps(IgemmParams& p, int stride) {
@@ -854,7 +966,7 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
     if (W % STEM_ROW_PIX == 0) {
       dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
       hipLaunchKernelGGL(conv_stem_fwd_rows_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N,
-                         H, W, Cout);
+                         H, W, Cout, (float2*)nullptr);
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
       hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N, H,
@@ -1063,5 +1175,165 @@ extern "C" int unet_conv1x1_bwd_data(const float* dy, const float* wT, int Cin_t
   p.Ncols = Ccols; p.sin = 1; p.sout = 1; p.py = p.px = 0;
   p.ntaps = 1; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
   set_tap(p, 0, 0, 0, 0);
+  return dispatch_igemm(p, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// Fused layer forward (include/unet_hip.h "fused layer pipeline"): convolution with the
+// producing layers' InstanceNorm + LeakyReLU + dropout applied to the operands on load and the
+// InstanceNorm statistics of the output emitted from the epilogue.
+// Replaces Conv2d + InstanceNorm2d of ConvBlock (Our_UNet/models/unet.py:101-134).
+// ---------------------------------------------------------------------------
+namespace {
+// statistics tiles hold at least 64 pixels (the smallest gather-GEMM tile)
+size_t stats_partial_bytes(int N, int HoWo, int Cout) {
+  return align_up((size_t)N * (size_t)ceil_div(HoWo, 64) * Cout * sizeof(float2), 256);
+}
+// largest batch chunk whose per-source tensors stay below the 2 GiB buffer-descriptor range
+int batch_chunk(int N, long long per_image_bytes) {
+  const long long lim = (1LL << 31) - 1;
+  long long n = lim / (per_image_bytes > 0 ? per_image_bytes : 1);
+  if (n < 1) n = 0;
+  return (int)(n < N ? n : N);
+}
+}  // namespace
+
+extern "C" size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || stride < 1) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const size_t a = stats_partial_bytes(N, Ho * Wo, Cout);
+  const size_t b = unet_instnorm_workspace_bytes(N, Ho * Wo, Cout);
+  return a > b ? a : b;
+}
+
+extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                                const float* w, const float* bias, int ksize, int stride, float* y,
+                                const float* gamma, const float* beta, float eps,
+                                const float* mask, float* mean, float* rstd, float* alpha_out,
+                                float* beta_out, void* workspace, size_t workspace_bytes, int N,
+                                int H, int W, int Cout, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(s0 && s0->x && w && y && mean && rstd && workspace, "conv_in_fwd: null pointer");
+  UNET_REQUIRE(ksize == 3 || ksize == 1, "conv_in_fwd: kernel size %d unsupported", ksize);
+  UNET_REQUIRE(stride == 1 || (stride == 2 && ksize == 3), "conv_in_fwd: stride %d unsupported",
+               stride);
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0, "conv_in_fwd: bad shape");
+  UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv_in_fwd: Cout %d must be a multiple of 32", Cout);
+  const int C0 = s0->C, C1 = s1 ? s1->C : 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (workspace_bytes < unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, stride)) {
+    unet_set_error("conv_in_fwd: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  int stats_px = 0;
+  if (C0 == 3) {   // RGB stem: the image is a plain operand
+    UNET_REQUIRE(C1 == 0 && stride == 1 && ksize == 3 && !s0->alpha,
+                 "conv_in_fwd: the RGB stem is a plain stride-1 3x3 single source");
+    const long long M = (long long)N * H * W;
+    if (W % STEM_ROW_PIX == 0) {
+      dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
+      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel, grid, dim3(256), 0, stream, s0->x, w, bias, y,
+                         N, H, W, Cout, reinterpret_cast<float2*>(workspace));
+      stats_px = STEM_ROW_PIX;
+    } else {
+      dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
+      hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, s0->x, w, bias, y, N, H,
+                         W, Cout);
+    }
+    UNET_CHECK_LAUNCH("conv_stem_fwd");
+  } else {
+    UNET_REQUIRE(C0 > 0 && C0 % 32 == 0 && C1 >= 0 && C1 % 32 == 0,
+                 "conv_in_fwd: channel counts (%d,%d) must be multiples of 32", C0, C1);
+    UNET_REQUIRE(C1 == 0 || s1->x, "conv_in_fwd: second source is null with C1=%d", C1);
+    UNET_REQUIRE((!s0->alpha || s0->beta) && (!s1 || !s1->alpha || s1->beta),
+                 "conv_in_fwd: alpha without beta");
+    const int Cin = C0 + C1;
+    const int taps = ksize * ksize;
+    UNET_REQUIRE((long long)taps * Cout * Cin * 4 < (1LL << 31), "conv_in_fwd: weights exceed 2 GiB");
+    // batch chunks keep each source inside the 2 GiB buffer-descriptor range
+    const int nmax = batch_chunk(N, (long long)H * W * (C0 > C1 ? C0 : C1) * 4);
+    UNET_REQUIRE(nmax >= 1, "conv_in_fwd: one image exceeds the 2 GiB buffer-descriptor range");
+    const bool chunked = nmax < N;
+    for (int nb = 0; nb < N; nb += nmax) {
+      const int n = (N - nb) < nmax ? (N - nb) : nmax;
+      IgemmParams p{};
+      p.src0 = s0->x + (size_t)nb * H * W * C0;
+      p.src1 = s1 ? s1->x + (size_t)nb * H * W * C1 : nullptr;
+      p.C0 = C0; p.C1 = C1;
+      p.act0_alpha = s0->alpha ? s0->alpha + (size_t)nb * C0 : nullptr;
+      p.act0_beta = s0->alpha ? s0->beta + (size_t)nb * C0 : nullptr;
+      p.act1_alpha = (s1 && s1->alpha) ? s1->alpha + (size_t)nb * C1 : nullptr;
+      p.act1_beta = (s1 && s1->alpha) ? s1->beta + (size_t)nb * C1 : nullptr;
+      p.slope = slope;
+      p.w = w; p.tap_stride = Cout * Cin; p.n_off = 0; p.bias = bias;
+      p.src0_bytes = (unsigned)((long long)n * H * W * C0 * 4);
+      p.src1_bytes = (unsigned)((long long)n * H * W * C1 * 4);
+      p.w_bytes = (unsigned)((long long)taps * Cout * Cin * 4);
+      p.out = y + (size_t)nb * Ho * Wo * Cout; p.ldo = Cout; p.accumulate = 0;
+      p.N = n; p.Hin = H; p.Win = W;
+      p.Hl = p.Hout = Ho; p.Wl = p.Wout = Wo;
+      p.Ncols = Cout;
+      // the statistics epilogue needs one tile layout for the whole batch: chunked calls use
+      // the stand-alone statistics pass instead
+      p.stats = chunked ? nullptr : reinterpret_cast<float2*>(workspace);
+      int px = 0;
+      int rc;
+      if (ksize == 1) {
+        p.sin = 1; p.sout = 1; p.py = p.px = 0;
+        p.ntaps = 1; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
+        set_tap(p, 0, 0, 0, 0);
+        rc = dispatch_igemm(p, stream, &px);
+      } else {
+        fill_fwd_taps(p, stride);
+        // K = 32: row-fused kernel with the weights resident in LDS; wider K: the patch kernel
+        if (stride == 1 && rf_applicable(p) &&
+            (Cin == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
+          rc = (Cin == 32) ? launch_igemm_rf<128, 32, 32, 32, true, true>(p, 0, stream, &px)
+                           : launch_igemm_rf<128, 32, 32, 32, false, true>(p, 0, stream, &px);
+        else
+          rc = dispatch_igemm(p, stream, &px);
+      }
+      if (rc != UNET_OK) return rc;
+      stats_px = px;
+    }
+  }
+  const int HoWo = Ho * Wo;
+  if (stats_px > 0)
+    return unet_in_finalize_tiles(workspace, HoWo / stats_px, stats_px, gamma, beta, eps, mask,
+                                  mean, rstd, alpha_out, beta_out, N, HoWo, Cout, stream);
+  return unet_in_stats_masked(y, gamma, beta, eps, mask, mean, rstd, alpha_out, beta_out, workspace,
+                              workspace_bytes, N, HoWo, Cout, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Data gradient of conv3x3(upsample2x(a)) with respect to a, at LOW resolution:
+//   g[q][ci] = sum_tap sum_co D[q][tap*Cout + co] * wd[tap][ci][co]
+// (misc.hip upsample2x_bwd_taps_kernel has the derivation): a 1x1 gather-GEMM over the low-
+// resolution pixels with K = 9*Cout, i.e. a quarter of the FLOPs of the 3x3 data gradient on the
+// up-sampled grid, and it lands directly on the low-resolution tensor (no upsample2x_bwd pass).
+// ---------------------------------------------------------------------------
+extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin_total,
+                                        int ci_offset, float* g, int N, int h, int w, int Cout,
+                                        int Ccols, int accumulate, unet_stream_t stream) {
+  UNET_REQUIRE(D && wd && g, "conv3x3_up_bwd_data: null pointer");
+  UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
+                   ci_offset + Ccols <= Cin_total && N > 0 && h > 0 && w > 0,
+               "conv3x3_up_bwd_data: bad shape Cout=%d Ccols=%d slice %d of %d", Cout, Ccols,
+               ci_offset, Cin_total);
+  UNET_REQUIRE((long long)N * h * w * 9 * Cout * 4 < (1LL << 31) &&
+                   (long long)9 * Cout * Cin_total * 4 < (1LL << 31),
+               "conv3x3_up_bwd_data: tensor exceeds the 2 GiB buffer-descriptor range");
+  IgemmParams p{};
+  p.src0 = D; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
+  p.src0_pitch = 9 * Cout; p.tap_cstride = Cout;
+  p.w = wd; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
+  p.src0_bytes = (unsigned)((long long)N * h * w * 9 * Cout * 4);
+  p.src1_bytes = 0;
+  p.w_bytes = (unsigned)((long long)9 * Cout * Cin_total * 4);
+  p.out = g; p.ldo = Ccols; p.accumulate = accumulate;
+  p.N = N; p.Hin = p.Hl = p.Hout = h; p.Win = p.Wl = p.Wout = w;
+  p.Ncols = Ccols; p.sin = 1; p.sout = 1; p.py = p.px = 0;
+  p.ntaps = 9; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
+  for (int t = 0; t < 9; ++t) set_tap(p, t, 0, 0, t);
   return dispatch_igemm(p, (hipStream_t)stream);
 }

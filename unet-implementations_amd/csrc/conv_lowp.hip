@@ -441,13 +441,8 @@ int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
 template <int BM, int BN, int WM, int WN>
 int launch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * 3 * (size_t)(BM + BN) * 24 * sizeof(__bf16);
-  static bool attr_set = false;
   auto kern = conv_igemm_split_kernel<BM, BN, WM, WN>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  UNET_SET_DYN_LDS(kern, lds);
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);

@@ -33,6 +33,24 @@ struct IgemmParams {
   const __bf16* w3;
   int w3_plane;       // elements per plane
   unsigned w3_bytes;
+  // Fused layer pipeline (kernels instantiated with ACT / STATS; ignored by the others).
+  // ACT: source s holds the RAW output of the producing convolution and the loader applies
+  // that layer's InstanceNorm + LeakyReLU + channel dropout while staging it:
+  //   a = lrelu(v * act_alpha[n][c] + act_beta[n][c])   (coefficients already times the
+  //   dropout mask; zero padding stays 0).  A null pointer = the source is used as stored.
+  const float* act0_alpha; const float* act0_beta;   // [N][C0]
+  const float* act1_alpha; const float* act1_beta;   // [N][C1]
+  float slope;
+  // STATS: per-tile (mean, M2) of the output (bias included) for the InstanceNorm that
+  // follows: stats[(n * stats_tiles + tile_in_image) * Ncols + col]; every tile holds the
+  // same number of pixels of ONE image.
+  float2* stats;
+  int stats_tiles;
+  // "channel taps" (gather-GEMM only): tap t reads the source channels [t*tap_cstride + c) of a
+  // pixel whose channel pitch is src0_pitch (0 = C0): the nine D_tap tensors of the
+  // low-resolution data gradient of conv3x3(upsample2x(.)) stored as 9*Cout channels per pixel.
+  int tap_cstride;
+  int src0_pitch;
 };
 
 inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
@@ -61,12 +79,88 @@ __device__ __forceinline__ void store_block16(float* const (&o)[16], const f32x1
 }
 #endif  // __HIPCC__
 
+#ifdef __HIPCC__
+// Consumer-side activation of four channels: InstanceNorm (folded into alpha/beta) + LeakyReLU
+// with 0 <= slope <= 1 (so lrelu(z) = max(z, slope*z): no compare / select pair), written as
+// whole-vector expressions so the multiplies and the fma become v_pk_*_f32.  okf = 1 inside the
+// image, 0 for a zero-padding slot (the padding is applied AFTER the activation).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 act4f(const f32x4 v, const f32x4 al, const f32x4 be,
+                                       float slope, float okf) {
+  const f32x4 z = (v * al + be) * okf;
+  const f32x4 sz = z * slope;
+  return __builtin_elementwise_max(z, sz);
+}
+__device__ __forceinline__ f32x4 act4(const f32x4 v, const f32x4 al, const f32x4 be, float slope,
+                                      bool ok) {
+  return act4f(v, al, be, slope, ok ? 1.f : 0.f);
+}
+
+// merge two (mean, M2) summaries of `cnt` samples each into the first
+__device__ __forceinline__ void wf_merge_eq(float& mean, float& m2, float mb, float m2b,
+                                            float cnt) {
+  const float d = mb - mean;
+  mean += 0.5f * d;
+  m2 += m2b + d * d * (0.5f * cnt);
+}
+
+// (mean, M2) of the TM x 16 values val(m, r) (accumulator + bias) a lane holds for one output
+// column, merged with the partner lane (lane ^ 32 holds the other 16 rows of each 32-row
+// block): the result summarises the wave's 32*TM pixels of that column.
+template <int TM, typename F>
+__device__ __forceinline__ float2 wave_col_stats(F&& val) {
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += val(m, r);
+  float mean = s * (1.f / (16 * TM));
+  float m2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = val(m, r) - mean;
+      m2 = fmaf(d, d, m2);
+    }
+  const float mb = __shfl_xor(mean, 32, 64), qb = __shfl_xor(m2, 32, 64);
+  wf_merge_eq(mean, m2, mb, qb, 16.f * TM);
+  return float2{mean, m2};
+}
+
+// Block-level finish of the statistics epilogue: `mine` = this wave's summary (32*TM pixels) of
+// column `col_local` (0..BN-1); waves_m waves cover different pixels of the same columns.  red
+// = LDS scratch of waves_m * BN float2 that no other wave is still reading.  Thread c < BN
+// merges the waves in fixed order and returns true with the tile summary in `out`.
+template <int BN, int WAVES_M>
+__device__ __forceinline__ bool block_col_stats(float2* red, int wave_m, int col_local, bool writer,
+                                                float2 mine, float cnt_wave, float2& out) {
+  if (writer) red[wave_m * BN + col_local] = mine;
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c >= BN) return false;
+  float mean = red[c].x, m2 = red[c].y;
+  if (WAVES_M == 2) {
+    wf_merge_eq(mean, m2, red[BN + c].x, red[BN + c].y, cnt_wave);
+  } else if (WAVES_M == 4) {
+    float mean1 = red[2 * BN + c].x, m21 = red[2 * BN + c].y;
+    wf_merge_eq(mean, m2, red[BN + c].x, red[BN + c].y, cnt_wave);
+    wf_merge_eq(mean1, m21, red[3 * BN + c].x, red[3 * BN + c].y, cnt_wave);
+    wf_merge_eq(mean, m2, mean1, m21, 2.f * cnt_wave);
+  }
+  out = float2{mean, m2};
+  return true;
+}
+#endif  // __HIPCC__
+
 // ---- dispatchers implemented in the other translation units -------------------------------
 bool patch_f32_applicable(const IgemmParams& p);              // conv_patch.hip
-int launch_patch_f32_auto(const IgemmParams& p, hipStream_t stream);   // returns 1 if no tile fits
+int launch_patch_f32_auto(const IgemmParams& p, hipStream_t stream,    // returns 1 if no tile fits
+                          int* stats_px = nullptr);
 int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream);
 bool patch_split_applicable(const IgemmParams& p);
-int dispatch_igemm(const IgemmParams& p, hipStream_t stream);          // conv_igemm.hip
+int dispatch_igemm(const IgemmParams& p, hipStream_t stream,           // conv_igemm.hip
+                   int* stats_px = nullptr);
 int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream);     // conv_lowp.hip
 int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream);    // conv_lowp.hip
 

@@ -235,8 +235,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
 // buffered.  One K step = one tap = 16 k-pairs x TM x TN MFMAs per wave between barriers.
 // LDS: patch (TH+2)*34 x 144 B + weights 2 x BN x 144 B (66 KB at TH 4 / BN 128: two
 // workgroups per CU).
+// ACT: the sources hold raw convolution outputs and the previous layer's InstanceNorm +
+// LeakyReLU + dropout is applied while the patch goes from registers to LDS (once per element
+// per chunk; zero padding stays zero).  STATS: the epilogue emits the tile's per-column
+// (mean, M2) for the InstanceNorm that follows this convolution.
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParams p) {
   constexpr int BK = 32, LDA = BK + 4;
   constexpr int TW = 32, PW = TW + 2;
@@ -297,7 +301,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
     wslot_lds[j] = row * LDA + seg * 4;
   }
 
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
   f32x4 pr[P_PASSES], rb[B_PASSES];
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -307,6 +310,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
 
+  // ACT: coefficients of this thread's four channels (slot & 7 is the same for every pass)
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
   auto load_patch = [&](int chunk) {
     const int c = chunk * BK;
     const bool first = c < p.C0;
@@ -318,10 +324,27 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
       const unsigned off = ((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i];
       pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
+    if (ACT) {
+      const float* al = first ? p.act0_alpha : p.act1_alpha;
+      const float* be = first ? p.act0_beta : p.act1_beta;
+      if (al) {   // uniform
+        const size_t o = (size_t)n * Cs + (first ? c : c - p.C0) + (tid & 7) * 4;
+        ca = *reinterpret_cast<const f32x4*>(al + o);
+        cb = *reinterpret_cast<const f32x4*>(be + o);
+        cs = p.slope;
+      } else {    // plain source: z = v, slope 1 = identity
+        ca = f32x4{1.f, 1.f, 1.f, 1.f};
+        cb = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = 1.f;
+      }
+    }
   };
   auto store_patch = [&]() {
 #pragma unroll
-    for (int i = 0; i < P_PASSES; ++i) *reinterpret_cast<f32x4*>(Ps + pp_lds[i]) = pr[i];
+    for (int i = 0; i < P_PASSES; ++i) {
+      if (ACT) pr[i] = act4(pr[i], ca, cb, cs, (pp_oob[i] >> 31) == 0u);
+      *reinterpret_cast<f32x4*>(Ps + pp_lds[i]) = pr[i];
+    }
   };
   auto load_b = [&](int t, int chunk) {
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
@@ -420,43 +443,41 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
       }
     }
   }
+  if (STATS && p.stats) {   // uniform
+    // the K loop ended on a barrier: the patch area is free scratch
+    constexpr int WAVES_M = 4 / WAVES_N;
+    float2* red = reinterpret_cast<float2*>(Ps);
+    static_assert(WAVES_M * BN * 2 <= PPIX * LDA, "stats scratch fits in the patch area");
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const int col = n0 + wn0 + nb * 32 + li;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r] + bv; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
+      p.stats[((size_t)n * p.stats_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
+  }
 }
 
 template <int BN, int WM, int WN, int TH>
 int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds =
       (3 * (size_t)((TH + 2) * 34) * 24 + 2 * 3 * (size_t)BN * 24) * sizeof(__bf16);
-  static bool attr_set = false;
   auto kern = conv_patch_split_kernel<BN, WM, WN, TH>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_patch_split");
   return UNET_OK;
 }
 
-// stride-1 3x3 over an image that tiles as 4 x 32 pixels
-bool patch_split_applicable(const IgemmParams& p) {
-  static const int off = getenv("UNET_NO_PATCH") ? 1 : 0;
-  return !off && p.ntaps == 9 && p.sin == 1 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
-         p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 && p.Win % 32 == 0 &&
-         p.C0 % 16 == 0 && p.C1 % 16 == 0;
-}
-
-template <int BN, int WM, int WN, int TH>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false>
 int launch_patch_f32(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = ((size_t)((TH + 2) * 34) * 36 + 2 * (size_t)BN * 36) * sizeof(float);
-  static bool attr_set = false;
-  auto kern = conv_patch_f32_kernel<BN, WM, WN, TH>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  auto kern = conv_patch_f32_kernel<BN, WM, WN, TH, ACT, STATS>;
+  UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_patch_f32");
@@ -476,22 +497,37 @@ bool patch_split_applicable(const IgemmParams& p) {
 // the same with 32-channel chunks (fp32 form)
 bool patch_f32_applicable(const IgemmParams& p) {
   static const int off = getenv("UNET_NO_PATCH") ? 1 : 0;
-  return !off && p.ntaps == 9 && p.sin == 1 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
-         p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 && p.Win % 32 == 0 &&
-         p.C0 % 32 == 0 && p.C1 % 32 == 0;
+  return !off && p.ntaps == 9 && p.tap_cstride == 0 && p.sin == 1 && p.sout == 1 &&
+         p.Hl == p.Hin && p.Wl == p.Win && p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 &&
+         p.Win % 32 == 0 && p.C0 % 32 == 0 && p.C1 % 32 == 0;
 }
 
 // fp32: measured on the net's layers +5..19 % over the gather-GEMM at 64 and 128 columns, +8 %
 // at 32 columns when K > 32 (K = 32 stays on the row-fused kernel).  Returns 1 when no tile
 // shape fits (too few tiles): the caller falls back to the gather-GEMM.
-int launch_patch_f32_auto(const IgemmParams& p, hipStream_t stream) {
+// stats_px != nullptr selects the fused-layer instantiation (activation on load, statistics
+// epilogue into p.stats) and receives the number of pixels per statistics tile.
+int launch_patch_f32_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+  IgemmParams p = p0;
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   const long long mt = M / 128;
-  if (nc % 128 == 0 && mt * (nc / 128) >= 512) return launch_patch_f32<128, 64, 64, 4>(p, stream);
-  if (nc % 64 == 0 && mt * (nc / 64) >= 512) return launch_patch_f32<64, 64, 32, 4>(p, stream);
-  if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 512)
-    return launch_patch_f32<32, 64, 32, 8>(p, stream);
+  const bool fused = stats_px != nullptr;
+  if (nc % 128 == 0 && mt * (nc / 128) >= 512) {
+    if (!fused) return launch_patch_f32<128, 64, 64, 4>(p, stream);
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_f32<128, 64, 64, 4, true, true>(p, stream);
+  }
+  if (nc % 64 == 0 && mt * (nc / 64) >= 512) {
+    if (!fused) return launch_patch_f32<64, 64, 32, 4>(p, stream);
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_f32<64, 64, 32, 4, true, true>(p, stream);
+  }
+  if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 512) {
+    if (!fused) return launch_patch_f32<32, 64, 32, 8>(p, stream);
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_patch_f32<32, 64, 32, 8, true, true>(p, stream);
+  }
   return 1;
 }
 

@@ -15,10 +15,21 @@
 //
 // Replaces the weight-gradient half of aten::convolution_backward reached from
 // loss.backward() (Our_UNet/src/train.py:663).
-#include "common.h"
+#include "conv_params.h"
+#include <utility>
 
 namespace {
-
+using unet_conv::act4;
+template <int I> using template_ic = std::integral_constant<int, I>;
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E)
+template <int B, int... I, typename F>
+__device__ __forceinline__ void for_range_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(template_ic<B + I>{}), ...);
+}
+template <int B, int E, typename F>
+__device__ __forceinline__ void for_range(F&& f) {
+  for_range_impl<B>(std::make_integer_sequence<int, (E > B ? E - B : 0)>{}, f);
+}
 
 struct WgradParams {
   const float* x;   // [N][H][W][Cx]
@@ -29,6 +40,12 @@ struct WgradParams {
   int segs_per_row, total_segs, segs_per_block, split;
   int ci_tiles, co_tiles;
   unsigned x_bytes, dy_bytes;  // buffer-descriptor ranges (< 2 GiB each)
+  // fused layer pipeline (ACT instantiations): x holds the RAW output of the producing
+  // convolution; a = lrelu(x * alpha[n][c] + beta[n][c], slope) is applied while the patch is
+  // staged (zero padding stays zero)
+  const float* alpha;  // [N][Cx]
+  const float* beta;   // [N][Cx]
+  float slope;
 };
 
 // Workgroup = 4 waves (one per SIMD, so co-resident workgroups load every SIMD alike).
@@ -36,7 +53,7 @@ struct WgradParams {
 // sub-block w % NSB for ALL nine taps (9 accumulator blocks = 144 VGPRs) and, when NSB < 4,
 // the pixel pairs q = w / NSB (mod NPP) of each segment - its sums then go to a slab of
 // their own (slab index sp*NPP + pp), folded by the ordinary slab reduction.
-template <int CI_T, int CO_T, int S, int STRIDE>
+template <int CI_T, int CO_T, int S, int STRIDE, bool ACT = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
   constexpr int NSB = TI * TJ, NPP = 4 / NSB;
@@ -73,15 +90,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
   // patch slot: (row-1, col-1, channel); invalid slots (idx >= NP4) get row = -2^20 so the
   // bounds test fails and the buffer load returns 0
-  int p_r[NLP], p_c[NLP], p_ch[NLP];
+  // (row, column) of a slot packed into one register: row in the high half (invalid: 0x4000)
+  int p_rc[NLP];
+  const int p_ch = ci0 + (tid % (CI_T / 4)) * 4;   // NT % (CI_T/4) == 0: the same for every k
 #pragma unroll
   for (int k = 0; k < NLP; ++k) {
     const int idx = tid + NT * k;
-    const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
+    const int pix = idx / (CI_T / 4);
     const int prow = pix / PW, pcol = pix - prow * PW;
-    p_r[k] = idx < NP4 ? prow - 1 : -(1 << 20);
-    p_c[k] = pcol - 1;
-    p_ch[k] = ci0 + seg * 4;
+    p_rc[k] = ((idx < NP4 ? prow : 0x4000) << 16) | pcol;
   }
   int d_p[NLD], d_ch[NLD];
 #pragma unroll
@@ -93,28 +110,58 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 
   f32x4 rp[NLP], rd[NLD];
-  auto load_stage = [&](int g) {
+  // ACT: coefficients of this thread's four channels (the channel group of a patch slot is
+  // tid % (CI_T/4) for every k because CI_T/4 divides the block size), in-image flags
+  static_assert(NT % (CI_T / 4) == 0, "one channel group per thread");
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  unsigned okm = 0;
+
+  // Uniform cursor of the segment being LOADED: image ln, output row loy, first output column lx0.
+  int ln, loy, lx0;
+  auto set_cursor = [&](int g) {
     const int xs = g % p.segs_per_row;
     const int r = g / p.segs_per_row;
-    const int oy = r % p.Ho;
-    const int n = r / p.Ho;
-    const int x0 = xs * S;
-#pragma unroll
-    for (int k = 0; k < NLP; ++k) {
-      const int iy = oy * STRIDE + p_r[k], ix = x0 * STRIDE + p_c[k];
+    loy = r % p.Ho;
+    ln = r / p.Ho;
+    lx0 = xs * S;
+  };
+  auto advance_cursor = [&]() {   // next segment in (n, row, column) order: a few scalar ops
+    lx0 += S;
+    if (lx0 >= p.segs_per_row * S) {
+      lx0 = 0;
+      if (++loy == p.Ho) { loy = 0; ++ln; }
+    }
+  };
+  auto load_coef = [&]() {
+    if (ACT) {
+      const size_t o = (size_t)ln * p.Cx + p_ch;
+      ca = *reinterpret_cast<const f32x4*>(p.alpha + o);
+      cb = *reinterpret_cast<const f32x4*>(p.beta + o);
+      okm = 0;
+    }
+  };
+  // one loader slot of the cursor's segment: slots [0, NLP) = patch, [NLP, NLP+NLD) = dy
+  auto issue_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < NLP) {
+      const int iy = loy * STRIDE - 1 + (p_rc[k] >> 16), ix = lx0 * STRIDE - 1 + (p_rc[k] & 0xffff);
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned off = ((unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + p_ch[k]) * 4u) |
+      if (ACT) okm |= (ok ? 1u : 0u) << k;
+      const unsigned off = ((unsigned)(((ln * p.H + iy) * p.W + ix) * p.Cx + p_ch) * 4u) |
                            (ok ? 0u : 0x80000000u);
       rp[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
-    }
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const int ox = x0 + d_p[k];
+    } else {
+      constexpr int j = k - NLP;
+      const int ox = lx0 + d_p[j];
       const bool ok = ox < p.Wo;
-      const unsigned off = ((unsigned)(((n * p.Ho + oy) * p.Wo + ox) * p.Cout + d_ch[k]) * 4u) |
+      const unsigned off = ((unsigned)(((ln * p.Ho + loy) * p.Wo + ox) * p.Cout + d_ch[j]) * 4u) |
                            (ok ? 0u : 0x80000000u);
-      rd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+      rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
     }
+  };
+  auto act_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (ACT) rp[k] = act4(rp[k], ca, cb, p.slope, (okm >> k) & 1u);
   };
   auto store_stage = [&](int buf) {
     float* base = smem + buf * STAGE;
@@ -136,15 +183,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
 
+  // Schedule of one stage (= one segment, NQ pixel-pair steps of 9 MFMAs per wave).  Everything
+  // that is not an MFMA is placed by hand behind a step's MFMAs and fenced there, so it issues
+  // in the shadow of the matrix pipe instead of at the loop top / bottom:
+  //   steps [0, LQ):        the next segment's buffer loads (address arithmetic + issue)
+  //   steps [NQ-HALF, NQ):  the activation of the loaded patch slots (ACT)
+  //   after the last step:  LDS writes of the next stage, barrier.
+  constexpr int NLS = NLP + NLD;
+  constexpr int LQ = NQ >= 4 ? NQ / 4 : 1;
+  constexpr int LPER = (NLS + LQ - 1) / LQ;
+  constexpr int HALF = NQ >= 2 ? NQ / 2 : 1;
+  constexpr int APER = (NLP + HALF - 1) / HALF;
+
   if (g_begin < g_end) {
-    load_stage(g_begin);
+    set_cursor(g_begin);
+    load_coef();
+    for_range<0, NLS>(issue_slot);
+    for_range<0, NLP>(act_slot);
     store_stage(0);
     __syncthreads();
     for (int g = g_begin; g < g_end; ++g) {
       const int buf = (g - g_begin) & 1;
       // always stage (the last iteration re-stages the final segment into the idle buffer):
       // branch-free, so the compute part of a stage is one scheduling region
-      load_stage(min(g + 1, g_end - 1));
+      if (g + 1 < g_end) advance_cursor();
+      load_coef();
       const float* P = smem + buf * STAGE + wi * 32 + li;
       const float* D = smem + buf * STAGE + PATCH + wj * 32 + li;
       float a[2][3][3], b[2];
@@ -156,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
           for (int v = 0; v < 3; ++v) a[0][u][v] = P[(u * PW + xx * STRIDE + v) * CI_T];
         b[0] = D[xx * CO_T];
       }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int cur = q & 1, nxt = cur ^ 1;
-        if (q + 1 < NQ) {
+      for_range<0, NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int cur = q & 1, nxt = cur ^ 1;
+        if constexpr (q + 1 < NQ) {
           const int xx = 2 * (pp + NPP * (q + 1)) + lh;
 #pragma unroll
           for (int u = 0; u < 3; ++u)
@@ -172,19 +235,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
           for (int v = 0; v < 3; ++v)
             acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][v], b[cur], acc[u][v], 0, 0, 0);
-      }
-      // Pin the software pipeline: LDS fragment reads run one pixel pair ahead of their MFMAs,
-      // the next segment's buffer loads issue right behind the first pair (LDS writes follow;
-      // hipcc otherwise parks the loads at the end and waits for them on the spot).
-      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-      if (NQ > 1) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, NLP + NLD, 0);
-#pragma unroll
-      for (int q = 1; q < NQ; ++q) {
-        if (q + 1 < NQ) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
-      }
+        if constexpr (q < LQ)
+          for_range<q * LPER, ((q + 1) * LPER < NLS ? (q + 1) * LPER : NLS)>(issue_slot);
+        if constexpr (ACT && q >= NQ - HALF) {
+          constexpr int s0 = (q - (NQ - HALF)) * APER;
+          for_range<s0, (s0 + APER < NLP ? s0 + APER : NLP)>(act_slot);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
       store_stage(buf ^ 1);
       __syncthreads();
     }
@@ -201,6 +259,171 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[u][v][r];
       }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Weight gradient of conv3x3(upsample2x(a)) with respect to the up-sampled operand, at LOW
+// resolution (misc.hip upsample2x_bwd_taps_kernel has the derivation):
+//   dW[tap][ci][co] = sum over low-resolution pixels q of act(x)[q][ci] * D[q][tap*Cout + co].
+// Nine GEMMs that share the A operand: the blocking of conv_wgrad_kernel with the roles of
+// the operands swapped - per pixel pair ONE A fragment and nine B fragments (there: nine
+// shifted A fragments and one B fragment) - and no halo: a segment is S consecutive pixels of
+// the flattened [N*h*w] pixel list.  Same slabs / reductions as conv_wgrad_kernel.
+// WgradParams: x = the low-resolution operand [Q][Cx], dy = D [Q][9*Cout], N*H*W = Q.
+// ---------------------------------------------------------------------------
+template <int CI_T, int CO_T, int S, bool ACT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradParams p) {
+  constexpr int TI = CI_T / 32, TJ = CO_T / 32;
+  constexpr int NSB = TI * TJ, NPP = 4 / NSB;
+  static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
+  constexpr int NT = 256;
+  constexpr int BW = 9 * CO_T;             // floats per pixel of the staged D tile
+  constexpr int NA4 = S * CI_T / 4;        // float4 slots of the A segment
+  constexpr int NB4 = S * BW / 4;          // float4 slots of the D segment
+  constexpr int ATILE = NA4 * 4;
+  constexpr int STAGE = ATILE + NB4 * 4;
+  constexpr int NLA = (NA4 + NT - 1) / NT, NLB = (NB4 + NT - 1) / NT;
+  static_assert(NA4 % NT == 0 || NLA == 1, "A slots");
+  static_assert(NB4 % NT == 0, "D slots fill whole passes");
+  constexpr int NQ = (S / 2) / NPP;        // pixel pairs per wave per segment
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int sb = wave % NSB, pp = wave / NSB;
+  const int wi = sb / TJ, wj = sb - wi * TJ;
+
+  // the tiles of one pixel range run on ONE XCD (they share its D / A segments through L2)
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+  const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+  const int sp = bid;
+  const int ci0 = ci_t * CI_T, co0 = co_t * CO_T;
+  const int g_begin = sp * p.segs_per_block;
+  const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
+  const int HW = p.H * p.W;
+  const int Q = p.N * HW;
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+  // A slot: pixel a_px[k] of the segment, channels a_ch..+3; D slot: pixel, float offset in BW
+  int a_px[NLA], b_px[NLB], b_col[NLB];
+  const int a_ch = ci0 + (tid % (CI_T / 4)) * 4;
+#pragma unroll
+  for (int k = 0; k < NLA; ++k) a_px[k] = (tid + NT * k) / (CI_T / 4);
+#pragma unroll
+  for (int k = 0; k < NLB; ++k) {
+    const int idx = tid + NT * k;
+    b_px[k] = idx / (BW / 4);
+    const int f = (idx - b_px[k] * (BW / 4)) * 4;      // float offset within the 9*CO_T row
+    const int t = f / CO_T;
+    b_col[k] = t * p.Cout + co0 + (f - t * CO_T);      // channel of D's 9*Cout axis
+  }
+
+  f32x4 ra[NLA], rb[NLB];
+  f32x4 ca[NLA], cb[NLA];
+  unsigned okm = 0;
+  int lq0 = 0;   // first pixel of the segment being loaded
+  auto issue_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < NLA) {
+      const int q = lq0 + a_px[k];
+      const bool ok = q < Q && (NA4 % NT == 0 || tid < NA4);
+      const unsigned off = ((unsigned)(q * p.Cx + a_ch) * 4u) | (ok ? 0u : 0x80000000u);
+      ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+      if (ACT) {
+        const int n = ok ? q / HW : 0;
+        ca[k] = *reinterpret_cast<const f32x4*>(p.alpha + (size_t)n * p.Cx + a_ch);
+        cb[k] = *reinterpret_cast<const f32x4*>(p.beta + (size_t)n * p.Cx + a_ch);
+        okm |= (ok ? 1u : 0u) << k;
+      }
+    } else {
+      constexpr int j = k - NLA;
+      const int q = lq0 + b_px[j];
+      const bool ok = q < Q;
+      const unsigned off = ((unsigned)(q * (9 * p.Cout) + b_col[j]) * 4u) | (ok ? 0u : 0x80000000u);
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+    }
+  };
+  auto act_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (ACT) ra[k] = act4(ra[k], ca[k], cb[k], p.slope, (okm >> k) & 1u);
+  };
+  auto store_stage = [&](int buf) {
+    float* base = smem + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < NLA; ++k)
+      if (NA4 % NT == 0 || tid < NA4) *reinterpret_cast<f32x4*>(base + 4 * (tid + NT * k)) = ra[k];
+#pragma unroll
+    for (int k = 0; k < NLB; ++k)
+      *reinterpret_cast<f32x4*>(base + ATILE + 4 * (tid + NT * k)) = rb[k];
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // stage schedule as in conv_wgrad_kernel: loads behind the first steps' MFMAs, the
+  // activation behind the last steps', LDS writes + barrier at the end
+  constexpr int NLS = NLA + NLB;
+  constexpr int LQ = NQ >= 4 ? NQ / 2 : 1;
+  constexpr int LPER = (NLS + LQ - 1) / LQ;
+
+  if (g_begin < g_end) {
+    lq0 = g_begin * S;
+    for_range<0, NLS>(issue_slot);
+    for_range<0, NLA>(act_slot);
+    store_stage(0);
+    __syncthreads();
+    for (int g = g_begin; g < g_end; ++g) {
+      const int buf = (g - g_begin) & 1;
+      if (g + 1 < g_end) lq0 += S;   // the last iteration re-stages the final segment
+      okm = 0;
+      const float* A = smem + buf * STAGE + wi * 32 + li;
+      const float* B = smem + buf * STAGE + ATILE + wj * 32 + li;
+      float a[2], b[2][9];
+      {
+        const int xx = 2 * pp + lh;
+        a[0] = A[xx * CI_T];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[0][t] = B[xx * BW + t * CO_T];
+      }
+      for_range<0, NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int cur = q & 1, nxt = cur ^ 1;
+        if constexpr (q + 1 < NQ) {
+          const int xx = 2 * (pp + NPP * (q + 1)) + lh;
+          a[nxt] = A[xx * CI_T];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) b[nxt][t] = B[xx * BW + t * CO_T];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], b[cur][t], acc[t], 0, 0, 0);
+        if constexpr (q < LQ)
+          for_range<q * LPER, ((q + 1) * LPER < NLS ? (q + 1) * LPER : NLS)>(issue_slot);
+        if constexpr (ACT && q == NQ - 1) for_range<0, NLA>(act_slot);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* out = p.partial + ((size_t)((sp * NPP + pp) * 9 + t) * p.Cx) * p.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[t][r];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -695,18 +918,22 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   return pl;
 }
 
+template <int CI_T, int CO_T, int S, int STRIDE, bool ACT>
+int launch_wgrad_t(const WgradParams& p, hipStream_t stream);
+
 template <int CI_T, int CO_T, int S, int STRIDE>
 int launch_wgrad(const WgradParams& p, hipStream_t stream) {
+  if (p.alpha) return launch_wgrad_t<CI_T, CO_T, S, STRIDE, true>(p, stream);
+  return launch_wgrad_t<CI_T, CO_T, S, STRIDE, false>(p, stream);
+}
+
+template <int CI_T, int CO_T, int S, int STRIDE, bool ACT>
+int launch_wgrad_t(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = (S - 1) * STRIDE + 3;
   constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
   constexpr int NT = 256;
-  static bool attr_set = false;
-  auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE, ACT>;
+  UNET_SET_DYN_LDS(kern, lds);
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_wgrad");
@@ -717,17 +944,53 @@ template <int CI_T, int CO_T, int S, int NPL = 1, bool SB = false>
 int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = S + 2;
   constexpr size_t lds = (SB ? 1 : 2) * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
-  static bool attr_set = false;
   auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, NPL, SB>;
-  if (!attr_set) {
-    UNET_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  UNET_SET_DYN_LDS(kern, lds);
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_wgrad_bf16");
   return UNET_OK;
+}
+
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_taps(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)S * (CI_T + 9 * CO_T) * sizeof(float);
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, true>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, false>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_taps");
+  return UNET_OK;
+}
+
+// plan of the low-resolution tap GEMM: Q pixels, (Cx x Cout) channel tiles
+WgradPlan make_plan_taps(long long Q, int Cx, int Cout) {
+  WgradPlan pl{};
+  pl.ci_t = (Cx % 64 == 0) ? 64 : 32;
+  pl.co_t = (Cout % 64 == 0) ? 64 : 32;
+  if (pl.ci_t == 64 && pl.co_t == 32) pl.ci_t = 32;  // instantiated: 32x32, 32x64, 64x64
+  const int nsb = (pl.ci_t / 32) * (pl.co_t / 32);
+  pl.npp = 4 / nsb;
+  pl.S = nsb == 1 ? 32 : 16;
+  pl.segs_per_row = 0;
+  pl.total_segs = (int)ceil_div64(Q, pl.S);
+  const int tiles = (Cx / pl.ci_t) * (Cout / pl.co_t);
+  int split = ceil_div(512, tiles);
+  const int max_split = ceil_div(pl.total_segs, 4);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  pl.segs_per_block = ceil_div(pl.total_segs, split);
+  pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
+  const size_t E = (size_t)9 * Cx * Cout;
+  const int slabs = pl.split * pl.npp;
+  pl.ws_floats = (size_t)slabs * E + 2 * (size_t)ceil_div(slabs, kSlabChunk) * E;
+  return pl;
 }
 
 // db[c] = sum over pixels of dy[.][c]: 64 row chunks per 32-channel group, then the chunk sums
@@ -766,7 +1029,9 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
 static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
                                 int ci_offset, int Cin_total, float* db, void* workspace,
                                 size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
-                                bool center_only, hipStream_t stream, int prec = 0) {
+                                bool center_only, hipStream_t stream, int prec = 0,
+                                const float* act_alpha = nullptr, const float* act_beta = nullptr,
+                                float slope = 0.f) {
   UNET_REQUIRE(x && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
@@ -820,6 +1085,9 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                  "conv3x3_bwd_weight: tensor exceeds the 2 GiB buffer-descriptor range");
     p.x_bytes = (unsigned)((long long)N * H * W * Cx * 4);
     p.dy_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
+    p.alpha = act_alpha; p.beta = act_beta; p.slope = slope;
+    UNET_REQUIRE(!act_alpha || (act_beta && prec == 0),
+                 "conv_bwd_weight: activation on load is an fp32-path feature");
     int rc;
     // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
     const bool use_bf16 = prec != 0 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
@@ -939,4 +1207,81 @@ extern "C" int unet_conv3x3_bwd_weight_bf16x3(const float* x, int Cx, const floa
   return conv_bwd_weight_impl(x, Cx, dy, dw_oihw, ci_offset, Cin_total, db, workspace,
                               workspace_bytes, N, H, W, Cout, stride, false, (hipStream_t)stream,
                               3);
+}
+
+extern "C" int unet_conv_in_bwd_weight(const unet_act_src* x, float slope, const float* dy,
+                                       float* dw_oihw, int ci_offset, int Cin_total, int ksize,
+                                       int stride, void* workspace, size_t workspace_bytes, int N,
+                                       int H, int W, int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x, "conv_in_bwd_weight: null source");
+  UNET_REQUIRE(ksize == 3 || (ksize == 1 && stride == 1),
+               "conv_in_bwd_weight: kernel %d / stride %d unsupported", ksize, stride);
+  UNET_REQUIRE(x->C == 3 ? !x->alpha : x->C % 32 == 0,
+               "conv_in_bwd_weight: Cx %d unsupported (the RGB image is a plain operand)", x->C);
+  return conv_bwd_weight_impl(x->x, x->C, dy, dw_oihw, ci_offset, Cin_total, nullptr, workspace,
+                              workspace_bytes, N, H, W, Cout, stride, ksize == 1,
+                              (hipStream_t)stream, 0, x->alpha, x->beta, slope);
+}
+
+// ---- conv3x3(upsample2x(a)): weight gradient w.r.t. the up-sampled operand at low resolution
+extern "C" size_t unet_conv3x3_up_bwd_weight_workspace_bytes(int N, int h, int w, int Cx, int Cout) {
+  if (N <= 0 || h <= 0 || w <= 0 || Cx <= 0 || Cout <= 0) return 0;
+  return make_plan_taps((long long)N * h * w, Cx, Cout).ws_floats * sizeof(float);
+}
+
+extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, const float* D,
+                                          float* dw_oihw, int ci_offset, int Cin_total,
+                                          void* workspace, size_t workspace_bytes, int N, int h,
+                                          int w, int Cout, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(x && x->x && D && dw_oihw && workspace, "conv3x3_up_bwd_weight: null pointer");
+  const int Cx = x->C;
+  UNET_REQUIRE(Cx > 0 && Cx % 32 == 0 && Cout > 0 && Cout % 32 == 0 && N > 0 && h > 0 && w > 0,
+               "conv3x3_up_bwd_weight: bad shape Cx=%d Cout=%d", Cx, Cout);
+  UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_up_bwd_weight: bad ci slice");
+  UNET_REQUIRE(!x->alpha || x->beta, "conv3x3_up_bwd_weight: alpha without beta");
+  const long long Q = (long long)N * h * w;
+  UNET_REQUIRE(Q * Cx * 4 < (1LL << 31) && Q * 9 * Cout * 4 < (1LL << 31),
+               "conv3x3_up_bwd_weight: tensor exceeds the 2 GiB buffer-descriptor range");
+  const WgradPlan pl = make_plan_taps(Q, Cx, Cout);
+  if (workspace_bytes < pl.ws_floats * sizeof(float)) {
+    unet_set_error("conv3x3_up_bwd_weight: workspace %zu < %zu bytes", workspace_bytes,
+                   pl.ws_floats * sizeof(float));
+    return UNET_E_WORKSPACE;
+  }
+  float* ws = reinterpret_cast<float*>(workspace);
+  WgradParams p{};
+  p.x = x->x; p.dy = D; p.partial = ws; p.Cx = Cx; p.Cout = Cout;
+  p.N = N; p.H = h; p.W = w; p.Ho = h; p.Wo = w;
+  p.segs_per_row = 0; p.total_segs = pl.total_segs;
+  p.segs_per_block = pl.segs_per_block; p.split = pl.split;
+  p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
+  p.x_bytes = (unsigned)(Q * Cx * 4);
+  p.dy_bytes = (unsigned)(Q * 9 * Cout * 4);
+  p.alpha = x->alpha; p.beta = x->beta; p.slope = slope;
+  int rc;
+  if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
+  else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
+  else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
+  if (rc != UNET_OK) return rc;
+  const size_t E = (size_t)9 * Cx * Cout;
+  const float* cur = ws;
+  int nslab = pl.split * pl.npp;
+  float* ping = ws + (size_t)nslab * E;
+  float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
+  while (nslab > 8) {
+    const int chunks = ceil_div(nslab, kSlabChunk);
+    dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
+    hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
+                       (long long)(E / 4));
+    UNET_CHECK_LAUNCH("slab_reduce");
+    cur = ping;
+    float* t = ping; ping = pong; pong = t;
+    nslab = chunks;
+  }
+  dim3 rgrid(Cout / 32, Cx / 8);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
+                     Cout, ci_offset, Cin_total);
+  UNET_CHECK_LAUNCH("wgrad_reduce");
+  return UNET_OK;
 }

@@ -5,12 +5,12 @@
 //
 // Replaces segmentation_output (Our_UNet/models/unet.py:374-381,:430) and
 // SimpleLoss.forward + autograd (Our_UNet/models/losses.py:24-121).
-#include "common.h"
+#include "conv_params.h"
 
 namespace {
+using unet_conv::act4;
 
 constexpr int HT = 256;  // pixels per head tile
-constexpr int HLD = 33;
 
 // ------------------------------------------------------------------ head forward
 // 8 lanes per pixel, 4 channels per lane: a wave's load instruction reads 8 whole pixels
@@ -20,7 +20,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ logits, long long M,
-                                                       int HW, int K) {
+                                                       int HW, int K,
+                                                       const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta,
+                                                       float slope) {
+  // alpha != nullptr (fused layer pipeline): `a` is the raw output of the last convolution
+  // and its InstanceNorm + LeakyReLU + dropout is applied on load
   const int tid = threadIdx.x;
   const int seg = tid & 7;                       // channels 4*seg .. 4*seg+3
   f32x4 wk[4];
@@ -35,7 +40,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   for (int it = 0; it < HT / 32; ++it) {          // 32 pixels per pass of the 256 threads
     const long long m = m0 + it * 32 + (tid >> 3);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m < M) v = *reinterpret_cast<const f32x4*>(a + (size_t)m * 32 + seg * 4);
+    if (m < M) {
+      v = *reinterpret_cast<const f32x4*>(a + (size_t)m * 32 + seg * 4);
+      if (alpha) {
+        const size_t o = (size_t)(m / HW) * 32 + seg * 4;
+        v = act4(v, *reinterpret_cast<const f32x4*>(alpha + o),
+                 *reinterpret_cast<const f32x4*>(beta + o), slope, true);
+      }
+    }
     float acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -65,7 +77,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ w,
                                                        float* __restrict__ da,
                                                        float* __restrict__ partial, long long M,
-                                                       int HW, int K, long long tiles) {
+                                                       int HW, int K, long long tiles,
+                                                       const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta,
+                                                       float slope) {
   // 8 lanes per pixel, 4 channels per lane (as head_fwd_kernel): a and da move as whole pixels
   // (1 KB per wave instruction), the K logit gradients of a pixel are broadcast loads; every
   // lane keeps its own dw[k][4 channels] partial sums over the pixels it sees, merged per block
@@ -93,6 +108,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       const long long mc = m < M ? m : M - 1;
       av[it] = *reinterpret_cast<const f32x4*>(a + (size_t)mc * 32 + seg * 4);
       const long long n = mc / HW, pp = mc - n * HW;
+      if (alpha)   // uniform: the operand is a raw convolution output, activated on load
+        av[it] = act4(av[it], *reinterpret_cast<const f32x4*>(alpha + (size_t)n * 32 + seg * 4),
+                      *reinterpret_cast<const f32x4*>(beta + (size_t)n * 32 + seg * 4), slope, true);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         dv[it][k] = (k < K && m < M) ? dl[((size_t)n * K + k) * HW + pp] : 0.f;
@@ -487,7 +505,21 @@ extern "C" int unet_head1x1_fwd(const float* a, const float* w, const float* b, 
                "head1x1_fwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
   const long long M = (long long)N * HW;
   hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
-                     (hipStream_t)stream, a, w, b, logits, M, HW, K);
+                     (hipStream_t)stream, a, w, b, logits, M, HW, K, (const float*)nullptr,
+                     (const float*)nullptr, 0.f);
+  UNET_CHECK_LAUNCH("head_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_head1x1_in_fwd(const unet_act_src* x, float slope, const float* w,
+                                   const float* b, float* logits, int N, int HW, int K,
+                                   unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && w && logits, "head1x1_in_fwd: null pointer");
+  UNET_REQUIRE(x->C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0 && (!x->alpha || x->beta),
+               "head1x1_in_fwd: needs C == 32, K <= 4 (got C=%d K=%d)", x->C, K);
+  const long long M = (long long)N * HW;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
+                     (hipStream_t)stream, x->x, w, b, logits, M, HW, K, x->alpha, x->beta, slope);
   UNET_CHECK_LAUNCH("head_fwd");
   return UNET_OK;
 }
@@ -498,9 +530,31 @@ extern "C" size_t unet_head1x1_bwd_workspace_bytes(int N, int HW, int C, int K) 
   return (size_t)head_bwd_blocks(tiles) * (K * 32 + K) * sizeof(float);
 }
 
+static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w, float* da,
+                            float* dw, float* db, void* workspace, size_t workspace_bytes, int N,
+                            int HW, int C, int K, const float* alpha, const float* beta,
+                            float slope, unet_stream_t stream);
+
 extern "C" int unet_head1x1_bwd(const float* a, const float* dlogits, const float* w, float* da,
                                 float* dw, float* db, void* workspace, size_t workspace_bytes,
                                 int N, int HW, int C, int K, unet_stream_t stream) {
+  return head1x1_bwd_impl(a, dlogits, w, da, dw, db, workspace, workspace_bytes, N, HW, C, K,
+                          nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int unet_head1x1_in_bwd(const unet_act_src* x, float slope, const float* dlogits,
+                                   const float* w, float* da, float* dw, float* db,
+                                   void* workspace, size_t workspace_bytes, int N, int HW, int K,
+                                   unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && (!x->alpha || x->beta), "head1x1_in_bwd: null source");
+  return head1x1_bwd_impl(x->x, dlogits, w, da, dw, db, workspace, workspace_bytes, N, HW, x->C, K,
+                          x->alpha, x->beta, slope, stream);
+}
+
+static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w, float* da,
+                            float* dw, float* db, void* workspace, size_t workspace_bytes, int N,
+                            int HW, int C, int K, const float* alpha, const float* beta,
+                            float slope, unet_stream_t stream) {
   UNET_REQUIRE(a && dlogits && w && da && workspace, "head1x1_bwd: null pointer");
   UNET_REQUIRE(C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0,
                "head1x1_bwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
@@ -513,7 +567,7 @@ extern "C" int unet_head1x1_bwd(const float* a, const float* dlogits, const floa
   const int blocks = head_bwd_blocks(tiles);
   float* partial = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dlogits,
-                     w, da, partial, M, HW, K, tiles);
+                     w, da, partial, M, HW, K, tiles, alpha, beta, slope);
   UNET_CHECK_LAUNCH("head_bwd");
   hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(K * 32 + K), dim3(256), 0, (hipStream_t)stream,
                      partial, dw, db, blocks, K);

@@ -104,8 +104,9 @@ __global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restr
 constexpr int FL = 32;
 __global__ __launch_bounds__(32 * FL) void in_stats_finalize_kernel(
     const float2* __restrict__ partial, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ mean, float* __restrict__ rstd,
-    float* __restrict__ alpha, float* __restrict__ beta2, int N, int HW, int C, int split) {
+    const float* __restrict__ beta, float eps, const float* __restrict__ mask,
+    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ alpha,
+    float* __restrict__ beta2, int N, int HW, int C, int split) {
   __shared__ float sn[FL][33], sm[FL][33], sq[FL][33];
   const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
@@ -141,8 +142,11 @@ __global__ __launch_bounds__(32 * FL) void in_stats_finalize_kernel(
     rstd[i] = rs;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float a = g * rs;
-    if (alpha) alpha[i] = a;
-    if (beta2) beta2[i] = b - mu * a;
+    // with `mask` (the fused layer pipeline) the dropout factor m >= 0 is folded into the
+    // coefficients: lrelu(z) * m == lrelu(z * m)
+    const float mk = mask ? mask[i] : 1.f;
+    if (alpha) alpha[i] = a * mk;
+    if (beta2) beta2[i] = (b - mu * a) * mk;
   }
 }
 
@@ -389,7 +393,15 @@ extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const flo
                                    float* mean, float* rstd, float* alpha, float* beta2,
                                    void* workspace, size_t workspace_bytes, int N, int HW, int C,
                                    unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return unet_in_stats_masked(y, gamma, beta, eps, nullptr, mean, rstd, alpha, beta2, workspace,
+                              workspace_bytes, N, HW, C, (hipStream_t)stream_);
+}
+
+// stand-alone statistics pass; `mask` folds the dropout factor into alpha / beta2
+int unet_in_stats_masked(const float* y, const float* gamma, const float* beta, float eps,
+                         const float* mask, float* mean, float* rstd, float* alpha, float* beta2,
+                         void* workspace, size_t workspace_bytes, int N, int HW, int C,
+                         hipStream_t stream) {
   UNET_REQUIRE(y && mean && rstd && workspace, "instnorm_stats: null pointer");
   UNET_REQUIRE(shape_ok(N, HW, C) && C <= 1024 && kThreads % (C / 4) == 0,
                "instnorm_stats: unsupported shape N=%d HW=%d C=%d", N, HW, C);
@@ -405,8 +417,23 @@ extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const flo
                      C, split);
   UNET_CHECK_LAUNCH("in_stats");
   hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
-                     partial, gamma, beta, eps, mean, rstd, alpha, beta2, N, HW, C, split);
+                     partial, gamma, beta, eps, mask, mean, rstd, alpha, beta2, N, HW, C, split);
   UNET_CHECK_LAUNCH("in_stats_finalize");
+  return UNET_OK;
+}
+
+// Finalize per-tile (mean, M2) summaries written by a convolution's statistics epilogue:
+// partial[(n * tiles + t) * C + c], every tile holding px_per_tile pixels of image n.
+int unet_in_finalize_tiles(const void* partial, int tiles, int px_per_tile, const float* gamma,
+                           const float* beta, float eps, const float* mask, float* mean,
+                           float* rstd, float* alpha, float* beta2, int N, int HW, int C,
+                           hipStream_t stream) {
+  UNET_REQUIRE(partial && mean && rstd && tiles > 0 && tiles * px_per_tile == HW,
+               "in_finalize_tiles: %d tiles of %d pixels do not cover %d", tiles, px_per_tile, HW);
+  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
+                     reinterpret_cast<const float2*>(partial), gamma, beta, eps, mask, mean, rstd,
+                     alpha, beta2, N, HW, C, tiles);
+  UNET_CHECK_LAUNCH("in_stats_finalize(tiles)");
   return UNET_OK;
 }
 

@@ -1,7 +1,7 @@
 // misc.hip — layout conversion, weight packing, bilinear 2x up-sampling,
 // SGD-Nesterov and the library-level entry points (error string, version).
 // All kernels here are HBM-bound streaming kernels (float4 per lane).
-#include "common.h"
+#include "conv_params.h"
 
 static thread_local char g_err[512] = "";
 
@@ -204,9 +204,14 @@ __device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float
   w0 = 1.f - w1;
 }
 
+// alpha != nullptr (fused layer pipeline): x is a raw convolution output; its InstanceNorm +
+// LeakyReLU + dropout is applied to each of the four taps before they are blended.
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x,
                                                              float* __restrict__ y, int h, int w,
-                                                             int C, long long total4) {
+                                                             int C, long long total4,
+                                                             const float* __restrict__ alpha,
+                                                             const float* __restrict__ beta,
+                                                             float slope) {
   const int lpp = C >> 2;
   const int H2 = 2 * h, W2 = 2 * w;
   const long long stride = (long long)gridDim.x * 256;
@@ -222,10 +227,18 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
     up_taps(oy, h, y0, y1, wy0, wy1);
     up_taps(ox, w, x0, x1, wx0, wx1);
     const float* b = x + (size_t)n * h * w * C + c;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x0) * C);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x1) * C);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x0) * C);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x1) * C);
+    f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x0) * C);
+    f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x1) * C);
+    f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x0) * C);
+    f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x1) * C);
+    if (alpha) {   // uniform
+      const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * C + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (size_t)n * C + c);
+      v00 = unet_conv::act4(v00, al, be, slope, true);
+      v01 = unet_conv::act4(v01, al, be, slope, true);
+      v10 = unet_conv::act4(v10, al, be, slope, true);
+      v11 = unet_conv::act4(v11, al, be, slope, true);
+    }
     const f32x4 o = (v00 * wx0 + v01 * wx1) * wy0 + (v10 * wx0 + v11 * wx1) * wy1;
     *reinterpret_cast<f32x4*>(y + i * 4) = o;
   }
@@ -271,6 +284,93 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     f32x4* o = reinterpret_cast<f32x4*>(gx + i * 4);
     if (accumulate) acc += *o;
     *o = acc;
+  }
+}
+
+// ---- backward of conv3x3(upsample2x(a)) at LOW resolution -----------------------------------
+// The bilinear up-sampling U is linear, so for y = conv3x3(U a) (zero padding):
+//   dW[tap]  = sum_p (U a)[p + tap] (x) dy[p]            =  sum_q a[q] (x) D_tap[q]
+//   dL/da[q] = U^T sum_tap W_tap^T shift_tap(dy)          =  sum_tap W_tap^T D_tap[q]
+// with  D_tap = U^T shift_tap(dy)   (shift_tap(dy)[P] = dy[P - off_tap], zero outside the image),
+// i.e. both gradients are plain GEMMs over the LOW-resolution pixels q (a quarter of the
+// positions: 1/4 of the FLOPs of running the 3x3 weight / data gradient on the up-sampled
+// tensor) once dy has been reduced to the nine tensors D_tap.  This kernel writes
+// D[n][i][j][tap * C + c] (9C channels per low-resolution pixel) from dy[n][2h][2w][C].
+// One thread = one low-resolution pixel x 4 channels: 6 x 6 dy pixels in, 9 x 4 sums out.
+__global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const float* __restrict__ dy,
+                                                                  float* __restrict__ D, int h,
+                                                                  int w, int C, long long total4) {
+  const int lpp = C >> 2;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += stride) {
+    const long long pix = i4 / lpp;
+    const int c = (int)(i4 - pix * lpp) * 4;
+    const int j = (int)(pix % w);
+    const long long r = pix / w;
+    const int i = (int)(r % h);
+    const long long n = r / h;
+    // 1-D transposed stencil of low index i: up rows 2i-1, 2i, 2i+1, 2i+2 with these weights
+    // (0 where the row does not exist or does not touch x[i])
+    float wy[4], wx[4];
+    wy[0] = i >= 1 ? 0.25f : 0.f;
+    wy[1] = i == 0 ? 1.0f : 0.75f;
+    wy[2] = i == h - 1 ? 1.0f : 0.75f;
+    wy[3] = i < h - 1 ? 0.25f : 0.f;
+    wx[0] = j >= 1 ? 0.25f : 0.f;
+    wx[1] = j == 0 ? 1.0f : 0.75f;
+    wx[2] = j == w - 1 ? 1.0f : 0.75f;
+    wx[3] = j < w - 1 ? 0.25f : 0.f;
+    const float* b = dy + (size_t)n * H2 * W2 * C + c;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[ky][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // dy row R' = R - (ky - 1) for up row R = 2i - 1 + a: rows 2i-2 .. 2i+3, same for columns
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const int Ry = 2 * i - 2 + rr;
+      if ((unsigned)Ry >= (unsigned)H2) continue;
+      f32x4 v[6];
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        const int Rx = 2 * j - 2 + cc;
+        v[cc] = (unsigned)Rx < (unsigned)W2
+                    ? *reinterpret_cast<const f32x4*>(b + ((size_t)Ry * W2 + Rx) * C)
+                    : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // column stencil: for tap kx, up column S = 2j-1+bb reads dy column S-(kx-1) = index
+      // cc = bb + 2 - kx of v
+      f32x4 colsum[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int S = 2 * j - 1 + bb;           // up column (must exist)
+          const float wgt = (unsigned)S < (unsigned)W2 ? wx[bb] : 0.f;
+          t += v[bb + 2 - kx] * wgt;
+        }
+        colsum[kx] = t;
+      }
+      // row stencil: dy row Ry serves tap ky for up row R = Ry + ky - 1 = 2i-1+a, a = rr+ky-2
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int a = rr + ky - 2;
+        if (a < 0 || a > 3) continue;
+        const int R = 2 * i - 1 + a;
+        const float wgt = (unsigned)R < (unsigned)H2 ? wy[a] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky][kx] += colsum[kx] * wgt;
+      }
+    }
+    float* o = D + (size_t)pix * 9 * C + c;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        *reinterpret_cast<f32x4*>(o + (size_t)(ky * 3 + kx) * C) = acc[ky][kx];
   }
 }
 
@@ -379,7 +479,20 @@ extern "C" int unet_upsample2x_fwd(const float* x, float* y, int N, int h, int w
                "upsample2x_fwd: bad argument");
   const long long total4 = (long long)N * 4 * h * w * (C / 4);
   hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
-                     (hipStream_t)stream, x, y, h, w, C, total4);
+                     (hipStream_t)stream, x, y, h, w, C, total4, (const float*)nullptr,
+                     (const float*)nullptr, 0.f);
+  UNET_CHECK_LAUNCH("upsample2x_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_upsample2x_in_fwd(const unet_act_src* x, float slope, float* up, int N, int h,
+                                      int w, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && up && N > 0 && h > 0 && w > 0 && x->C > 0 && x->C % 4 == 0 &&
+                   (!x->alpha || x->beta),
+               "upsample2x_in_fwd: bad argument");
+  const long long total4 = (long long)N * 4 * h * w * (x->C / 4);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+                     (hipStream_t)stream, x->x, up, h, w, x->C, total4, x->alpha, x->beta, slope);
   UNET_CHECK_LAUNCH("upsample2x_fwd");
   return UNET_OK;
 }
@@ -392,6 +505,17 @@ extern "C" int unet_upsample2x_bwd(const float* gy, float* gx, int N, int h, int
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
                      (hipStream_t)stream, gy, gx, h, w, C, total4, accumulate);
   UNET_CHECK_LAUNCH("upsample2x_bwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_upsample2x_bwd_taps(const float* dy, float* D, int N, int h, int w, int C,
+                                        unet_stream_t stream) {
+  UNET_REQUIRE(dy && D && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
+               "upsample2x_bwd_taps: bad argument");
+  const long long total4 = (long long)N * h * w * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_taps_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+                     (hipStream_t)stream, dy, D, h, w, C, total4);
+  UNET_CHECK_LAUNCH("upsample2x_bwd_taps");
   return UNET_OK;
 }
 

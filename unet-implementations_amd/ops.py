@@ -6,7 +6,9 @@ launches asynchronously on `torch.cuda.current_stream()`.
 """
 import torch
 
-from ._lib import check, lib
+import ctypes
+
+from ._lib import ActSrc, check, lib
 
 
 def _stream():
@@ -312,6 +314,147 @@ def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma,
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws),
                                              ws.numel(), N, H * W, C, _stream()))
     return dy
+
+
+# ---- fused layer pipeline (include/unet_hip.h) ---------------------------------------------
+class Act:
+    """An operand that is activated on load: `x` is the RAW output of a convolution (NHWC)
+    and the consumer applies `lrelu(x * alpha[n, c] + beta[n, c])` while staging it, or a
+    plain tensor (`alpha is None`).  alpha / beta are rows 2 and 3 of the statistics tensor
+    `conv_in_fwd` returns (InstanceNorm scale / shift with the dropout mask folded in)."""
+
+    __slots__ = ("x", "alpha", "beta")
+
+    def __init__(self, x, alpha=None, beta=None):
+        self.x, self.alpha, self.beta = x, alpha, beta
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+    def c_struct(self):
+        return ActSrc(_ptr(self.x), self.x.shape[3], _ptr(self.alpha), _ptr(self.beta))
+
+
+def _act(a):
+    if a is None:
+        return None, None
+    if not isinstance(a, Act):
+        a = Act(a)
+    st = a.c_struct()
+    return a, ctypes.byref(st)
+
+
+def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask):
+    """Fused layer forward: y = conv(cat(act(s0), act(s1))) + bias and the InstanceNorm
+    statistics of y.  Returns (y, st) with st = [mean, rstd, alpha, beta] as [4, N, Cout];
+    alpha / beta carry the dropout `mask` [N, Cout] (or None) folded in."""
+    s0, r0 = _act(s0)
+    s1, r1 = _act(s1)
+    N, H, W, C0 = s0.shape
+    C1 = 0 if s1 is None else s1.shape[3]
+    if s1 is not None:
+        assert s1.shape[:3] == s0.shape[:3]
+    Cout = w.shape[1] if ksize == 3 else w.shape[0]
+    assert (w.shape[0] == 9 and w.shape[2] == C0 + C1) if ksize == 3 else w.shape[1] == C0 + C1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = _f32((N, Ho, Wo, Cout), s0.x)
+    st = _f32((4, N, Cout), s0.x)
+    ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, stride), s0.x)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().unet_conv_in_fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y),
+                                 _ptr(gamma), _ptr(beta), eps, _ptr(mask), _ptr(st[0]),
+                                 _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), _ptr(ws), ws.numel(), N, H,
+                                 W, Cout, _stream()))
+    if t0 is not None:   # the conv launch + the statistics finalize
+        _timer.end("conv_stem_fwd" if C0 == 3 else "conv_igemm",
+                   2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout, 1, t0)
+    return y, st
+
+
+def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
+    """Weight gradient of a fused layer: dw[:, ci_offset : ci_offset + Cx] = act(x) (x) dy."""
+    x, rx = _act(x)
+    N, H, W, Cx = x.shape
+    Cout = dy.shape[3]
+    assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
+    ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride), dy)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().unet_conv_in_bwd_weight(rx, slope, _ptr(dy), _ptr(dw_oihw), ci_offset,
+                                        dw_oihw.shape[1], ksize, stride, _ptr(ws), ws.numel(), N,
+                                        H, W, Cout, _stream()))
+    if t0 is not None:
+        _timer.end("conv_stem_wgrad" if Cx == 3 else "conv_wgrad",
+                   2.0 * N * dy.shape[1] * dy.shape[2] * ksize * ksize * Cx * Cout, 2, t0)
+    return dw_oihw
+
+
+def upsample2x_in_fwd(x, slope):
+    x, rx = _act(x)
+    N, h, w, C = x.shape
+    up = _f32((N, 2 * h, 2 * w, C), x.x)
+    check(lib().unet_upsample2x_in_fwd(rx, slope, _ptr(up), N, h, w, _stream()))
+    return up
+
+
+def upsample2x_bwd_taps(dy):
+    """D[N, h, w, 9*C] = the nine transposed-upsampled shifts of dy[N, 2h, 2w, C] (tap-major)."""
+    N, H2, W2, C = dy.shape
+    D = _f32((N, H2 // 2, W2 // 2, 9 * C), dy)
+    check(lib().unet_upsample2x_bwd_taps(_ptr(dy), _ptr(D), N, H2 // 2, W2 // 2, C, _stream()))
+    return D
+
+
+def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
+    """dw[:, ci_offset : ci_offset + Cx] of conv3x3(upsample2x(act(x))) from D (low-res GEMM)."""
+    x, rx = _act(x)
+    N, h, w, Cx = x.shape
+    Cout = D.shape[3] // 9
+    assert D.shape[:3] == x.shape[:3] and dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
+    ws = _ws(lib().unet_conv3x3_up_bwd_weight_workspace_bytes(N, h, w, Cx, Cout), D)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().unet_conv3x3_up_bwd_weight(rx, slope, _ptr(D), _ptr(dw_oihw), ci_offset,
+                                           dw_oihw.shape[1], _ptr(ws), ws.numel(), N, h, w, Cout,
+                                           _stream()))
+    if t0 is not None:   # algorithmic FLOPs: the 3x3 weight gradient on the up-sampled grid
+        _timer.end("conv_wgrad", 2.0 * N * 4 * h * w * 9 * Cx * Cout, 2, t0)
+    return dw_oihw
+
+
+def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False):
+    """g[N, h, w, ccols] (+)= dL/d(low-res operand) of conv3x3(upsample2x(.)) from D."""
+    N, h, w, C9 = D.shape
+    Cout = C9 // 9
+    cin_total = wd.shape[1]
+    assert wd.shape[0] == 9 and wd.shape[2] == Cout
+    g = out if out is not None else _f32((N, h, w, ccols), D)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().unet_conv3x3_up_bwd_data(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w,
+                                         Cout, ccols, 1 if accumulate else 0, _stream()))
+    if t0 is not None:   # algorithmic FLOPs: the 3x3 data gradient on the up-sampled grid
+        _timer.end("conv_igemm", 2.0 * N * 4 * h * w * 9 * ccols * Cout, 1, t0)
+    return g
+
+
+def head1x1_in_fwd(x, slope, w, b):
+    x, rx = _act(x)
+    N, H, W, C = x.shape
+    K = w.shape[0]
+    logits = _f32((N, K, H, W), x.x)
+    check(lib().unet_head1x1_in_fwd(rx, slope, _ptr(w), _ptr(b), _ptr(logits), N, H * W, K,
+                                    _stream()))
+    return logits
+
+
+def head1x1_in_bwd(x, slope, dlogits, w, dw, db):
+    x, rx = _act(x)
+    N, H, W, C = x.shape
+    K = w.shape[0]
+    da = torch.empty_like(x.x)
+    ws = _ws(lib().unet_head1x1_bwd_workspace_bytes(N, H * W, C, K), x.x)
+    check(lib().unet_head1x1_in_bwd(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw),
+                                    _ptr(db), _ptr(ws), ws.numel(), N, H * W, K, _stream()))
+    return da
 
 
 # ---- bilinear 2x ---------------------------------------------------------------------

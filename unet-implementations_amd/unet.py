@@ -7,9 +7,12 @@ the same 90 `state_dict()` keys/shapes, same `forward(x) -> logits` contract
 `forward` runs the whole network as ONE autograd node whose forward/backward
 launch the gfx950 kernels of libunet_hip.so through the C ABI.
 
-Internal layout: activations NHWC fp32; per 3x3 conv layer the raw output y,
-its per-(n,c) InstanceNorm statistics and the activated tensor
-a = dropout(leaky_relu(IN(y))) are kept for the backward pass.
+Internal layout: activations NHWC fp32.  Default (`fused_pipeline`, fp32 operand mode): per
+conv layer only the RAW output y and its per-(n,c) InstanceNorm statistics live in HBM; the
+statistics come out of the convolution's epilogue and every consumer (next conv, its weight
+gradient, the up-sampling, the head) applies a = dropout(leaky_relu(IN(y))) while it stages
+the operand (`ops.Act`).  The stand-alone pipeline (bf16 / bf16x3 operand modes, or
+`fused_pipeline = False`) also materialises a.
 """
 from typing import Dict, List, Optional, Tuple, Type, Union
 
@@ -22,9 +25,11 @@ from . import ops
 class SpatialDropout2d(nn.Module):
     """Channel dropout (reference: Our_UNet/models/unet.py:13-35).
 
-    Only carries `drop_prob`; the mask [N, C] (already divided by 1-p) is drawn by
-    `UNet.forward` with the same torch calls as the reference, so a given seed yields
-    the mask sequence the reference would draw on the same device.
+    Only carries `drop_prob`.  On the fused path `UNet.forward` draws the masks [N, C]
+    (already divided by 1-p) of ALL dropout modules with one Bernoulli launch
+    (`_draw_masks`): the same distribution as the reference's per-module
+    `new_empty(N, C, 1, 1).bernoulli_(1 - p).div_(1 - p)`, but not the same random stream,
+    so parity tests inject masks through `UNet.dropout_mask_override`.
     """
 
     def __init__(self, drop_prob):
@@ -202,6 +207,9 @@ class UNet(nn.Module):
         # stride-1 weight gradient) are rounded to bf16 on chip and contracted on the bf16 matrix
         # cores with fp32 accumulation (tensors, InstanceNorm statistics, master weights: fp32)
         self.matmul_precision = "fp32"
+        # fp32 operand mode only: keep just the raw conv outputs in HBM (statistics from the
+        # conv epilogue, InstanceNorm + LeakyReLU + dropout applied by the consumers on load)
+        self.fused_pipeline = True
 
     def _build_bottleneck(self, common):
         """Hook for variants that add modules between encoder and decoder (CLIPUNet)."""
@@ -444,7 +452,41 @@ class _UNetFunction(torch.autograd.Function):
                                   wd3=wd3 if l.ksize == 3 else None))
             return a
 
-        cur = x          # NHWC image
+        fused = bf16 == "fp32" and model.fused_pipeline and \
+            len({l.slope for l in layers}) == 1
+        slope = layers[0].slope
+
+        def run_layer_fused(l, s0, s1):
+            """s0 / s1: ops.Act operands; returns the Act of this layer's output."""
+            w = l.conv.weight
+            if l.ksize == 1:
+                wk = w.detach().view(w.shape[0], w.shape[1])
+                wd = ops.transpose2d(wk) if need_grad else None
+            else:
+                k = packed[id(w)]
+                wk, wd = table.wf[k], table.wd[k]
+            m = mask_of[id(l)]
+            y, st = ops.conv_in_fwd(s0, s1, slope, wk, l.conv.bias.detach(), l.ksize, l.stride,
+                                    l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps, m)
+            if need_grad:
+                saved.append(dict(layer=l, x0=s0, x1=s1, y=y, st=st, mask=m, wd=wd, wd3=None))
+            return ops.Act(y, st[2], st[3])
+
+        def run_up_layer_fused(l, low, skip):
+            """First conv of a decoder stage: conv3x3(cat(upsample2x(act(low)), act(skip))).
+            The up-sampled tensor only lives for this call: backward works on `low`
+            (ops.conv3x3_up_bwd_weight / _data)."""
+            out = run_layer_fused(l, ops.Act(ops.upsample2x_in_fwd(low, slope)), skip)
+            if need_grad:
+                saved[-1]["x0"] = None
+                saved[-1]["x0_low"] = low
+            return out
+
+        if fused:
+            run_layer = run_layer_fused
+            cur = ops.Act(x)     # the NHWC image is a plain operand
+        else:
+            cur = x          # NHWC image
         skips = []
         for bi, blk in enumerate(enc):
             for l in blk:
@@ -455,20 +497,30 @@ class _UNetFunction(torch.autograd.Function):
             if extra.shape[:3] != cur.shape[:3]:
                 raise NotImplementedError("bottleneck features must match the 1/32-resolution "
                                           f"grid {tuple(cur.shape[1:3])} (got {tuple(extra.shape[1:3])})")
-            cur = run_layer(fusion, cur, extra)
+            cur = run_layer(fusion, cur, ops.Act(extra) if fused else extra)
         for di, blk in enumerate(dec):
             skip = skips[len(skips) - 1 - di]
             if cur.shape[1] * 2 != skip.shape[1] or cur.shape[2] * 2 != skip.shape[2]:
                 raise NotImplementedError("decoder up-sampling must be exactly 2x")
+            if fused:
+                for li, l in enumerate(blk):
+                    cur = run_up_layer_fused(l, cur, skip) if li == 0 else run_layer(l, cur, None)
+                continue
             up = ops.upsample2x_fwd(cur)
             for li, l in enumerate(blk):
                 cur = run_layer(l, up, skip) if li == 0 else run_layer(l, cur, None)
         head = model.segmentation_output
-        logits = ops.head1x1_fwd(cur, head.weight.detach().view(head.out_channels, -1),
-                                 head.bias.detach())
+        hw = head.weight.detach().view(head.out_channels, -1)
+        if fused:
+            logits = ops.head1x1_in_fwd(cur, slope, hw, head.bias.detach())
+        else:
+            logits = ops.head1x1_fwd(cur, hw, head.bias.detach())
         if need_grad:
             ctx.model = model
             ctx.saved = saved
+            ctx.fused = fused
+            ctx.slope = slope
+            ctx.last = cur
             ctx.n_enc_blocks = len(enc)
             ctx.params = params
             ctx.bf16 = bf16
@@ -482,9 +534,15 @@ class _UNetFunction(torch.autograd.Function):
         gv = model._grad_view
         dlogits = dlogits.contiguous()
         head = model.segmentation_output
-        last = saved[-1]
-        g = ops.head1x1_bwd(last["a"], dlogits, head.weight.detach().view(head.out_channels, -1),
-                            gv(head.weight).view(head.out_channels, -1), gv(head.bias))
+        fused, slope = ctx.fused, ctx.slope
+        hw = head.weight.detach().view(head.out_channels, -1)
+        if fused:
+            g = ops.head1x1_in_bwd(ctx.last, slope, dlogits, hw,
+                                   gv(head.weight).view(head.out_channels, -1), gv(head.bias))
+        else:
+            g = ops.head1x1_bwd(saved[-1]["a"], dlogits, hw,
+                                gv(head.weight).view(head.out_channels, -1), gv(head.bias))
+        ctx.last = None
 
         idx = len(saved) - 1
         skip_grads = {}
@@ -527,6 +585,26 @@ class _UNetFunction(torch.autograd.Function):
             x0, x1 = rec["x0"], rec["x1"]
             dw = gv(l.conv.weight)
             want_dw = l.conv.weight.requires_grad
+            low = rec.get("x0_low")
+            if low is not None:
+                # conv3x3(upsample2x(act(low))): both gradients of the up-sampled operand are
+                # GEMMs over the LOW-resolution pixels once dy is reduced to its nine D_tap
+                C0 = low.shape[3]
+                D = ops.upsample2x_bwd_taps(dy) if (want_dw or need_dx) else None
+                if want_dw:
+                    ops.conv3x3_up_bwd_weight(low, slope, D, dw, 0)
+                    ops.conv_in_bwd_weight(x1, slope, dy, dw, C0, 3, 1)
+                g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0) if need_dx else None
+                dx1 = None
+                if need_dx1:
+                    dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], x1.shape[1],
+                                               x1.shape[2], 1)
+                return g_low, dx1
+            if want_dw and fused:      # the weight gradient activates its operand on load
+                ops.conv_in_bwd_weight(x0, slope, dy, dw, 0, l.ksize, l.stride)
+                if x1 is not None:
+                    ops.conv_in_bwd_weight(x1, slope, dy, dw, x0.shape[3], l.ksize, l.stride)
+                want_dw = False
             if l.ksize == 1:
                 if want_dw:
                     dw2d = dw.view(dw.shape[0], dw.shape[1])
@@ -570,8 +648,8 @@ class _UNetFunction(torch.autograd.Function):
             idx -= 1
             if g_skip is not None:
                 skip_grads[e] = g_skip
-            if g_up is not None:
-                g = ops.upsample2x_bwd(g_up)
+            if g_up is not None:   # fused pipeline: already the low-resolution gradient
+                g = g_up if "x0_low" in saved[idx + 1] else ops.upsample2x_bwd(g_up)
             ready(model.decoder_stages[di])
         if ctx.fusion is not None and not done and idx >= stop:
             g, _ = layer_bwd(idx, g)
