@@ -24,17 +24,67 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 385.188   # fwd + dgrad + wgrad, convolutions only
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (spec)
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E
+CONV_GROUPS = ("conv_igemm", "conv_igemm_bf16", "conv_igemm_bf16x3")
 
 
 def hbm_traffic(args):
-    """HBM bytes per conv_igemm launch from the PMC passes committed under profiles/ (rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script, FETCH_SIZE doubled as the
-    MI355X guide prescribes for gfx950); valid for the default fp32 bs=8 512x512 workload."""
-    path = os.path.join(ROOT, "profiles", "r01_igemm_hbm_traffic.json")
-    if args.matmul != "fp32" or args.hw != 512 or args.batch != 8 or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)["hbm_bytes_per_launch"]
+    """HBM bytes per launch of the forward / data-gradient convolution group from the PMC passes
+    committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of
+    this command, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950; tools/
+    pmc_traffic.py).  A committed measurement of the default workload, not of this run."""
+    if args.matmul != "fp32" or args.hw != 512 or args.batch != 8 or args.clip:
+        return None, None
+    for name in ("r02_conv_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f)["hbm_bytes_per_launch"], "profiles/" + name
+    return None, None
+
+
+def roofline_of(summ, steps, matmul, args):
+    """`roofline` object of the dominant kernel group (all 3x3 / 1x1 convolution forward and
+    data-gradient launches) and the per-group table, from the KernelTimer summary."""
+    k = next((summ[t] for t in CONV_GROUPS if t in summ), None)
+    groups = {}
+    for t, v in summ.items():
+        sec = v["ms"] * 1e-3
+        g = {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps}
+        if v["flops"]:
+            g["tflops"] = v["flops"] / sec * 1e-12
+            if v["executed"] != v["flops"]:
+                g["executed_tflops"] = v["executed"] / sec * 1e-12
+        if v["bytes"]:   # streaming kernels: algorithmic bytes against the HBM roofline
+            g["hbm_gbs"] = v["bytes"] / sec * 1e-9
+            g["frac_of_hbm_peak"] = g["hbm_gbs"] / PEAK_HBM_GBS
+        groups[t] = g
+    if k is None:
+        return None, groups
+    total = sum(v["flops"] for v in summ.values())
+    sec = k["ms"] * 1e-3
+    ach = k["flops"] / sec * 1e-12
+    # bf16x3 issues 6 bf16 MFMA flops per algorithmic flop
+    peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
+            "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[matmul]
+    traffic, src = hbm_traffic(args) if matmul == "fp32" else (None, None)
+    roof = {
+        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "traffic": traffic, "traffic_source": src,
+        # MFMA FLOPs actually issued: the data gradient of the up-sampled operand runs on the
+        # low-resolution grid (1/4 of the algorithmic 3x3 work), everything else executes its
+        # algorithmic count
+        "executed": k["executed"] / sec * 1e-12, "executed_frac": k["executed"] / sec * 1e-12 / peak,
+        "kernel": "convolution forward + data-gradient group (conv_patch_f32_kernel, "
+                  "conv_igemm_kernel, conv_igemm_rf_kernel, conv_dgrad_s2_kernel): "
+                  f"{k['flops'] / steps * 1e-12:.3f} of the step's "
+                  f"{total / steps * 1e-12:.3f} algorithmic conv TFLOP",
+        "launches_per_step": k["launches"] / steps,
+        "avg_launch_us": 1e3 * k["ms"] / k["launches"],
+        "flop_per_step": k["flops"] / steps,
+        "flop_per_launch": k["flops"] / k["launches"],
+    }
+    return roof, groups
 
 
 def synthetic_batch(seed, n, h, w):
@@ -51,6 +101,17 @@ def synthetic_batch(seed, n, h, w):
         mask[i][d < 1.0] = 1 + (i % 2)
         mask[i][(d >= 1.0) & (d < 1.0 + 8.0 / min(ry, rx))] = 255
     return img, torch.from_numpy(mask)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(steps=8, hw=512, n=2):
@@ -74,8 +135,18 @@ def cpu_baseline(steps=8, hw=512, n=2):
     for _ in range(steps):
         O.train_step(sd, bufs, img, tgt, masks)
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+    used = torch.get_num_threads()
+    # one thread: one step on ONE image (a bs-2 step would take ~20 s)
+    torch.set_num_threads(1)
+    m1 = [m[:1] for m in masks]
+    t1 = time.perf_counter()
+    O.train_step(sd, bufs, img[:1], tgt[:1], m1)
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(used)
+    return {"value": n * steps / dt, "unit": "images/s", "cores": used,
+            "kind": "port", "cpu": cpu_model(),
+            "one_thread": {"value": 1.0 / dt1, "unit": "images/s",
+                           "sample": f"1 train step of the oracle at bs=1, {hw}x{hw}, 1 thread"},
             "sample": f"{steps} train steps of the oracle (torch CPU fp32) at bs={n}, {hw}x{hw}, "
                       f"after 1 warm-up step"}
 
@@ -118,10 +189,12 @@ def main():
     import unet_implementations_amd as ua
     from unet_implementations_amd import ddp
 
+    backend_used = None
     if world > 1:
         # backend "nccl" is RCCL on ROCm; UNET_DIST_BACKEND=gloo lets the N>1 path be rehearsed
         # with several ranks sharing one GPU (RCCL refuses duplicate devices)
         backend = os.environ.get("UNET_DIST_BACKEND", "nccl")
+        backend_used = backend if backend != "nccl" else "nccl (RCCL)"
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -195,11 +268,14 @@ def main():
         for _ in range(max(2, args.warmup // 2)):
             step()
         fence()
+        alt_timer = None if args.no_kernel_timer else ua.ops.KernelTimer()
+        ua.ops.set_timer(alt_timer)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         fence()
         dt_alt = time.perf_counter() - t1
+        ua.ops.set_timer(None)
         if world > 1:
             t = torch.tensor([dt_alt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,6 +287,13 @@ def main():
                      "per multiply, f32 accumulate",
             "parity": "same fixtures and tolerances as fp32 (1e-4 logits, bit-exact argmax off "
                       "ties); per-conv error vs fp64 <= the fp32 MFMA kernels'"}}
+        if alt_timer is not None and rank == 0:
+            roof, groups = roofline_of(alt_timer.summary(), args.steps, "bf16x3", args)
+            if roof:
+                roof["note"] = ("peak = dense bf16 MFMA peak / 6 products per multiply; the chip "
+                                "holds ~1.8 GHz under this load (DESIGN.md section 3b)")
+                alt["bf16x3"]["roofline"] = roof
+            alt["bf16x3"]["kernel_groups"] = groups
         model.matmul_precision = args.matmul
 
     if rank == 0:
@@ -230,33 +313,17 @@ def main():
                                    "fp32 train step (fwd + Dice/wCE loss + bwd + SGD-Nesterov), "
                                    "train mode, HIP conv/IN/upsample kernels",
                        "global_batch": args.batch * world, "image": [args.hw, args.hw],
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "world": world,
+                       "dist_backend": backend_used},
             "final_loss": final_loss,
             "step_tflops": value / world * GFLOP_PER_IMAGE * 1e-3,
             "step_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * 1e-3 / PEAK_F32_MFMA_TFLOPS,
         }
         if timer is not None:
-            summ = timer.summary()
-            k = summ.get("conv_igemm") or summ.get("conv_igemm_bf16") or summ.get("conv_igemm_bf16x3")
-            if k:
-                ach = k["flops"] / (k["ms"] * 1e-3) * 1e-12
-                # bf16x3 issues 6 bf16 MFMA flops per algorithmic flop
-                peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
-                        "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.matmul]
-                result["roofline"] = {
-                    "bound": "mfma", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": hbm_traffic(args),
-                    "kernel": "3x3 conv forward + data gradient group: conv_patch_f32_kernel, "
-                              "conv_igemm_kernel, conv_igemm_rf_kernel, conv_dgrad_s2_kernel "
-                              "(1.366 TFLOP of the step's 2.049)",
-                    "launches_per_step": k["launches"] / args.steps,
-                    "avg_launch_us": 1e3 * k["ms"] / k["launches"],
-                    "flop_per_step": k["flops"] / args.steps,
-                }
-            result["kernel_groups"] = {
-                t: {"tflops": v["flops"] / (v["ms"] * 1e-3) * 1e-12, "ms_per_step": v["ms"] / args.steps,
-                    "launches_per_step": v["launches"] / args.steps}
-                for t, v in summ.items()}
+            roof, groups = roofline_of(timer.summary(), args.steps, args.matmul, args)
+            if roof:
+                result["roofline"] = roof
+            result["kernel_groups"] = groups
         if alt is not None:
             result["alt_modes"] = alt
         if world == 1 and not args.no_cpu_baseline:

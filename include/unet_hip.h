@@ -44,6 +44,12 @@ int unet_abi_version(void);
 /* number of HIP devices visible to the library (0 without a GPU); never fails */
 int unet_device_count(void);
 
+/* Test hook.  Operands are addressed through 2 GiB buffer descriptors; a batch whose tensor is
+ * larger (the reference trains at bs 32: Our_UNet/src/train.py:748) is split over N inside the
+ * convolution entry points.  This lowers the split threshold so the chunked path can be
+ * exercised on small tensors; bytes <= 0 restores 2^31 - 1. */
+int unet_debug_set_chunk_limit(int64_t bytes);
+
 /* ---- layout helpers ------------------------------------------------------ */
 
 /* NCHW -> NHWC (module boundary for the input image, Our_UNet/models/unet.py:399) */
@@ -311,19 +317,40 @@ typedef struct unet_act_src {
 } unet_act_src;
 
 /* y[N][Ho][Wo][Cout] = conv_kxk(cat(act(s0), act(s1))) + bias  (ksize 3: pad 1, stride 1|2,
- * w = wf[9][Cout][Cin]; ksize 1: stride 1, w = [Cout][Cin]; s1 may be NULL), plus the
- * InstanceNorm statistics of y and the folded coefficients for ITS consumers:
- * mean, rstd, alpha_out, beta_out [N][Cout] (gamma/beta = the norm's affine parameters,
- * mask [N][Cout] = this layer's dropout factors or NULL).
- * Replaces Conv2d + InstanceNorm2d statistics (+ the previous unit's IN apply / LeakyReLU /
- * dropout) of ConvBlock (Our_UNet/models/unet.py:101-134) and the torch.cat of UpBlock (:228).
- * H, W = input spatial size. */
+ * w = wf[9][Cout][Cin]; ksize 1: stride 1, w = [Cout][Cin]; s1 may be NULL).  The epilogue leaves
+ * per-tile (mean, M2) summaries of y in `workspace`; *stats_px_out (HOST int) receives the pixels
+ * per summary tile, or 0 when this shape has no statistics epilogue (tiny or ragged maps).
+ * Replaces Conv2d (+ the previous unit's InstanceNorm apply / LeakyReLU / dropout) of ConvBlock
+ * (Our_UNet/models/unet.py:101-134) and the torch.cat of UpBlock (:228).  H, W = input size. */
 size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout, int stride);
 int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope, const float* w,
-                     const float* bias, int ksize, int stride, float* y, const float* gamma,
-                     const float* beta, float eps, const float* mask, float* mean, float* rstd,
-                     float* alpha_out, float* beta_out, void* workspace, size_t workspace_bytes,
-                     int N, int H, int W, int Cout, unet_stream_t stream);
+                     const float* bias, int ksize, int stride, float* y, void* workspace,
+                     size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
+                     unet_stream_t stream);
+/* InstanceNorm statistics of y [N][HoWo][Cout] from the summaries unet_conv_in_fwd left in
+ * `workspace` (stats_px > 0: a few-microsecond merge) or from y itself (stats_px == 0), and the
+ * folded coefficients for y's consumers: mean, rstd, alpha_out, beta_out [N][Cout]
+ * (gamma / beta = the norm's affine parameters, mask [N][Cout] = this layer's dropout factors
+ * or NULL).  Replaces the statistics half of nn.InstanceNorm2d (unet.py:118-119). */
+int unet_conv_in_stats_finalize(const float* y, void* workspace, size_t workspace_bytes,
+                                int stats_px, const float* gamma, const float* beta, float eps,
+                                const float* mask, float* mean, float* rstd, float* alpha_out,
+                                float* beta_out, int N, int HoWo, int Cout, unet_stream_t stream);
+
+/* RGB stem straight from the dataset's uint8 HWC image [N][H][W][3]: the normalisation
+ * ((v / 255) - mean[c]) / std[c] of PetSegmentationDataset.__getitem__ (Our_UNet/src/train.py:
+ * 303-308) happens in the loaders of the first convolution and of its weight gradient, so the
+ * fp32 image is never written (12x less input traffic).  mean3 / std3 are HOST pointers.
+ * W % 128 == 0; other widths go through unet_preprocess_u8.  Workspaces / *stats_px_out as
+ * unet_conv_in_fwd (stride 1) and unet_conv3x3_bwd_weight (Cx = 3). */
+int unet_stem_u8_fwd(const uint8_t* image_hwc, const float* mean3, const float* std3,
+                     const float* wf, const float* bias, float* y, void* workspace,
+                     size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
+                     unet_stream_t stream);
+int unet_stem_u8_bwd_weight(const uint8_t* image_hwc, const float* mean3, const float* std3,
+                            const float* dy, float* dw_oihw, void* workspace,
+                            size_t workspace_bytes, int N, int H, int W, int Cout,
+                            unet_stream_t stream);
 
 /* Weight gradient with the activation applied to the input operand on load:
  * dw_oihw[Cout][Cin_total][k][k] (columns ci_offset .. +x->C) = sum_pixels act(x) (x) dy.

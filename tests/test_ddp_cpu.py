@@ -108,28 +108,78 @@ def test_single_process_is_a_noop():
         dist.destroy_process_group()
 
 
+class _P:
+    def __init__(self, rg, grad=None):
+        self.requires_grad = rg
+        self.grad = grad
+
+
+class _M(_Arena):
+    """Arena stand-in with a parameter table: three parameters at offsets 0 / 40 / 70."""
+
+    def __init__(self, frozen=(True, True, False)):
+        super().__init__(100)
+        self._offsets = [0, 40, 70]
+        self._params = [_P(not f) for f in frozen]
+
+    def parameters(self):
+        return iter(self._params)
+
+    def named_parameters(self):
+        return iter([(f"p{i}", p) for i, p in enumerate(self._params)])
+
+
 def test_frozen_prefix_is_left_out_of_the_exchange():
-    """A frozen encoder prefix (requires_grad=False) is not all-reduced: finish() starts at the
-    first trainable parameter's arena offset."""
-    from unet_implementations_amd import ddp
+    """A frozen encoder prefix (requires_grad=False) is not all-reduced: the ranges actually
+    handed to all_reduce start at the first trainable parameter's arena offset."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from unet_implementations_amd import ddp
+        m = _M()
+        sync = ddp.GradBucketAllReduce(m, None, bucket_bytes=4 * 20)
+        assert sync._frozen_prefix() == 70
+        # UNet.backward reports suffixes, the last call carries the frozen-prefix offset
+        for lo in (90, 70):
+            m.grad_ready_hook(lo)
+        sync.finish()
+        assert sync.sent_ranges == [(70, 100)] or sync.sent_ranges == [(90, 100), (70, 90)]
+        assert min(lo for lo, _ in sync.sent_ranges) == 70
+        # nothing frozen: the whole arena is covered exactly once, back to front
+        m2 = _M(frozen=(False, False, False))
+        sync2 = ddp.GradBucketAllReduce(m2, None, bucket_bytes=4 * 20)
+        for lo in (90, 70, 40, 0):
+            m2.grad_ready_hook(lo)
+        sync2.finish()
+        covered = sorted(sync2.sent_ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == 100
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        sync.model = _Arena(10)          # no parameter table: whole arena
+        assert sync._frozen_prefix() == 0
+    finally:
+        dist.destroy_process_group()
 
-    class _P:
-        def __init__(self, rg):
-            self.requires_grad = rg
 
-    class _M(_Arena):
-        def __init__(self):
-            super().__init__(100)
-            self._offsets = [0, 40, 70]
-            self._params = [_P(False), _P(False), _P(True)]
-
-        def parameters(self):
-            return iter(self._params)
-
-    sync = ddp.GradBucketAllReduce.__new__(ddp.GradBucketAllReduce)
-    sync.model = _M()
-    assert sync._frozen_prefix() == 70
-    sync.model._params[0].requires_grad = True
-    assert sync._frozen_prefix() == 0
-    sync.model = _Arena(10)          # no parameter table: whole arena
-    assert sync._frozen_prefix() == 0
+def test_finish_refuses_gradients_outside_the_arena():
+    """If a parameter's .grad is not a view of the arena the all-reduce did not cover it:
+    finish() must raise instead of training on un-reduced gradients."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from unet_implementations_amd import ddp
+        m = _M(frozen=(False, False, False))
+        for p, off, n in zip(m._params, m._offsets, (40, 30, 30)):
+            p.grad = m.garena[off:off + n]
+        sync = ddp.GradBucketAllReduce(m, None)
+        m.grad_ready_hook(0)
+        sync.finish()                                   # all views: fine
+        m._params[1].grad = m.garena[40:70].clone()     # a detached copy
+        m.grad_ready_hook(0)
+        with pytest.raises(RuntimeError, match="does not alias the gradient arena"):
+            sync.finish()
+    finally:
+        dist.destroy_process_group()

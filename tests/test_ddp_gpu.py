@@ -139,3 +139,29 @@ def test_two_rank_global_exact_equals_one_process_on_concatenated_batch():
         logits = O.unet_forward(sd0, img.cpu(), masks)
         ref_loss = O.simple_loss(logits, tgt.cpu()).item()
     assert abs(out["loss0"] - ref_loss) <= 2e-5 * abs(ref_loss)
+
+
+def test_bench_two_ranks_through_torch_distributed_run():
+    """The driver's multi-GPU command line (`python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N`) rehearsed with 2 ranks sharing cuda:0 over gloo: the JSON line must carry
+    the contract fields, the world size and the backend that ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UNET_SHARE_GPU="1", UNET_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--hw", "64", "--no-alt", "--no-cpu-baseline"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["scaling"] == "weak" and r["higher_is_better"] is True and r["value"] > 0
+    assert r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["world"] == 2 and r["config"]["dist_backend"] == "gloo"
+    assert abs(r["value"] - 4 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]

@@ -317,3 +317,85 @@ def test_conv3x3_up_backward_at_low_resolution(ua, case):
     check(from_nhwc(g), a.grad, 3e-5, "dL/da (low resolution)")
     g2 = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx, out=g.clone(), accumulate=True)
     check(from_nhwc(g2), 2 * a.grad, 3e-5, "accumulate")
+
+
+# --------------------------------------------------------------------------- 2 GiB batch chunking
+@pytest.fixture
+def small_chunks(ua):
+    """Lower the buffer-range threshold so a 4-image batch is processed in three chunks."""
+    def setter(per_image_bytes):
+        ua.lib().unet_debug_set_chunk_limit(int(1.5 * per_image_bytes))
+    yield setter
+    ua.lib().unet_debug_set_chunk_limit(0)
+
+
+def test_batch_chunking_matches_one_pass(ua, small_chunks):
+    """The reference trains at bs 32 (Our_UNet/src/train.py:748), where the 64-channel 512x512
+    tensors reach 2 GiB - past the buffer-descriptor range of the conv kernels.  The entry
+    points split such batches over N.  Here the threshold is lowered instead of the tensors
+    grown: every chunked entry point must reproduce its one-pass result exactly (forward,
+    statistics, data gradient) or to summation order (weight gradients: more slabs)."""
+    N, H, W, C0, C1, Cout = 4, 16, 32, 64, 32, 64
+    x0, x1 = rnd(N, C0, H, W, seed=1), rnd(N, C1, H, W, seed=2)
+    c0, c1 = coeffs(N, C0, 10), coeffs(N, C1, 20)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=0.05)
+    b, gamma, beta = rnd(Cout, seed=4), rnd(Cout, seed=5) * 0.2 + 1, rnd(Cout, seed=6) * 0.2
+    dy = to_nhwc(rnd(N, Cout, H, W, seed=7))
+    wf, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    s0, s1 = make_src(ua, x0, c0), make_src(ua, x1, c1)
+    xl = rnd(N, C0, H // 2, W // 2, seed=8)
+    sl = make_src(ua, xl, coeffs(N, C0, 30))
+
+    def run():
+        y, st = ua.ops.conv_in_fwd(s0, s1, SLOPE, wf, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV),
+                                   1e-5, None)
+        y2 = ua.ops.conv3x3_fwd(s0.x, s1.x, wf, b.to(DEV), 2)
+        dx = ua.ops.conv3x3_bwd_data(dy, wd, 0, C0, H, W, 1)
+        dw = torch.zeros(Cout, C0 + C1, 3, 3, device=DEV)
+        ua.ops.conv_in_bwd_weight(s0, SLOPE, dy, dw, 0, 3, 1)
+        ua.ops.conv_in_bwd_weight(s1, SLOPE, dy, dw, C0, 3, 1)
+        D = ua.ops.upsample2x_bwd_taps(dy)
+        dwu = torch.zeros(Cout, C0, 3, 3, device=DEV)
+        ua.ops.conv3x3_up_bwd_weight(sl, SLOPE, D, dwu, 0)
+        gl = ua.ops.conv3x3_up_bwd_data(D, wd, 0, C0)
+        return [t.clone() for t in (y, st, y2, dx, dw, dwu, gl)]
+
+    ref = run()
+    # threshold = 1.5 x the largest per-image operand (D: 9*Cout channels at half resolution):
+    # D goes one image at a time, the 64-channel sources three + one
+    small_chunks((H // 2) * (W // 2) * 9 * Cout * 4)
+    got = run()
+    for name, a, r in zip(("y", "stats", "y stride 2", "dx", "dw", "dw up", "g low"), got, ref):
+        if name in ("dw", "dw up", "stats"):
+            check(a, r, 2e-6, name)
+        else:
+            assert torch.equal(a, r), name
+
+
+def test_reference_batch_size_32_layer_runs(ua):
+    """dec4.0 of the bs-32 run the reference does: 64 up-sampled + 32 skip channels at 512x512.
+    Source 0 is exactly 2^31 bytes.  The call used to return UNET_E_INVALID; now it must run and
+    agree with the same layer evaluated per 8-image quarter."""
+    N, H, W, C0, C1, Cout = 32, 512, 512, 64, 32, 32
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x0 = torch.randn(N, H, W, C0, device=DEV, generator=g)
+    x1 = torch.randn(N, H, W, C1, device=DEV, generator=g)
+    assert x0.numel() * 4 == 1 << 31
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=0.05).to(DEV)
+    wf, wd = ua.ops.pack_conv3x3_weights(w)
+    b = rnd(Cout, seed=4).to(DEV)
+    y = ua.ops.conv3x3_fwd(x0, x1, wf, b, 1)
+    for q in range(4):
+        sl = slice(8 * q, 8 * q + 8)
+        yq = ua.ops.conv3x3_fwd(x0[sl].contiguous(), x1[sl].contiguous(), wf, b, 1)
+        assert torch.equal(y[sl], yq)
+    dw = torch.zeros(Cout, C0 + C1, 3, 3, device=DEV)
+    ua.ops.conv_in_bwd_weight(ua.ops.Act(x0), SLOPE, y, dw, 0, 3, 1)
+    dwq = torch.zeros_like(dw)
+    acc = torch.zeros_like(dw)
+    for q in range(4):
+        sl = slice(8 * q, 8 * q + 8)
+        ua.ops.conv_in_bwd_weight(ua.ops.Act(x0[sl].contiguous()), SLOPE, y[sl].contiguous(), dwq,
+                                  0, 3, 1)
+        acc += dwq
+    check(dw[:, :C0], acc[:, :C0], 1e-5, "dw over the 2 GiB operand")

@@ -572,3 +572,96 @@ def test_drawn_dropout_masks_have_the_reference_distribution(ua):
     assert not torch.equal(again[layers.index(drops[0][0])], drops[0][1])      # fresh draw
     model.eval()
     assert all(m is None for m in U._draw_masks(model, layers, n, torch.device(DEV)))
+
+
+def test_gradient_accumulation_and_in_place_zero_grad(ua):
+    """`.grad` are views of the gradient arena the kernels write.  A second backward before the
+    step must ACCUMULATE (reference semantics: loss.backward() twice adds), and
+    optimizer.zero_grad(set_to_none=False) followed by backward must give g, not 2 g."""
+    sd0 = O.fill_state_dict(3)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    lossf = ua.get_loss_function()
+    (img1, tgt1), (img2, tgt2) = O.synthetic_batch(1, 2, 64, 64), O.synthetic_batch(2, 2, 64, 64)
+    masks = O.draw_dropout_masks(4, 2)
+    model.dropout_mask_override = masks
+
+    def grads_of(img, tgt):
+        for p in model.parameters():
+            p.grad = None
+        lossf(model(img.to(DEV)), tgt.to(DEV)).backward()
+        return [p.grad.detach().clone() for p in model.parameters()]
+
+    g1, g2 = grads_of(img1, tgt1), grads_of(img2, tgt2)
+    for p in model.parameters():
+        p.grad = None
+    lossf(model(img1.to(DEV)), tgt1.to(DEV)).backward()
+    lossf(model(img2.to(DEV)), tgt2.to(DEV)).backward()
+    _, garena = model.flat_parameters()
+    for p, a, b, off in zip(model.parameters(), g1, g2, model._offsets):
+        assert p.grad.data_ptr() == garena.data_ptr() + 4 * off      # still the arena view
+        assert torch.allclose(p.grad, a + b, rtol=1e-6, atol=1e-7 * (a + b).abs().max().item())
+    opt = ua.create_optimizer(model)
+    opt.zero_grad(set_to_none=False)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in model.parameters())
+    lossf(model(img1.to(DEV)), tgt1.to(DEV)).backward()
+    for p, a in zip(model.parameters(), g1):
+        assert torch.equal(p.grad, a)
+    assert opt._flat_ready()
+
+
+def test_layer_that_did_not_run_gets_no_gradient(ua):
+    """CLIPUNet.forward(x) without features skips the fusion layer: its four parameters keep
+    .grad = None (as in the reference), so SGD leaves them - momentum and weight decay included -
+    alone."""
+    model = ua.CLIPUNet(with_clip_features=True, clip_dim=512).to(DEV).train()
+    img, tgt = O.synthetic_batch(9, 2, 64, 64)
+    opt = ua.create_optimizer(model)
+    before = {k: p.detach().clone() for k, p in model.named_parameters() if "clip_fusion" in k}
+    assert len(before) == 4
+    loss = ua.train_step(model, opt, ua.get_loss_function(), img.to(DEV), tgt.to(DEV))
+    assert torch.isfinite(loss)
+    for k, p in model.named_parameters():
+        if "clip_fusion" in k:
+            assert p.grad is None and torch.equal(p.detach(), before[k])
+        else:
+            assert p.grad is not None
+
+
+def test_uint8_batch_through_the_fused_stem(ua):
+    """forward(x_u8, input_layout="nhwc_u8"): the dataset normalisation (Our_UNet/src/train.py:
+    303-308) runs inside the loaders of the first convolution and of its weight gradient.  The
+    loaders compute the very floats `ops.preprocess_u8` writes (bit-exact against
+    oracle.preprocess_sample, test_preprocess_u8_bit_exact), so logits and every gradient must be
+    IDENTICAL to the run on the preprocessed fp32 tensor."""
+    g = torch.Generator().manual_seed(5)
+    x_u8 = torch.randint(0, 256, (2, 128, 128, 3), generator=g, dtype=torch.uint8).to(DEV)
+    tgt = torch.randint(0, 3, (2, 128, 128), generator=g).to(DEV)
+    sd0 = O.fill_state_dict(3)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    model.dropout_mask_override = O.draw_dropout_masks(4, 2)
+    lossf = ua.get_loss_function()
+
+    def run(layout):
+        for p in model.parameters():
+            p.grad = None
+        inp = x_u8 if layout == "nhwc_u8" else ua.ops.preprocess_u8(x_u8)[0]
+        logits = model(inp, input_layout=layout)
+        lossf(logits, tgt).backward()
+        return logits.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]
+
+    l_ref, g_ref = run("nhwc")
+    l_u8, g_u8 = run("nhwc_u8")
+    assert torch.equal(l_u8, l_ref)
+    for a, b in zip(g_u8, g_ref):
+        assert torch.equal(a, b)
+    # widths the raw-row stem does not cover fall back to the preprocessing kernel
+    x96 = torch.randint(0, 256, (1, 96, 96, 3), generator=g, dtype=torch.uint8).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        a = model(x96, input_layout="nhwc_u8")
+        b = model(ua.ops.preprocess_u8(x96)[0], input_layout="nhwc")
+    assert torch.equal(a, b)

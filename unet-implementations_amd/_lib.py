@@ -34,6 +34,7 @@ SIGNATURES = {
     "unet_last_error": (_c.c_char_p, []),
     "unet_abi_version": (_i, []),
     "unet_device_count": (_i, []),
+    "unet_debug_set_chunk_limit": (_i, [_i64]),
     "unet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "unet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "unet_pack_conv3x3_weights": (_i, [_p, _p, _p, _i, _i, _p]),
@@ -76,8 +77,14 @@ SIGNATURES = {
     "unet_sgd_nesterov_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
     "unet_add_inplace": (_i, [_p, _p, _i64, _p]),
     "unet_conv_in_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "unet_conv_in_fwd": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
-                              _sz, _i, _i, _i, _i, _p]),
+    "unet_conv_in_fwd": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,
+                              _i, _p]),
+    "unet_conv_in_stats_finalize": (_i, [_p, _p, _sz, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i,
+                                         _p]),
+    "unet_stem_u8_fwd": (_i, [_p, _c.POINTER(_f), _c.POINTER(_f), _p, _p, _p, _p, _sz,
+                              _c.POINTER(_i), _i, _i, _i, _i, _p]),
+    "unet_stem_u8_bwd_weight": (_i, [_p, _c.POINTER(_f), _c.POINTER(_f), _p, _p, _p, _sz, _i, _i,
+                                     _i, _i, _p]),
     "unet_conv_in_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
     "unet_upsample2x_bwd_taps": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -881,12 +881,26 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const float* __restr
 constexpr int STEM_ROW_PIX = 128;
 constexpr int STEM_ROW_PITCH = 393;
 
-__global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const float* __restrict__ x,
+// Input pixel of the RGB stem: fp32 as stored, or uint8 normalised on load with the dataset's
+// expression ((v / 255) - mean[c]) / std[c] (Our_UNet/src/train.py:303-308) - the fp32 image is
+// then never written to HBM (12x less input traffic).
+struct StemNorm { float mean[3], std[3]; };
+__device__ __forceinline__ float stem_pixel(const float* x, size_t i, int, const StemNorm&) {
+  return x[i];
+}
+__device__ __forceinline__ float stem_pixel(const unsigned char* x, size_t i, int c,
+                                            const StemNorm& nm) {
+  return ((float)x[i] / 255.0f - nm.mean[c]) / nm.std[c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const T* __restrict__ x,
                                                                  const float* __restrict__ wf,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ y, int N,
                                                                  int H, int W, int Cout,
-                                                                 float2* __restrict__ stats) {
+                                                                 float2* __restrict__ stats,
+                                                                 const StemNorm nm) {
   __shared__ float Rw[3 * STEM_ROW_PITCH];
   __shared__ float B[28 * 32];
   __shared__ float2 red[4 * 32];
@@ -907,7 +921,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const float* __
     const int iy = yy + ky - 1, ix = x0 - 1 + j / 3;
     float v = 0.f;
     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      v = x[((size_t)n * HW + (size_t)iy * W + x0 - 1) * 3 + j];
+      v = stem_pixel(x, ((size_t)n * HW + (size_t)iy * W + x0 - 1) * 3 + j, j % 3, nm);
     Rw[ky * STEM_ROW_PITCH + j] = v;
   }
   __syncthreads();
@@ -965,8 +979,8 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
     const long long M = (long long)N * H * W;
     if (W % STEM_ROW_PIX == 0) {
       dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
-      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N,
-                         H, W, Cout, (float2*)nullptr);
+      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel<float>, grid, dim3(256), 0, stream, x0, wf, bias,
+                         y, N, H, W, Cout, (float2*)nullptr, StemNorm{});
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
       hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N, H,
@@ -978,12 +992,26 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
   UNET_REQUIRE(C0 > 0 && C0 % 32 == 0 && C1 >= 0 && C1 % 32 == 0,
                "conv3x3_fwd: channel counts (%d,%d) must be multiples of 32", C0, C1);
   UNET_REQUIRE(C1 == 0 || x1, "conv3x3_fwd: x1 is null with C1=%d", C1);
+  UNET_REQUIRE((long long)9 * Cout * (C0 + C1) * 4 < (1LL << 31), "conv3x3_fwd: weights exceed 2 GiB");
+  {  // batch chunks keep every source inside the 2 GiB buffer-descriptor range
+    const int nmax = batch_chunk(N, (long long)H * W * (C0 > C1 ? C0 : C1) * 4);
+    UNET_REQUIRE(nmax >= 1, "conv3x3_fwd: one image exceeds the 2 GiB buffer-descriptor range");
+    if (nmax < N) {
+      const size_t Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+      for (int nb = 0; nb < N; nb += nmax) {
+        const int n = N - nb < nmax ? N - nb : nmax;
+        const int rc = conv3x3_fwd_impl(x0 + (size_t)nb * H * W * C0,  C0,
+                                        x1 ? x1 + (size_t)nb * H * W * C1 : nullptr, C1, wf, bias,
+                                        y + (size_t)nb * Ho * Wo * Cout, n, H, W, Cout, stride, prec,
+                                        stream, wf3);
+        if (rc != UNET_OK) return rc;
+      }
+      return UNET_OK;
+    }
+  }
   IgemmParams p{};
   p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1;
   p.w = wf; p.tap_stride = Cout * (C0 + C1); p.n_off = 0; p.bias = bias;
-  UNET_REQUIRE((long long)N * H * W * (C0 > C1 ? C0 : C1) * 4 < (1LL << 31) &&
-                   (long long)9 * Cout * (C0 + C1) * 4 < (1LL << 31),
-               "conv3x3_fwd: tensor exceeds the 2 GiB buffer-descriptor range");
   p.src0_bytes = (unsigned)((long long)N * H * W * C0 * 4);
   p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 4);
   p.w_bytes = (unsigned)((long long)9 * Cout * (C0 + C1) * 4);
@@ -1046,12 +1074,25 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   UNET_REQUIRE(stride == 1 || (H % 2 == 0 && W % 2 == 0),
                "conv3x3_bwd_data: stride 2 needs even H, W");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  UNET_REQUIRE((long long)9 * Cout * Cin_total * 4 < (1LL << 31),
+               "conv3x3_bwd_data: weights exceed 2 GiB");
+  {  // batch chunks keep dy inside the 2 GiB buffer-descriptor range
+    const int nmax = batch_chunk(N, (long long)Ho * Wo * Cout * 4);
+    UNET_REQUIRE(nmax >= 1, "conv3x3_bwd_data: one image exceeds the 2 GiB buffer-descriptor range");
+    if (nmax < N) {
+      for (int nb = 0; nb < N; nb += nmax) {
+        const int n = N - nb < nmax ? N - nb : nmax;
+        const int rc = conv3x3_bwd_data_impl(dy + (size_t)nb * Ho * Wo * Cout, wd, Cin_total,
+                                             ci_offset, dx + (size_t)nb * H * W * Ccols, n, H, W,
+                                             Cout, Ccols, stride, accumulate, prec, stream, wd3);
+        if (rc != UNET_OK) return rc;
+      }
+      return UNET_OK;
+    }
+  }
   IgemmParams p{};
   p.src0 = dy; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
   p.w = wd; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
-  UNET_REQUIRE((long long)N * Ho * Wo * Cout * 4 < (1LL << 31) &&
-                   (long long)9 * Cout * Cin_total * 4 < (1LL << 31),
-               "conv3x3_bwd_data: tensor exceeds the 2 GiB buffer-descriptor range");
   p.src0_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
   p.src1_bytes = 0;
   p.w_bytes = (unsigned)((long long)9 * Cout * Cin_total * 4);
@@ -1140,11 +1181,23 @@ extern "C" int unet_conv1x1_fwd(const float* x0, int C0, const float* x1, int C1
   UNET_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 32 == 0 && C0 > 0 && C0 % 32 == 0 &&
                    C1 >= 0 && C1 % 32 == 0 && (C1 == 0 || x1),
                "conv1x1_fwd: channel counts (%d,%d)->%d must be multiples of 32", C0, C1, Cout);
+  {
+    const int nmax = batch_chunk(N, (long long)H * W * (C0 > C1 ? C0 : C1) * 4);
+    UNET_REQUIRE(nmax >= 1, "conv1x1_fwd: one image exceeds the 2 GiB buffer-descriptor range");
+    if (nmax < N) {
+      for (int nb = 0; nb < N; nb += nmax) {
+        const int n = N - nb < nmax ? N - nb : nmax;
+        const int rc = unet_conv1x1_fwd(x0 + (size_t)nb * H * W * C0, C0,
+                                        x1 ? x1 + (size_t)nb * H * W * C1 : nullptr, C1, w, bias,
+                                        y + (size_t)nb * H * W * Cout, n, H, W, Cout, stream);
+        if (rc != UNET_OK) return rc;
+      }
+      return UNET_OK;
+    }
+  }
   IgemmParams p{};
   p.src0 = x0; p.src1 = x1; p.C0 = C0; p.C1 = C1;
   p.w = w; p.tap_stride = Cout * (C0 + C1); p.n_off = 0; p.bias = bias;
-  UNET_REQUIRE((long long)N * H * W * (C0 > C1 ? C0 : C1) * 4 < (1LL << 31),
-               "conv1x1_fwd: tensor exceeds the 2 GiB buffer-descriptor range");
   p.src0_bytes = (unsigned)((long long)N * H * W * C0 * 4);
   p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 4);
   p.w_bytes = (unsigned)((long long)Cout * (C0 + C1) * 4);
@@ -1162,11 +1215,23 @@ extern "C" int unet_conv1x1_bwd_data(const float* dy, const float* wT, int Cin_t
   UNET_REQUIRE(dy && wT && dx, "conv1x1_bwd_data: null pointer");
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
                    ci_offset + Ccols <= Cin_total, "conv1x1_bwd_data: bad channel slice");
+  {
+    const int nmax = batch_chunk(N, (long long)H * W * Cout * 4);
+    UNET_REQUIRE(nmax >= 1, "conv1x1_bwd_data: one image exceeds the 2 GiB buffer-descriptor range");
+    if (nmax < N) {
+      for (int nb = 0; nb < N; nb += nmax) {
+        const int n = N - nb < nmax ? N - nb : nmax;
+        const int rc = unet_conv1x1_bwd_data(dy + (size_t)nb * H * W * Cout, wT, Cin_total,
+                                             ci_offset, dx + (size_t)nb * H * W * Ccols, n, H, W,
+                                             Cout, Ccols, accumulate, stream);
+        if (rc != UNET_OK) return rc;
+      }
+      return UNET_OK;
+    }
+  }
   IgemmParams p{};
   p.src0 = dy; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
   p.w = wT; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
-  UNET_REQUIRE((long long)N * H * W * Cout * 4 < (1LL << 31),
-               "conv1x1_bwd_data: tensor exceeds the 2 GiB buffer-descriptor range");
   p.src0_bytes = (unsigned)((long long)N * H * W * Cout * 4);
   p.src1_bytes = 0;
   p.w_bytes = (unsigned)((long long)Cout * Cin_total * 4);
@@ -1189,13 +1254,6 @@ namespace {
 size_t stats_partial_bytes(int N, int HoWo, int Cout) {
   return align_up((size_t)N * (size_t)ceil_div(HoWo, 64) * Cout * sizeof(float2), 256);
 }
-// largest batch chunk whose per-source tensors stay below the 2 GiB buffer-descriptor range
-int batch_chunk(int N, long long per_image_bytes) {
-  const long long lim = (1LL << 31) - 1;
-  long long n = lim / (per_image_bytes > 0 ? per_image_bytes : 1);
-  if (n < 1) n = 0;
-  return (int)(n < N ? n : N);
-}
 }  // namespace
 
 extern "C" size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout, int stride) {
@@ -1208,12 +1266,10 @@ extern "C" size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout
 
 extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope,
                                 const float* w, const float* bias, int ksize, int stride, float* y,
-                                const float* gamma, const float* beta, float eps,
-                                const float* mask, float* mean, float* rstd, float* alpha_out,
-                                float* beta_out, void* workspace, size_t workspace_bytes, int N,
+                                void* workspace, size_t workspace_bytes, int* stats_px_out, int N,
                                 int H, int W, int Cout, unet_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  UNET_REQUIRE(s0 && s0->x && w && y && mean && rstd && workspace, "conv_in_fwd: null pointer");
+  UNET_REQUIRE(s0 && s0->x && w && y && workspace && stats_px_out, "conv_in_fwd: null pointer");
   UNET_REQUIRE(ksize == 3 || ksize == 1, "conv_in_fwd: kernel size %d unsupported", ksize);
   UNET_REQUIRE(stride == 1 || (stride == 2 && ksize == 3), "conv_in_fwd: stride %d unsupported",
                stride);
@@ -1232,8 +1288,8 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
     const long long M = (long long)N * H * W;
     if (W % STEM_ROW_PIX == 0) {
       dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
-      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel, grid, dim3(256), 0, stream, s0->x, w, bias, y,
-                         N, H, W, Cout, reinterpret_cast<float2*>(workspace));
+      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel<float>, grid, dim3(256), 0, stream, s0->x, w,
+                         bias, y, N, H, W, Cout, reinterpret_cast<float2*>(workspace), StemNorm{});
       stats_px = STEM_ROW_PIX;
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
@@ -1297,12 +1353,24 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
       stats_px = px;
     }
   }
-  const int HoWo = Ho * Wo;
+  *stats_px_out = stats_px;
+  return UNET_OK;
+}
+
+extern "C" int unet_conv_in_stats_finalize(const float* y, void* workspace, size_t workspace_bytes,
+                                           int stats_px, const float* gamma, const float* beta,
+                                           float eps, const float* mask, float* mean, float* rstd,
+                                           float* alpha_out, float* beta_out, int N, int HoWo,
+                                           int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(y && workspace && mean && rstd, "conv_in_stats_finalize: null pointer");
+  UNET_REQUIRE(stats_px >= 0 && (stats_px == 0 || HoWo % stats_px == 0),
+               "conv_in_stats_finalize: %d-pixel tiles do not cover %d pixels", stats_px, HoWo);
   if (stats_px > 0)
     return unet_in_finalize_tiles(workspace, HoWo / stats_px, stats_px, gamma, beta, eps, mask,
-                                  mean, rstd, alpha_out, beta_out, N, HoWo, Cout, stream);
+                                  mean, rstd, alpha_out, beta_out, N, HoWo, Cout,
+                                  (hipStream_t)stream);
   return unet_in_stats_masked(y, gamma, beta, eps, mask, mean, rstd, alpha_out, beta_out, workspace,
-                              workspace_bytes, N, HoWo, Cout, stream);
+                              workspace_bytes, N, HoWo, Cout, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1320,9 +1388,22 @@ extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin
                    ci_offset + Ccols <= Cin_total && N > 0 && h > 0 && w > 0,
                "conv3x3_up_bwd_data: bad shape Cout=%d Ccols=%d slice %d of %d", Cout, Ccols,
                ci_offset, Cin_total);
-  UNET_REQUIRE((long long)N * h * w * 9 * Cout * 4 < (1LL << 31) &&
-                   (long long)9 * Cout * Cin_total * 4 < (1LL << 31),
-               "conv3x3_up_bwd_data: tensor exceeds the 2 GiB buffer-descriptor range");
+  UNET_REQUIRE((long long)9 * Cout * Cin_total * 4 < (1LL << 31),
+               "conv3x3_up_bwd_data: weights exceed 2 GiB");
+  {
+    const int nmax = batch_chunk(N, (long long)h * w * 9 * Cout * 4);
+    UNET_REQUIRE(nmax >= 1, "conv3x3_up_bwd_data: one image exceeds the 2 GiB buffer-descriptor range");
+    if (nmax < N) {
+      for (int nb = 0; nb < N; nb += nmax) {
+        const int n = N - nb < nmax ? N - nb : nmax;
+        const int rc = unet_conv3x3_up_bwd_data(D + (size_t)nb * h * w * 9 * Cout, wd, Cin_total,
+                                                ci_offset, g + (size_t)nb * h * w * Ccols, n, h, w,
+                                                Cout, Ccols, accumulate, stream);
+        if (rc != UNET_OK) return rc;
+      }
+      return UNET_OK;
+    }
+  }
   IgemmParams p{};
   p.src0 = D; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
   p.src0_pitch = 9 * Cout; p.tap_cstride = Cout;
@@ -1336,4 +1417,32 @@ extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin
   p.ntaps = 9; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
   for (int t = 0; t < 9; ++t) set_tap(p, t, 0, 0, t);
   return dispatch_igemm(p, (hipStream_t)stream);
+}
+
+// RGB stem straight from the dataset's uint8 HWC image: normalisation fused into the loader
+// (Our_UNet/src/train.py:303-308 + the first Conv2d of encoder_stages.0), statistics epilogue as
+// unet_conv_in_fwd.  Needs W % 128 == 0 (the raw-row form); other widths: unet_preprocess_u8.
+extern "C" int unet_stem_u8_fwd(const uint8_t* image_hwc, const float* mean3, const float* std3,
+                                const float* wf, const float* bias, float* y, void* workspace,
+                                size_t workspace_bytes, int* stats_px_out, int N, int H, int W,
+                                int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(image_hwc && mean3 && std3 && wf && y && workspace && stats_px_out,
+               "stem_u8_fwd: null pointer");
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0 && W % STEM_ROW_PIX == 0 && Cout > 0 && Cout % 32 == 0,
+               "stem_u8_fwd: needs W %% %d == 0 and Cout %% 32 == 0 (got W=%d Cout=%d)",
+               STEM_ROW_PIX, W, Cout);
+  if (workspace_bytes < unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1)) {
+    unet_set_error("stem_u8_fwd: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  StemNorm nm;
+  for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.std[c] = std3[c]; }
+  const long long M = (long long)N * H * W;
+  dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
+  hipLaunchKernelGGL(conv_stem_fwd_rows_kernel<unsigned char>, grid, dim3(256), 0,
+                     (hipStream_t)stream, image_hwc, wf, bias, y, N, H, W, Cout,
+                     reinterpret_cast<float2*>(workspace), nm);
+  UNET_CHECK_LAUNCH("conv_stem_fwd(u8)");
+  *stats_px_out = STEM_ROW_PIX;
+  return UNET_OK;
 }

@@ -53,6 +53,16 @@ struct IgemmParams {
   int src0_pitch;
 };
 
+// The kernels address their operands through buffer descriptors (free zero padding), whose
+// range is 2 GiB.  Images are independent along N, so the host dispatchers split a batch whose
+// tensor exceeds the range into chunks of this many images (0: one image is already too big).
+long long& chunk_limit_bytes();   // misc.hip; 2^31 - 1 unless a test lowered it
+inline int batch_chunk(int N, long long per_image_bytes) {
+  const long long lim = chunk_limit_bytes();
+  const long long n = lim / (per_image_bytes > 0 ? per_image_bytes : 1);
+  return (int)(n < N ? n : N);
+}
+
 inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
   const unsigned e = (unsigned)(oy + 1) | ((unsigned)(ox + 1) << 2) | ((unsigned)wt << 4);
   p.tapw[t >> 2] |= e << ((t & 3) * 8);

@@ -790,9 +790,20 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const float* __res
 // different banks.  Same stages, partial layout and reductions as conv_stem_wgrad_kernel.
 constexpr int SWR_PITCH = 393;
 
+// T = unsigned char: the dataset's uint8 image, normalised on load (see unet_stem_u8_fwd)
+struct StemNormW { float mean[3], std[3]; };
+__device__ __forceinline__ float stem_px(const float* x, size_t i, int, const StemNormW&) {
+  return x[i];
+}
+__device__ __forceinline__ float stem_px(const unsigned char* x, size_t i, int c,
+                                         const StemNormW& nm) {
+  return ((float)x[i] / 255.0f - nm.mean[c]) / nm.std[c];
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_rows_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
-    int H, int W, int Cout, int stages_per_block, long long total_stages) {
+    const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
+    int H, int W, int Cout, int stages_per_block, long long total_stages, const StemNormW nm) {
   __shared__ float Rw[3 * SWR_PITCH];
   __shared__ float D[SW_PIX * 32];      // [pix][co]
   __shared__ float R[4][32 * 32];
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_rows_kernel(
       const int iy = yy + ky - 1, ix = x0 - 1 + j / 3;
       float v = 0.f;
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = x[((size_t)n * HW + (size_t)iy * W + x0 - 1) * 3 + j];
+        v = stem_px(x, ((size_t)n * HW + (size_t)iy * W + x0 - 1) * 3 + j, j % 3, nm);
       Rw[ky * SWR_PITCH + j] = v;
     }
     for (int i = tid; i < SW_PIX * 8; i += 256) {
@@ -993,6 +1004,64 @@ WgradPlan make_plan_taps(long long Q, int Cx, int Cout) {
   return pl;
 }
 
+// kernel instantiation for a plan (tile, segment length, stride, operand mode)
+int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int prec,
+                      hipStream_t stream) {
+  // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
+  const bool use_bf16 = prec != 0 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
+  if (use_bf16 && prec == 3) {
+    if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64, 3, true>(p, stream);
+    if (pl.ci_t == 32) return launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
+    return launch_wgrad_bf16<64, 64, 16, 3>(p, stream);
+  }
+  if (use_bf16 && prec == 1) {
+    if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64>(p, stream);
+    if (pl.ci_t == 32) return launch_wgrad_bf16<32, 64, 32>(p, stream);
+    return pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
+                      : launch_wgrad_bf16<64, 64, 16>(p, stream);
+  }
+  if (pl.ci_t == 32 && pl.co_t == 32) {
+    if (stride == 1)
+      return pl.S == 64 ? launch_wgrad<32, 32, 64, 1>(p, stream)
+           : pl.S == 32 ? launch_wgrad<32, 32, 32, 1>(p, stream)
+                        : launch_wgrad<32, 32, 16, 1>(p, stream);
+    return pl.S == 32 ? launch_wgrad<32, 32, 32, 2>(p, stream)
+                      : launch_wgrad<32, 32, 16, 2>(p, stream);
+  }
+  if (pl.ci_t == 32 && pl.co_t == 64) {
+    if (stride == 1)
+      return pl.S == 32 ? launch_wgrad<32, 64, 32, 1>(p, stream)
+                        : launch_wgrad<32, 64, 16, 1>(p, stream);
+    return pl.S == 32 ? launch_wgrad<32, 64, 32, 2>(p, stream)
+                      : launch_wgrad<32, 64, 16, 2>(p, stream);
+  }
+  if (stride == 1)
+    return pl.S == 32 ? launch_wgrad<64, 64, 32, 1>(p, stream)
+                      : launch_wgrad<64, 64, 16, 1>(p, stream);
+  return launch_wgrad<64, 64, 16, 2>(p, stream);
+}
+
+// x and dy are addressed through 2 GiB buffer descriptors: a larger batch is processed in
+// chunks of `nmax` images whose slabs are reduced together.
+int wgrad_batch_chunk(int N, int H, int W, int Cx, int Cout, int stride) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long a = (long long)H * W * Cx * 4, b = (long long)Ho * Wo * Cout * 4;
+  return unet_conv::batch_chunk(N, a > b ? a : b);
+}
+
+size_t wgrad_ws_floats(int N, int H, int W, int Cx, int Cout, int stride, int prec) {
+  if (Cx == 3) return make_plan(N, H, W, Cx, Cout, stride, prec).ws_floats;
+  const int nmax = wgrad_batch_chunk(N, H, W, Cx, Cout, stride);
+  if (nmax < 1) return 0;
+  const size_t E = (size_t)9 * Cx * Cout;
+  size_t slabs = 0;
+  for (int nb = 0; nb < N; nb += nmax) {
+    const WgradPlan pl = make_plan(N - nb < nmax ? N - nb : nmax, H, W, Cx, Cout, stride, prec);
+    slabs += (size_t)pl.split * pl.npp;
+  }
+  return slabs * E + 2 * (size_t)ceil_div((int)slabs, kSlabChunk) * E;
+}
+
 // db[c] = sum over pixels of dy[.][c]: 64 row chunks per 32-channel group, then the chunk sums
 // (fixed order => deterministic).  out[chunk][C] when chunks > 1.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
@@ -1021,8 +1090,8 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
                                                           int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cx <= 0 || Cout <= 0) return 0;
   // one size for every operand mode (the bf16x3 plan uses shorter segments on 64x64 tiles)
-  const size_t a = make_plan(N, H, W, Cx, Cout, stride, 0).ws_floats;
-  const size_t b = make_plan(N, H, W, Cx, Cout, stride, 3).ws_floats;
+  const size_t a = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0);
+  const size_t b = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 3);
   return (a > b ? a : b) * sizeof(float);
 }
 
@@ -1031,16 +1100,18 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                                 size_t workspace_bytes, int N, int H, int W, int Cout, int stride,
                                 bool center_only, hipStream_t stream, int prec = 0,
                                 const float* act_alpha = nullptr, const float* act_beta = nullptr,
-                                float slope = 0.f) {
-  UNET_REQUIRE(x && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
+                                float slope = 0.f, const unsigned char* x_u8 = nullptr,
+                                const float* u8_mean_std = nullptr) {
+  UNET_REQUIRE((x || x_u8) && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
   UNET_REQUIRE(Cx == 3 || (Cx > 0 && Cx % 32 == 0), "conv3x3_bwd_weight: Cx %d unsupported", Cx);
   UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_bwd_weight: bad ci slice");
-  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride, (prec == 3 && stride == 1) ? 3 : 0);
-  if (workspace_bytes < pl.ws_floats * sizeof(float)) {
-    unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes,
-                   pl.ws_floats * sizeof(float));
+  const int pprec = (prec == 3 && stride == 1) ? 3 : 0;
+  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride, pprec);
+  const size_t need = wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec) * sizeof(float);
+  if (workspace_bytes < need || need == 0) {
+    unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     return UNET_E_WORKSPACE;
   }
   float* ws = reinterpret_cast<float*>(workspace);
@@ -1048,9 +1119,15 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   if (pl.stem) {
     UNET_REQUIRE(stride == 1 && Cin_total == 3 && ci_offset == 0, "conv3x3_bwd_weight: stem shape");
     dim3 grid(pl.stem_blocks, Cout / 32);
-    if (W % SW_PIX == 0)   // a 128-pixel stage never straddles image rows: raw-row form
-      hipLaunchKernelGGL(conv_stem_wgrad_rows_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H,
-                         W, Cout, pl.stem_spb, pl.stem_stages);
+    if (x_u8) {
+      UNET_REQUIRE(W % SW_PIX == 0, "stem_u8_bwd_weight: needs W %% %d == 0", SW_PIX);
+      StemNormW nm;
+      for (int c = 0; c < 3; ++c) { nm.mean[c] = u8_mean_std[c]; nm.std[c] = u8_mean_std[3 + c]; }
+      hipLaunchKernelGGL(conv_stem_wgrad_rows_kernel<unsigned char>, grid, dim3(256), 0, stream,
+                         x_u8, dy, ws, N, H, W, Cout, pl.stem_spb, pl.stem_stages, nm);
+    } else if (W % SW_PIX == 0)   // a 128-pixel stage never straddles image rows: raw-row form
+      hipLaunchKernelGGL(conv_stem_wgrad_rows_kernel<float>, grid, dim3(256), 0, stream, x, dy, ws,
+                         N, H, W, Cout, pl.stem_spb, pl.stem_stages, StemNormW{});
     else
       hipLaunchKernelGGL(conv_stem_wgrad_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H, W,
                          Cout, pl.stem_spb, pl.stem_stages);
@@ -1074,58 +1151,31 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                        dw_oihw, nslab, Cout);
     UNET_CHECK_LAUNCH("stem_wgrad_reduce");
   } else {
-    WgradParams p{};
-    p.x = x; p.dy = dy; p.partial = ws; p.Cx = Cx; p.Cout = Cout;
-    p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
-    p.segs_per_row = pl.segs_per_row; p.total_segs = pl.total_segs;
-    p.segs_per_block = pl.segs_per_block; p.split = pl.split;
-    p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
-    UNET_REQUIRE((long long)N * H * W * Cx * 4 < (1LL << 31) &&
-                     (long long)N * Ho * Wo * Cout * 4 < (1LL << 31),
-                 "conv3x3_bwd_weight: tensor exceeds the 2 GiB buffer-descriptor range");
-    p.x_bytes = (unsigned)((long long)N * H * W * Cx * 4);
-    p.dy_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
-    p.alpha = act_alpha; p.beta = act_beta; p.slope = slope;
     UNET_REQUIRE(!act_alpha || (act_beta && prec == 0),
                  "conv_bwd_weight: activation on load is an fp32-path feature");
-    int rc;
-    // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
-    const bool use_bf16 = prec != 0 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
-    if (use_bf16 && prec == 3) {
-      if (pl.ci_t == 32 && pl.co_t == 32) rc = launch_wgrad_bf16<32, 32, 64, 3, true>(p, stream);
-      else if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
-      else rc = launch_wgrad_bf16<64, 64, 16, 3>(p, stream);
-    } else if (use_bf16 && prec == 1) {
-      if (pl.ci_t == 32 && pl.co_t == 32) rc = launch_wgrad_bf16<32, 32, 64>(p, stream);
-      else if (pl.ci_t == 32) rc = launch_wgrad_bf16<32, 64, 32>(p, stream);
-      else rc = pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
-                           : launch_wgrad_bf16<64, 64, 16>(p, stream);
-    } else if (pl.ci_t == 32 && pl.co_t == 32) {
-      if (stride == 1)
-        rc = pl.S == 64 ? launch_wgrad<32, 32, 64, 1>(p, stream)
-           : pl.S == 32 ? launch_wgrad<32, 32, 32, 1>(p, stream)
-                        : launch_wgrad<32, 32, 16, 1>(p, stream);
-      else
-        rc = pl.S == 32 ? launch_wgrad<32, 32, 32, 2>(p, stream)
-                        : launch_wgrad<32, 32, 16, 2>(p, stream);
-    } else if (pl.ci_t == 32 && pl.co_t == 64) {
-      if (stride == 1)
-        rc = pl.S == 32 ? launch_wgrad<32, 64, 32, 1>(p, stream)
-                        : launch_wgrad<32, 64, 16, 1>(p, stream);
-      else
-        rc = pl.S == 32 ? launch_wgrad<32, 64, 32, 2>(p, stream)
-                        : launch_wgrad<32, 64, 16, 2>(p, stream);
-    } else {
-      if (stride == 1)
-        rc = pl.S == 32 ? launch_wgrad<64, 64, 32, 1>(p, stream)
-                        : launch_wgrad<64, 64, 16, 1>(p, stream);
-      else
-        rc = launch_wgrad<64, 64, 16, 2>(p, stream);
-    }
-    if (rc != UNET_OK) return rc;
     const size_t E = (size_t)9 * Cx * Cout;
+    const int nmax = wgrad_batch_chunk(N, H, W, Cx, Cout, stride);
+    int nslab = 0;
+    for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
+      const int nc = N - nb < nmax ? N - nb : nmax;
+      const WgradPlan pc = make_plan(nc, H, W, Cx, Cout, stride, pprec);
+      WgradParams p{};
+      p.x = x + (size_t)nb * H * W * Cx; p.dy = dy + (size_t)nb * Ho * Wo * Cout;
+      p.partial = ws + (size_t)nslab * E; p.Cx = Cx; p.Cout = Cout;
+      p.N = nc; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+      p.segs_per_row = pc.segs_per_row; p.total_segs = pc.total_segs;
+      p.segs_per_block = pc.segs_per_block; p.split = pc.split;
+      p.ci_tiles = Cx / pc.ci_t; p.co_tiles = Cout / pc.co_t;
+      p.x_bytes = (unsigned)((long long)nc * H * W * Cx * 4);
+      p.dy_bytes = (unsigned)((long long)nc * Ho * Wo * Cout * 4);
+      p.alpha = act_alpha ? act_alpha + (size_t)nb * Cx : nullptr;
+      p.beta = act_alpha ? act_beta + (size_t)nb * Cx : nullptr;
+      p.slope = slope;
+      const int rc = launch_wgrad_plan(p, pc, stride, prec, stream);
+      if (rc != UNET_OK) return rc;
+      nslab += pc.split * pc.npp;
+    }
     const float* cur = ws;
-    int nslab = pl.split * pl.npp;
     float* ping = ws + (size_t)nslab * E;
     float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
     while (nslab > 8) {
@@ -1224,9 +1274,27 @@ extern "C" int unet_conv_in_bwd_weight(const unet_act_src* x, float slope, const
 }
 
 // ---- conv3x3(upsample2x(a)): weight gradient w.r.t. the up-sampled operand at low resolution
+namespace {
+int up_wgrad_chunk(int N, int h, int w, int Cx, int Cout) {
+  const long long a = (long long)h * w * Cx * 4, b = (long long)h * w * 9 * Cout * 4;
+  return unet_conv::batch_chunk(N, a > b ? a : b);
+}
+size_t up_wgrad_ws_floats(int N, int h, int w, int Cx, int Cout) {
+  const int nmax = up_wgrad_chunk(N, h, w, Cx, Cout);
+  if (nmax < 1) return 0;
+  const size_t E = (size_t)9 * Cx * Cout;
+  size_t slabs = 0;
+  for (int nb = 0; nb < N; nb += nmax) {
+    const WgradPlan pl = make_plan_taps((long long)(N - nb < nmax ? N - nb : nmax) * h * w, Cx, Cout);
+    slabs += (size_t)pl.split * pl.npp;
+  }
+  return slabs * E + 2 * (size_t)ceil_div((int)slabs, kSlabChunk) * E;
+}
+}  // namespace
+
 extern "C" size_t unet_conv3x3_up_bwd_weight_workspace_bytes(int N, int h, int w, int Cx, int Cout) {
   if (N <= 0 || h <= 0 || w <= 0 || Cx <= 0 || Cout <= 0) return 0;
-  return make_plan_taps((long long)N * h * w, Cx, Cout).ws_floats * sizeof(float);
+  return up_wgrad_ws_floats(N, h, w, Cx, Cout) * sizeof(float);
 }
 
 extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, const float* D,
@@ -1240,33 +1308,40 @@ extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, co
                "conv3x3_up_bwd_weight: bad shape Cx=%d Cout=%d", Cx, Cout);
   UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_up_bwd_weight: bad ci slice");
   UNET_REQUIRE(!x->alpha || x->beta, "conv3x3_up_bwd_weight: alpha without beta");
-  const long long Q = (long long)N * h * w;
-  UNET_REQUIRE(Q * Cx * 4 < (1LL << 31) && Q * 9 * Cout * 4 < (1LL << 31),
-               "conv3x3_up_bwd_weight: tensor exceeds the 2 GiB buffer-descriptor range");
-  const WgradPlan pl = make_plan_taps(Q, Cx, Cout);
-  if (workspace_bytes < pl.ws_floats * sizeof(float)) {
-    unet_set_error("conv3x3_up_bwd_weight: workspace %zu < %zu bytes", workspace_bytes,
-                   pl.ws_floats * sizeof(float));
+  const int nmax = up_wgrad_chunk(N, h, w, Cx, Cout);
+  UNET_REQUIRE(nmax >= 1, "conv3x3_up_bwd_weight: one image exceeds the 2 GiB buffer-descriptor range");
+  const size_t need = up_wgrad_ws_floats(N, h, w, Cx, Cout) * sizeof(float);
+  if (workspace_bytes < need) {
+    unet_set_error("conv3x3_up_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     return UNET_E_WORKSPACE;
   }
   float* ws = reinterpret_cast<float*>(workspace);
-  WgradParams p{};
-  p.x = x->x; p.dy = D; p.partial = ws; p.Cx = Cx; p.Cout = Cout;
-  p.N = N; p.H = h; p.W = w; p.Ho = h; p.Wo = w;
-  p.segs_per_row = 0; p.total_segs = pl.total_segs;
-  p.segs_per_block = pl.segs_per_block; p.split = pl.split;
-  p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
-  p.x_bytes = (unsigned)(Q * Cx * 4);
-  p.dy_bytes = (unsigned)(Q * 9 * Cout * 4);
-  p.alpha = x->alpha; p.beta = x->beta; p.slope = slope;
-  int rc;
-  if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
-  else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
-  else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
-  if (rc != UNET_OK) return rc;
   const size_t E = (size_t)9 * Cx * Cout;
+  int nslab = 0;
+  for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
+    const int nc = N - nb < nmax ? N - nb : nmax;
+    const long long Q = (long long)nc * h * w;
+    const WgradPlan pl = make_plan_taps(Q, Cx, Cout);
+    WgradParams p{};
+    p.x = x->x + (size_t)nb * h * w * Cx; p.dy = D + (size_t)nb * h * w * 9 * Cout;
+    p.partial = ws + (size_t)nslab * E; p.Cx = Cx; p.Cout = Cout;
+    p.N = nc; p.H = h; p.W = w; p.Ho = h; p.Wo = w;
+    p.segs_per_row = 0; p.total_segs = pl.total_segs;
+    p.segs_per_block = pl.segs_per_block; p.split = pl.split;
+    p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
+    p.x_bytes = (unsigned)(Q * Cx * 4);
+    p.dy_bytes = (unsigned)(Q * 9 * Cout * 4);
+    p.alpha = x->alpha ? x->alpha + (size_t)nb * Cx : nullptr;
+    p.beta = x->alpha ? x->beta + (size_t)nb * Cx : nullptr;
+    p.slope = slope;
+    int rc;
+    if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
+    else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
+    else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
+    if (rc != UNET_OK) return rc;
+    nslab += pl.split * pl.npp;
+  }
   const float* cur = ws;
-  int nslab = pl.split * pl.npp;
   float* ping = ws + (size_t)nslab * E;
   float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
   while (nslab > 8) {
@@ -1284,4 +1359,17 @@ extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, co
                      Cout, ci_offset, Cin_total);
   UNET_CHECK_LAUNCH("wgrad_reduce");
   return UNET_OK;
+}
+
+// Weight gradient of the RGB stem from the uint8 image (normalised on load, W % 128 == 0);
+// workspace as unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, 3, Cout, 1).
+extern "C" int unet_stem_u8_bwd_weight(const uint8_t* image_hwc, const float* mean3,
+                                       const float* std3, const float* dy, float* dw_oihw,
+                                       void* workspace, size_t workspace_bytes, int N, int H,
+                                       int W, int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(image_hwc && mean3 && std3, "stem_u8_bwd_weight: null pointer");
+  const float ms[6] = {mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
+  return conv_bwd_weight_impl(nullptr, 3, dy, dw_oihw, 0, 3, nullptr, workspace, workspace_bytes,
+                              N, H, W, Cout, 1, false, (hipStream_t)stream, 0, nullptr, nullptr,
+                              0.f, image_hwc, ms);
 }

@@ -13,6 +13,18 @@ void unet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* unet_last_error(void) { return g_err; }
+
+namespace unet_conv {
+long long& chunk_limit_bytes() {
+  static long long lim = (1LL << 31) - 1;
+  return lim;
+}
+}  // namespace unet_conv
+
+extern "C" int unet_debug_set_chunk_limit(int64_t bytes) {
+  unet_conv::chunk_limit_bytes() = (bytes > 0 && bytes < (1LL << 31)) ? bytes : (1LL << 31) - 1;
+  return UNET_OK;
+}
 extern "C" int unet_abi_version(void) { return UNET_ABI_VERSION; }
 extern "C" int unet_device_count(void) {
   int n = 0;

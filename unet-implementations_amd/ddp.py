@@ -35,6 +35,7 @@ class GradBucketAllReduce:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._works = []
         self._hi = None
+        self.sent_ranges = []    # (lo, hi) arena ranges handed to all_reduce, newest last
         model.grad_ready_hook = self._on_ready
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world if average else 1.0
@@ -44,13 +45,14 @@ class GradBucketAllReduce:
         _, garena = self.model.flat_parameters()
         if self._hi is None:
             self._hi = garena.numel()
-        if self._hi - lo >= self.bucket_elems or lo == 0:
+        if self._hi - lo >= self.bucket_elems or lo <= self._frozen_prefix():
             self._launch(garena, lo, self._hi)
             self._hi = lo
 
     def _launch(self, garena, lo, hi):
         if hi <= lo:
             return
+        self.sent_ranges.append((lo, hi))
         if self.world == 1:
             return
         self._works.append(dist.all_reduce(garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
@@ -68,9 +70,25 @@ class GradBucketAllReduce:
                 return off
         return 0
 
+    def check_gradients_alias_arena(self):
+        """The exchange ships the gradient ARENA: every trainable parameter's .grad must be a
+        view into it (it is when autograd adopted the tensor UNet.backward returned).  A
+        detached copy would silently train on un-reduced gradients, so fail loudly."""
+        _, garena = self.model.flat_parameters()
+        if getattr(self.model, "_offsets", None) is None or \
+                not hasattr(self.model, "named_parameters"):
+            return      # a bare arena (tests): nothing to cross-check
+        gbase = garena.data_ptr()
+        for (name, p), off in zip(self.model.named_parameters(), self.model._offsets):
+            if p.requires_grad and p.grad is not None and p.grad.data_ptr() != gbase + 4 * off:
+                raise RuntimeError(
+                    f"{name}.grad does not alias the gradient arena, so the all-reduce did not "
+                    "cover it (was .grad assigned by hand, or accumulated into a foreign tensor?)")
+
     def finish(self):
         """Call between backward and optimizer.step(): flushes the tail bucket and makes the
         current stream wait for every outstanding all-reduce."""
+        self.check_gradients_alias_arena()
         if self._hi is not None and self._hi > 0 and self.world > 1:
             _, garena = self.model.flat_parameters()
             self._launch(garena, self._frozen_prefix(), self._hi)

@@ -16,29 +16,35 @@ def _stream():
 
 
 class KernelTimer:
-    """HIP-event timing of the matrix-core kernels, recorded on the stream the kernels are
-    launched on (torch's current stream).  bench.py installs one over its timed region to
-    report `roofline.achieved` = algorithmic FLOPs / measured kernel time."""
+    """HIP-event timing of kernel launches, recorded on the stream the kernels are launched on
+    (torch's current stream).  bench.py installs one over its timed region to report
+    `roofline.achieved` = algorithmic FLOPs / measured kernel time, the MFMA FLOPs actually
+    issued (`executed`: lower where a gradient is reassociated onto the low-resolution grid) and
+    the HBM rates of the streaming kernels (`nbytes` = algorithmic bytes)."""
 
     def __init__(self):
-        self.records = []  # (tag, flops, launches, start_event, end_event)
+        self.records = []  # (tag, flops, launches, start_event, end_event, executed, nbytes)
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def end(self, tag, flops, launches, start):
+    def end(self, tag, flops, launches, start, executed=None, nbytes=0.0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.records.append((tag, flops, launches, start, ev))
+        self.records.append((tag, flops, launches, start, ev,
+                             flops if executed is None else executed, nbytes))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for tag, flops, launches, e0, e1 in self.records:
-            d = out.setdefault(tag, dict(flops=0.0, ms=0.0, launches=0, calls=0))
+        for tag, flops, launches, e0, e1, executed, nbytes in self.records:
+            d = out.setdefault(tag, dict(flops=0.0, executed=0.0, bytes=0.0, ms=0.0, launches=0,
+                                         calls=0))
             d["flops"] += flops
+            d["executed"] += executed
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += launches
             d["calls"] += 1
@@ -46,6 +52,7 @@ class KernelTimer:
 
 
 _timer = None
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
 def set_timer(timer):
@@ -309,10 +316,13 @@ def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma,
     N, H, W, C = y.shape
     dy = ga if out is None else out
     ws = _ws(lib().unet_instnorm_workspace_bytes(N, H * W, C), y)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_instnorm_lrelu_drop_bwd(_ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd),
                                              _ptr(gamma), _ptr(beta), _ptr(mask), slope, _ptr(dy),
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws),
                                              ws.numel(), N, H * W, C, _stream()))
+    if t0 is not None:   # reduce pass: ga + y; apply pass: ga + y in, dy out (+ tiny finalizers)
+        _timer.end("instnorm_bwd", 0.0, 5, t0, nbytes=4.0 * 5 * y.numel())
     return dy
 
 
@@ -336,6 +346,30 @@ class Act:
         return ActSrc(_ptr(self.x), self.x.shape[3], _ptr(self.alpha), _ptr(self.beta))
 
 
+class U8Image:
+    """The dataset's uint8 HWC batch [N, H, W, 3] as the operand of the RGB stem: normalised
+    ((v / 255) - mean) / std inside the loaders of the first convolution and of its weight
+    gradient (unet_stem_u8_fwd / _bwd_weight), never materialised as fp32."""
+
+    __slots__ = ("x", "mean", "std")
+
+    def __init__(self, x, mean=None, std=None):
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3 or not x.is_contiguous():
+            raise TypeError("U8Image takes a contiguous uint8 [N,H,W,3] tensor")
+        if x.shape[2] % 128:
+            raise ValueError("the fused uint8 stem needs W % 128 == 0 (use preprocess_u8 otherwise)")
+        self.x = x
+        self.mean = tuple(IMAGENET_MEAN if mean is None else mean)
+        self.std = tuple(IMAGENET_STD if std is None else std)
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+    def c_mean_std(self):
+        return (ctypes.c_float * 3)(*self.mean), (ctypes.c_float * 3)(*self.std)
+
+
 def _act(a):
     if a is None:
         return None, None
@@ -349,7 +383,9 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask):
     """Fused layer forward: y = conv(cat(act(s0), act(s1))) + bias and the InstanceNorm
     statistics of y.  Returns (y, st) with st = [mean, rstd, alpha, beta] as [4, N, Cout];
     alpha / beta carry the dropout `mask` [N, Cout] (or None) folded in."""
-    s0, r0 = _act(s0)
+    u8 = s0 if isinstance(s0, U8Image) else None
+    if u8 is None:
+        s0, r0 = _act(s0)
     s1, r1 = _act(s1)
     N, H, W, C0 = s0.shape
     C1 = 0 if s1 is None else s1.shape[3]
@@ -361,19 +397,39 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask):
     y = _f32((N, Ho, Wo, Cout), s0.x)
     st = _f32((4, N, Cout), s0.x)
     ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, stride), s0.x)
+    px = ctypes.c_int(0)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv_in_fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y),
-                                 _ptr(gamma), _ptr(beta), eps, _ptr(mask), _ptr(st[0]),
-                                 _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), _ptr(ws), ws.numel(), N, H,
-                                 W, Cout, _stream()))
-    if t0 is not None:   # the conv launch + the statistics finalize
+    if u8 is not None:
+        assert s1 is None and ksize == 3 and stride == 1
+        m3, s3 = u8.c_mean_std()
+        check(lib().unet_stem_u8_fwd(_ptr(u8.x), m3, s3, _ptr(w), _ptr(bias), _ptr(y), _ptr(ws),
+                                     ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
+    else:
+        check(lib().unet_conv_in_fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y),
+                                     _ptr(ws), ws.numel(), ctypes.byref(px), N, H, W, Cout,
+                                     _stream()))
+    if t0 is not None:   # the convolution launch alone (its epilogue includes the statistics)
         _timer.end("conv_stem_fwd" if C0 == 3 else "conv_igemm",
                    2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout, 1, t0)
+    check(lib().unet_conv_in_stats_finalize(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma),
+                                            _ptr(beta), eps, _ptr(mask), _ptr(st[0]), _ptr(st[1]),
+                                            _ptr(st[2]), _ptr(st[3]), N, Ho * Wo, Cout, _stream()))
     return y, st
 
 
 def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
     """Weight gradient of a fused layer: dw[:, ci_offset : ci_offset + Cx] = act(x) (x) dy."""
+    if isinstance(x, U8Image):
+        N, H, W, _ = x.shape
+        Cout = dy.shape[3]
+        ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, 3, Cout, 1), dy)
+        m3, s3 = x.c_mean_std()
+        t0 = _timer.begin() if _timer is not None else None
+        check(lib().unet_stem_u8_bwd_weight(_ptr(x.x), m3, s3, _ptr(dy), _ptr(dw_oihw), _ptr(ws),
+                                            ws.numel(), N, H, W, Cout, _stream()))
+        if t0 is not None:
+            _timer.end("conv_stem_wgrad", 2.0 * N * H * W * 27 * Cout, 2, t0)
+        return dw_oihw
     x, rx = _act(x)
     N, H, W, Cx = x.shape
     Cout = dy.shape[3]
@@ -393,7 +449,10 @@ def upsample2x_in_fwd(x, slope):
     x, rx = _act(x)
     N, h, w, C = x.shape
     up = _f32((N, 2 * h, 2 * w, C), x.x)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_upsample2x_in_fwd(rx, slope, _ptr(up), N, h, w, _stream()))
+    if t0 is not None:
+        _timer.end("upsample2x_fwd", 0.0, 1, t0, nbytes=4.0 * (x.x.numel() + up.numel()))
     return up
 
 
@@ -401,7 +460,10 @@ def upsample2x_bwd_taps(dy):
     """D[N, h, w, 9*C] = the nine transposed-upsampled shifts of dy[N, 2h, 2w, C] (tap-major)."""
     N, H2, W2, C = dy.shape
     D = _f32((N, H2 // 2, W2 // 2, 9 * C), dy)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_upsample2x_bwd_taps(_ptr(dy), _ptr(D), N, H2 // 2, W2 // 2, C, _stream()))
+    if t0 is not None:   # reads dy once, writes 9/4 of it
+        _timer.end("upsample2x_bwd_taps", 0.0, 1, t0, nbytes=4.0 * dy.numel() * (1 + 9 / 4))
     return D
 
 
@@ -417,7 +479,8 @@ def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
                                            dw_oihw.shape[1], _ptr(ws), ws.numel(), N, h, w, Cout,
                                            _stream()))
     if t0 is not None:   # algorithmic FLOPs: the 3x3 weight gradient on the up-sampled grid
-        _timer.end("conv_wgrad", 2.0 * N * 4 * h * w * 9 * Cx * Cout, 2, t0)
+        _timer.end("conv_wgrad", 2.0 * N * 4 * h * w * 9 * Cx * Cout, 2, t0,
+                   executed=2.0 * N * h * w * 9 * Cx * Cout)
     return dw_oihw
 
 
@@ -432,7 +495,8 @@ def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False):
     check(lib().unet_conv3x3_up_bwd_data(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w,
                                          Cout, ccols, 1 if accumulate else 0, _stream()))
     if t0 is not None:   # algorithmic FLOPs: the 3x3 data gradient on the up-sampled grid
-        _timer.end("conv_igemm", 2.0 * N * 4 * h * w * 9 * ccols * Cout, 1, t0)
+        _timer.end("conv_igemm", 2.0 * N * 4 * h * w * 9 * ccols * Cout, 1, t0,
+                   executed=2.0 * N * h * w * 9 * ccols * Cout)
     return g
 
 
@@ -441,8 +505,11 @@ def head1x1_in_fwd(x, slope, w, b):
     N, H, W, C = x.shape
     K = w.shape[0]
     logits = _f32((N, K, H, W), x.x)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_head1x1_in_fwd(rx, slope, _ptr(w), _ptr(b), _ptr(logits), N, H * W, K,
                                     _stream()))
+    if t0 is not None:
+        _timer.end("head_fwd", 0.0, 1, t0, nbytes=4.0 * (x.x.numel() + logits.numel()))
     return logits
 
 
@@ -452,8 +519,11 @@ def head1x1_in_bwd(x, slope, dlogits, w, dw, db):
     K = w.shape[0]
     da = torch.empty_like(x.x)
     ws = _ws(lib().unet_head1x1_bwd_workspace_bytes(N, H * W, C, K), x.x)
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_head1x1_in_bwd(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw),
                                     _ptr(db), _ptr(ws), ws.numel(), N, H * W, K, _stream()))
+    if t0 is not None:
+        _timer.end("head_bwd", 0.0, 2, t0, nbytes=4.0 * (2 * da.numel() + dlogits.numel()))
     return da
 
 
@@ -565,9 +635,6 @@ def argmax_classes(logits):
     return preds
 
 
-IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
-
-
 def preprocess_u8(image_hwc_u8, mask_u8=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     """uint8 [N,H,W,3] (+ uint8 [N,H,W]) on the device -> (fp32 NHWC image, int64 target)."""
     import ctypes
@@ -591,9 +658,12 @@ def preprocess_u8(image_hwc_u8, mask_u8=None, mean=IMAGENET_MEAN, std=IMAGENET_S
 # ---- optimizer -------------------------------------------------------------------------
 def sgd_nesterov_step(params, grads, momentum, lr, mu, weight_decay, first_step, grad_scale=1.0):
     n = params.numel()
+    t0 = _timer.begin() if _timer is not None else None
     check(lib().unet_sgd_nesterov_step(_ptr(params), _ptr(grads), _ptr(momentum), n, lr, mu,
                                        weight_decay, 1 if first_step else 0, grad_scale,
                                        _stream()))
+    if t0 is not None:   # p, g, buf in; p, buf out
+        _timer.end("sgd_nesterov", 0.0, 1, t0, nbytes=4.0 * (5 if not first_step else 4) * n)
 
 
 def add_inplace(a, b):

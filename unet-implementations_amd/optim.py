@@ -55,7 +55,17 @@ class FusedSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if self._flat_ready():
+        flat = self._flat_ready()
+        if not flat and self.grad_scale != 1.0 and self._model is not None:
+            # grad_scale is set by the data-parallel wrapper, which all-reduces the ARENA: a
+            # gradient that left the arena was not reduced
+            m = self._model
+            _, garena = m.flat_parameters()
+            for (name, p), off in zip(m.named_parameters(), m._offsets):
+                if p.grad is not None and p.grad.data_ptr() != garena.data_ptr() + 4 * off:
+                    raise RuntimeError(f"{name}.grad does not alias the gradient arena the "
+                                       "all-reduce operates on")
+        if flat:
             g = self.param_groups[0]
             arena, garena = self._model.flat_parameters()
             first = self._flat_buf is None

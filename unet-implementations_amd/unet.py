@@ -210,6 +210,9 @@ class UNet(nn.Module):
         # fp32 operand mode only: keep just the raw conv outputs in HBM (statistics from the
         # conv epilogue, InstanceNorm + LeakyReLU + dropout applied by the consumers on load)
         self.fused_pipeline = True
+        # normalisation constants of forward(..., input_layout="nhwc_u8") (ImageNet, as the
+        # reference's dataset: Our_UNet/src/train.py:303-308)
+        self.input_mean, self.input_std = ops.IMAGENET_MEAN, ops.IMAGENET_STD
 
     def _build_bottleneck(self, common):
         """Hook for variants that add modules between encoder and decoder (CLIPUNet)."""
@@ -344,11 +347,26 @@ class UNet(nn.Module):
 
     # -- forward ----------------------------------------------------------------------------------
     def forward(self, x, extra=None, input_layout="nchw"):
-        """`input_layout="nhwc"` takes the [N,H,W,3] tensor of `ops.preprocess_u8` directly."""
-        if input_layout == "nhwc":
+        """`input_layout="nhwc"` takes the fp32 [N,H,W,3] tensor of `ops.preprocess_u8` directly;
+        `"nhwc_u8"` takes the dataset's uint8 [N,H,W,3] batch itself: its normalisation
+        ((v / 255) - input_mean) / input_std (Our_UNet/src/train.py:303-308) then runs inside the
+        loaders of the first convolution (fused pipeline, W % 128 == 0; other cases go through
+        `ops.preprocess_u8`)."""
+        u8 = None
+        if input_layout == "nhwc_u8":
+            if x.dtype != torch.uint8:
+                raise TypeError("input_layout='nhwc_u8' takes a uint8 [N,H,W,3] tensor")
+            fusable = self.matmul_precision == "fp32" and self.fused_pipeline and \
+                x.is_cuda and x.dim() == 4 and x.shape[2] % 128 == 0
+            if fusable:
+                u8 = ops.U8Image(x.contiguous(), self.input_mean, self.input_std)
+            else:
+                x = ops.preprocess_u8(x.contiguous(), None, self.input_mean, self.input_std)[0]
+            x = x.permute(0, 3, 1, 2)
+        elif input_layout == "nhwc":
             x = x.permute(0, 3, 1, 2)      # a view: the shape checks below see NCHW sizes
         elif input_layout != "nchw":
-            raise ValueError("input_layout must be 'nchw' or 'nhwc'")
+            raise ValueError("input_layout must be 'nchw', 'nhwc' or 'nhwc_u8'")
         if not x.is_cuda:
             raise RuntimeError("unet-implementations_amd.UNet runs on MI355X only: move the model "
                                "and the input to a ROCm device (no CPU fallback exists)")
@@ -363,7 +381,9 @@ class UNet(nn.Module):
         self._ensure_arena()
         params = list(self.parameters())
         self._param_index = {id(p): i for i, p in enumerate(params)}
-        if input_layout == "nhwc":
+        if u8 is not None:
+            x_nhwc = u8
+        elif input_layout != "nchw":
             x_nhwc = x.permute(0, 2, 3, 1).contiguous().float()     # already NHWC in memory
         else:
             x_nhwc = ops.nchw_to_nhwc(x.contiguous().float())
@@ -417,8 +437,9 @@ class _UNetFunction(torch.autograd.Function):
             [l for blk in dec for l in blk]
         need_grad = any(ctx.needs_input_grad)  # False under no_grad / frozen parameters
         N = x.shape[0]
+        dev = x.x.device if isinstance(x, ops.U8Image) else x.device
         use_masks = model.training or model.dropout_mask_override is not None
-        masks = _draw_masks(model, layers, N, x.device) if use_masks else [None] * len(layers)
+        masks = _draw_masks(model, layers, N, dev) if use_masks else [None] * len(layers)
         mask_of = {id(l): m for l, m in zip(layers, masks)}
         saved = []  # per layer: dict(inputs, y, stats, mask, a)
         if model.matmul_precision not in ("fp32", "bf16", "bf16x3"):
@@ -482,9 +503,11 @@ class _UNetFunction(torch.autograd.Function):
                 saved[-1]["x0_low"] = low
             return out
 
+        if isinstance(x, ops.U8Image) and not fused:
+            raise RuntimeError("the uint8 stem needs the fused fp32 pipeline")
         if fused:
             run_layer = run_layer_fused
-            cur = ops.Act(x)     # the NHWC image is a plain operand
+            cur = x if isinstance(x, ops.U8Image) else ops.Act(x)   # the image: a plain operand
         else:
             cur = x          # NHWC image
         skips = []
@@ -533,6 +556,23 @@ class _UNetFunction(torch.autograd.Function):
         enc, dec = model._plan
         gv = model._grad_view
         dlogits = dlogits.contiguous()
+        # The kernels WRITE the gradient arena and the returned views normally become p.grad.
+        # A gradient that already exists (a second backward before the step, or
+        # zero_grad(set_to_none=False)) must be accumulated into instead: arena-aliased ones
+        # are saved here and added back below (autograd gets None for them: adding the returned
+        # view to itself would double it); foreign tensors are left to autograd's own `+=`.
+        gbase = model._grad_arena.data_ptr()
+        carried = {}
+        for p, off in zip(params, model._offsets):
+            if p.grad is not None and p.grad.data_ptr() == gbase + 4 * off:
+                carried[id(p)] = p.grad.detach().clone()
+        if carried and model.grad_ready_hook is not None:
+            raise RuntimeError(
+                "gradient accumulation (a parameter already has .grad) cannot be combined with "
+                "the bucketed all-reduce hook: the buckets would ship before the old gradient is "
+                "added.  Clear model.grad_ready_hook for the accumulation micro-steps, or call "
+                "optimizer.zero_grad() (set_to_none=True) before each backward.")
+        touched = set()      # ids of parameters whose gradient this backward produced
         head = model.segmentation_output
         fused, slope = ctx.fused, ctx.slope
         hw = head.weight.detach().view(head.out_channels, -1)
@@ -543,6 +583,7 @@ class _UNetFunction(torch.autograd.Function):
             g = ops.head1x1_bwd(saved[-1]["a"], dlogits, hw,
                                 gv(head.weight).view(head.out_channels, -1), gv(head.bias))
         ctx.last = None
+        touched.update(id(q) for q in head.parameters())
 
         idx = len(saved) - 1
         skip_grads = {}
@@ -573,6 +614,7 @@ class _UNetFunction(torch.autograd.Function):
             rec = saved[i]
             l = rec["layer"]
             st = rec["st"]
+            touched.update(id(q) for q in (l.conv.weight, l.conv.bias, l.norm.weight, l.norm.bias))
             need_dx = need_dx and i > stop       # the first trainable layer needs no dx
             dbg = getattr(model, "_debug_capture", None)
             if dbg is not None:
@@ -678,7 +720,19 @@ class _UNetFunction(torch.autograd.Function):
             if not done:
                 ready(model.encoder_stages[bi])
         if hook is not None:
-            hook(0)       # frozen prefix: everything below is final (and zero-filled by us)
+            # everything below the first trainable parameter is a frozen prefix: no gradient,
+            # nothing to exchange
+            hook(next((off for p, off in zip(params, model._offsets) if p.requires_grad), 0))
         ctx.saved = None
-        grads = [gv(p) if p.requires_grad else None for p in params]
+        grads = []
+        for p in params:
+            # no gradient for frozen parameters and for layers that did not run (e.g. the CLIP
+            # fusion layer when no features were passed): like the reference, .grad stays None
+            if not p.requires_grad or id(p) not in touched:
+                grads.append(None)
+            elif id(p) in carried:
+                gv(p).add_(carried[id(p)])     # p.grad is this view: accumulated in place
+                grads.append(None)
+            else:
+                grads.append(gv(p))
         return (None, None, None, *grads)
