@@ -96,21 +96,32 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     dwacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     dbacc[k] = 0.f;
   }
+  const bool one_image = HW % HT == 0;   // a tile never straddles images
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
     const long long m0 = t * HT;
     // all loads of the tile first (rows past M are clamped and masked: no branch, so the eight
     // pixel loads and 8 x K gradient loads are in flight together)
     f32x4 av[HT / 32];
     float dv[HT / 32][4];
+    f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if (alpha && one_image) {   // uniform: one coefficient row for the whole tile
+      const size_t o = (size_t)(m0 / HW) * 32 + seg * 4;
+      al = *reinterpret_cast<const f32x4*>(alpha + o);
+      be = *reinterpret_cast<const f32x4*>(beta + o);
+    }
 #pragma unroll
     for (int it = 0; it < HT / 32; ++it) {
       const long long m = m0 + it * 32 + grp;
       const long long mc = m < M ? m : M - 1;
       av[it] = *reinterpret_cast<const f32x4*>(a + (size_t)mc * 32 + seg * 4);
-      const long long n = mc / HW, pp = mc - n * HW;
-      if (alpha)   // uniform: the operand is a raw convolution output, activated on load
-        av[it] = act4(av[it], *reinterpret_cast<const f32x4*>(alpha + (size_t)n * 32 + seg * 4),
-                      *reinterpret_cast<const f32x4*>(beta + (size_t)n * 32 + seg * 4), slope, true);
+      const long long n = one_image ? m0 / HW : mc / HW, pp = mc - n * HW;
+      if (alpha) {   // uniform: the operand is a raw convolution output, activated on load
+        if (!one_image) {
+          al = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * 32 + seg * 4);
+          be = *reinterpret_cast<const f32x4*>(beta + (size_t)n * 32 + seg * 4);
+        }
+        av[it] = act4(av[it], al, be, slope, true);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         dv[it][k] = (k < K && m < M) ? dl[((size_t)n * K + k) * HW + pp] : 0.f;

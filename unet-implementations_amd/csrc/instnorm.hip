@@ -150,6 +150,58 @@ __global__ __launch_bounds__(32 * FL) void in_stats_finalize_kernel(
   }
 }
 
+// Finalize for the statistics epilogue of the convolutions: every one of the `tiles` summaries
+// of an image holds the same number of pixels `per`, so the merge needs no running counts or
+// divisions:  mean = avg(mean_t),  M2 = sum(M2_t) + per * sum((mean_t - mean)^2).
+// block = 32 channels x FL lanes, grid (C/32, N); two passes over the (L2-resident) summaries,
+// fixed-order LDS trees (deterministic).
+__global__ __launch_bounds__(32 * FL) void in_stats_finalize_eq_kernel(
+    const float2* __restrict__ partial, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, const float* __restrict__ mask,
+    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ alpha,
+    float* __restrict__ beta2, int HW, int C, int tiles, float per) {
+  __shared__ float sa[FL][33];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
+  const float2* src = partial + (size_t)n * tiles * C + c;
+  auto block_sum = [&](float v) {
+    sa[l][cl] = v;
+    __syncthreads();
+#pragma unroll
+    for (int stride = FL / 2; stride >= 1; stride >>= 1) {
+      if (l < stride) sa[l][cl] += sa[l + stride][cl];
+      __syncthreads();
+    }
+    const float r = sa[0][cl];
+    __syncthreads();
+    return r;
+  };
+  float s = 0.f;
+  if (c < C)
+    for (int t = l; t < tiles; t += FL) s += src[(size_t)t * C].x;
+  const float mu = block_sum(s) / (float)tiles;
+  float q = 0.f;
+  if (c < C)
+    for (int t = l; t < tiles; t += FL) {
+      const float2 v = src[(size_t)t * C];
+      const float d = v.x - mu;
+      q += fmaf(per * d, d, v.y);
+    }
+  q = block_sum(q);
+  if (l == 0 && c < C) {
+    const int i = n * C + c;
+    const float var = q / (float)HW;  // biased, like F.instance_norm
+    const float rs = 1.0f / sqrtf(var + eps);
+    mean[i] = mu;
+    rstd[i] = rs;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float a = g * rs;
+    const float mk = mask ? mask[i] : 1.f;
+    if (alpha) alpha[i] = a * mk;
+    if (beta2) beta2[i] = (b - mu * a) * mk;
+  }
+}
+
 // ---------------------------------------------------------------- forward apply
 __global__ __launch_bounds__(kThreads) void in_apply_fwd_kernel(
     const float* __restrict__ y, const float* __restrict__ alpha, const float* __restrict__ beta2,
@@ -430,9 +482,9 @@ int unet_in_finalize_tiles(const void* partial, int tiles, int px_per_tile, cons
                            hipStream_t stream) {
   UNET_REQUIRE(partial && mean && rstd && tiles > 0 && tiles * px_per_tile == HW,
                "in_finalize_tiles: %d tiles of %d pixels do not cover %d", tiles, px_per_tile, HW);
-  hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
-                     reinterpret_cast<const float2*>(partial), gamma, beta, eps, mask, mean, rstd,
-                     alpha, beta2, N, HW, C, tiles);
+  hipLaunchKernelGGL(in_stats_finalize_eq_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0,
+                     stream, reinterpret_cast<const float2*>(partial), gamma, beta, eps, mask, mean,
+                     rstd, alpha, beta2, HW, C, tiles, (float)px_per_tile);
   UNET_CHECK_LAUNCH("in_stats_finalize(tiles)");
   return UNET_OK;
 }
