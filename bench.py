@@ -75,8 +75,12 @@ def roofline_of(summ, steps, matmul, args):
         # low-resolution grid (1/4 of the algorithmic 3x3 work), everything else executes its
         # algorithmic count
         "executed": k["executed"] / sec * 1e-12, "executed_frac": k["executed"] / sec * 1e-12 / peak,
-        "kernel": "convolution forward + data-gradient group (conv_patch_f32_kernel, "
-                  "conv_igemm_kernel, conv_igemm_rf_kernel, conv_dgrad_s2_kernel): "
+        "kernel": "convolution forward + data-gradient group ("
+                  + {"fp32": "conv_patch_f32_kernel, conv_igemm_kernel, conv_igemm_rf_kernel, "
+                             "conv_dgrad_s2_kernel",
+                     "bf16": "conv_igemm_bf16_kernel on bf16 tensors",
+                     "bf16x3": "conv_patch_split_kernel, conv_igemm_split_kernel + fp32 "
+                               "fallbacks"}[matmul] + "): "
                   f"{k['flops'] / steps * 1e-12:.3f} of the step's "
                   f"{total / steps * 1e-12:.3f} algorithmic conv TFLOP",
         "launches_per_step": k["launches"] / steps,
@@ -304,7 +308,8 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands; f32 accumulate + storage)",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (layer tensors and MFMA operands bf16; f32 "
+                                            "accumulate, statistics, weights, optimizer)",
                       "bf16x3": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMA products per "
                                 "multiply, f32 accumulate + storage)"}[args.matmul],
             "data": "synthetic",

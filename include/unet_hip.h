@@ -388,6 +388,56 @@ int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin_total, int
                              float* g, int N, int h, int w, int Cout, int Ccols, int accumulate,
                              unet_stream_t stream);
 
+/* ---- mixed precision with bf16 activations in HBM (BASELINE config 4) ----------------------
+ * The reference's AMP path is fp16 autocast + GradScaler (Our_UNet/src/train.py:638-652); the
+ * MI355X form is bf16 (fp32's exponent range: no loss scaling).  The *_b16 entry points are the
+ * fused-pipeline entry points above with every layer tensor -- raw convolution outputs y,
+ * activation gradients, dy, D -- stored as bf16 (uint16_t* here; `x` of a unet_act_src then
+ * points to bf16 data) while the RGB image, logits, InstanceNorm statistics / coefficients,
+ * weights, weight gradients and the optimizer state stay fp32.  Convolutions contract bf16
+ * operands on the bf16 matrix cores with fp32 accumulation (stride-1 weight gradients too;
+ * stride-2 weight gradients and the low-resolution tap GEMM use the fp32 matrix cores on bf16
+ * storage); the activation and all InstanceNorm arithmetic are fp32 on values widened on load;
+ * statistics come from the fp32 accumulators before y is rounded. */
+int unet_conv_in_fwd_b16(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                         const float* w, const float* bias, int ksize, int stride, uint16_t* y,
+                         void* workspace, size_t workspace_bytes, int* stats_px_out, int N, int H,
+                         int W, int Cout, unet_stream_t stream);
+int unet_conv_in_stats_finalize_b16(const uint16_t* y, void* workspace, size_t workspace_bytes,
+                                    int stats_px, const float* gamma, const float* beta, float eps,
+                                    const float* mask, float* mean, float* rstd, float* alpha_out,
+                                    float* beta_out, int N, int HoWo, int Cout,
+                                    unet_stream_t stream);
+int unet_conv_in_bwd_weight_b16(const unet_act_src* x, float slope, const uint16_t* dy,
+                                float* dw_oihw, int ci_offset, int Cin_total, int ksize, int stride,
+                                void* workspace, size_t workspace_bytes, int N, int H, int W,
+                                int Cout, unet_stream_t stream);
+int unet_conv3x3_bwd_data_b16(const uint16_t* dy, const float* wd, int Cin_total, int ci_offset,
+                              uint16_t* dx, int N, int H, int W, int Cout, int Ccols, int stride,
+                              int accumulate, unet_stream_t stream);
+int unet_instnorm_lrelu_drop_bwd_b16(const uint16_t* ga, const uint16_t* y, const float* mean,
+                                     const float* rstd, const float* gamma, const float* beta,
+                                     const float* mask, float slope, uint16_t* dy, float* dgamma,
+                                     float* dbeta, float* dbias, void* workspace,
+                                     size_t workspace_bytes, int N, int HW, int C,
+                                     unet_stream_t stream);
+int unet_upsample2x_in_fwd_b16(const unet_act_src* x, float slope, uint16_t* up, int N, int h,
+                               int w, unet_stream_t stream);
+int unet_upsample2x_bwd_taps_b16(const uint16_t* dy, uint16_t* D, int N, int h, int w, int C,
+                                 unet_stream_t stream);
+int unet_conv3x3_up_bwd_weight_b16(const unet_act_src* x, float slope, const uint16_t* D,
+                                   float* dw_oihw, int ci_offset, int Cin_total, void* workspace,
+                                   size_t workspace_bytes, int N, int h, int w, int Cout,
+                                   unet_stream_t stream);
+int unet_conv3x3_up_bwd_data_b16(const uint16_t* D, const float* wd, int Cin_total, int ci_offset,
+                                 uint16_t* g, int N, int h, int w, int Cout, int Ccols,
+                                 int accumulate, unet_stream_t stream);
+int unet_head1x1_in_fwd_b16(const unet_act_src* x, float slope, const float* w, const float* b,
+                            float* logits_nchw, int N, int HW, int K, unet_stream_t stream);
+int unet_head1x1_in_bwd_b16(const unet_act_src* x, float slope, const float* dlogits_nchw,
+                            const float* w, uint16_t* da, float* dw, float* db, void* workspace,
+                            size_t workspace_bytes, int N, int HW, int K, unet_stream_t stream);
+
 /* Head on an activated-on-load operand: logits = act(x) . w + b, and its backward
  * (da = dL/d act(x), dw, db); x->C == 32. */
 int unet_head1x1_in_fwd(const unet_act_src* x, float slope, const float* w, const float* b,

@@ -129,6 +129,43 @@ def draw_dropout_masks(seed, n):
 
 
 # --------------------------------------------------------------------------- per-op
+class _StoreBF16(torch.autograd.Function):
+    """A tensor that lives in HBM as bf16: rounded where it is written, forward and backward
+    (the mixed-precision pipeline stores activations and activation gradients as bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _operand_bf16(w):
+    """A matrix-core operand rounded on chip (weights): forward value rounded, gradient exact."""
+    return w + (w.bfloat16().float() - w).detach()
+
+
+def conv_in_lrelu_drop_bf16(x, w, b, gamma, beta, stride, mask=None, slope=NEG_SLOPE):
+    """The conv -> InstanceNorm -> LeakyReLU -> dropout unit with the rounding points of the
+    MI355X mixed-precision pipeline (BASELINE config 4; the reference's own AMP path is fp16
+    autocast, Our_UNet/src/train.py:638-652): operands of the convolution rounded to bf16, fp32
+    accumulation, statistics from the fp32 result, the result stored as bf16, everything after
+    it computed in fp32 from the stored value.  `x` is the previous unit's fp32 activation
+    (computed on the fly from its stored bf16 tensor)."""
+    y = F.conv2d(_operand_bf16(x) if not x.requires_grad else _StoreBF16.apply(x),
+                 _operand_bf16(w), b, stride=stride, padding=w.shape[-1] // 2)
+    mu = y.mean(dim=(2, 3), keepdim=True)
+    var = y.var(dim=(2, 3), unbiased=False, keepdim=True)
+    ys = _StoreBF16.apply(y)
+    z = (ys - mu) * torch.rsqrt(var + EPS) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    a = F.leaky_relu(z, slope)
+    if mask is not None:
+        a = a * mask.view(mask.shape[0], mask.shape[1], 1, 1)
+    return a
+
+
 def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None, slope=NEG_SLOPE):
     """Conv2d(3x3, pad 1) -> InstanceNorm2d(eps, affine) -> LeakyReLU(0.01) -> channel mask
     (models/unet.py:101-134; SpatialDropout2d.forward :22-35).  `record` (debug): list that
@@ -153,7 +190,8 @@ def upsample_concat(x, skip):
 
 
 # --------------------------------------------------------------------------- network
-def unet_forward(sd, x, masks=None, record=None, clip_features=None, slope=NEG_SLOPE):
+def unet_forward(sd, x, masks=None, record=None, clip_features=None, slope=NEG_SLOPE,
+                 bf16_storage=False):
     """UNet.forward (models/unet.py:399-432).  `masks`: list from draw_dropout_masks (train
     mode) or None (eval / rates 0).  `record` (debug): collects each conv's raw output.
     `clip_features` [N,clip_dim,h/32,w/32]: the CLIP_UNet bottleneck fusion
@@ -173,6 +211,13 @@ def unet_forward(sd, x, masks=None, record=None, clip_features=None, slope=NEG_S
         if kind == "dec_first":
             cur = upsample_concat(cur, skips.pop())
         m = next(mi) if (mi is not None and p > 0) else None
+        if bf16_storage:     # emulation of the MI355X mixed-precision pipeline's rounding points
+            cur = conv_in_lrelu_drop_bf16(cur, sd[f"{prefix}.{ci}.weight"],
+                                          sd[f"{prefix}.{ci}.bias"], sd[f"{prefix}.{ni}.weight"],
+                                          sd[f"{prefix}.{ni}.bias"], stride, m, slope)
+            if kind == "enc" and li % 2 == 1 and li < n_enc - 1:
+                skips.append(cur)
+            continue
         cur = conv_in_lrelu_drop(cur, sd[f"{prefix}.{ci}.weight"], sd[f"{prefix}.{ci}.bias"],
                                  sd[f"{prefix}.{ni}.weight"], sd[f"{prefix}.{ni}.bias"], stride, m,
                                  record, slope)

@@ -87,6 +87,21 @@ SIGNATURES = {
                                      _i, _i, _p]),
     "unet_conv_in_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
+    "unet_conv_in_fwd_b16": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i), _i, _i,
+                                  _i, _i, _p]),
+    "unet_conv_in_stats_finalize_b16": (_i, [_p, _p, _sz, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i,
+                                             _i, _p]),
+    "unet_conv_in_bwd_weight_b16": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i,
+                                         _p]),
+    "unet_conv3x3_bwd_data_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_instnorm_lrelu_drop_bwd_b16": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
+                                              _sz, _i, _i, _i, _p]),
+    "unet_upsample2x_in_fwd_b16": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
+    "unet_upsample2x_bwd_taps_b16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_up_bwd_weight_b16": (_i, [_ps, _f, _p, _p, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_conv3x3_up_bwd_data_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "unet_head1x1_in_fwd_b16": (_i, [_ps, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "unet_head1x1_in_bwd_b16": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _p]),
     "unet_upsample2x_bwd_taps": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "unet_conv3x3_up_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "unet_conv3x3_up_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),

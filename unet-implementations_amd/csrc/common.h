@@ -70,7 +70,7 @@ int unet_in_finalize_tiles(const void* partial, int tiles, int px_per_tile, cons
 int unet_in_stats_masked(const float* y, const float* gamma, const float* beta, float eps,
                          const float* mask, float* mean, float* rstd, float* alpha, float* beta2,
                          void* workspace, size_t workspace_bytes, int N, int HW, int C,
-                         hipStream_t stream);
+                         hipStream_t stream, int y_is_bf16 = 0);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -105,6 +105,40 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
   for (int i = 0; i < 4; ++i) { m[i] = (__bf16)r1[i]; r2[i] = r1[i] - (float)m[i]; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) l[i] = (__bf16)r2[i];
+}
+
+// ---- storage-type helpers -------------------------------------------------------------------
+// Activations live in HBM as fp32 or (mixed-precision mode, BASELINE config 4) as bf16; all
+// arithmetic on them is fp32.  ld4 / st4 move four consecutive channels, buf_ld4 does the same
+// through a buffer descriptor (`off` in ELEMENTS, `oob` = 0 or 0x80000000 to force the
+// out-of-range zero).
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+  const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, const f32x4 v) {
+  bf16x4 h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  *reinterpret_cast<bf16x4*>(p) = h;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+template <typename T>
+__device__ __forceinline__ f32x4 buf_ld4(const __amdgpu_buffer_rsrc_t rs, unsigned off,
+                                         unsigned oob) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (off * 4u) | oob, 0, 0));
+  } else {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (off * 2u) | oob, 0, 0);
+    // bf16 -> fp32 is a 16-bit shift
+    return f32x4{__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xffff0000),
+                 __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xffff0000)};
+  }
 }
 
 // Chan/Welford merge of (count, mean, M2) pairs.

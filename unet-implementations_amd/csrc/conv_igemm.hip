@@ -810,10 +810,11 @@ namespace {
 constexpr int STEM_PIX = 256;  // pixels per block
 constexpr int STEM_LDK = 29;   // odd row stride: conflict-free column reads
 
+template <typename TO>
 __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ wf,
                                                             const float* __restrict__ bias,
-                                                            float* __restrict__ y, int N, int H,
+                                                            TO* __restrict__ y, int N, int H,
                                                             int W, int Cout) {
   __shared__ float A[STEM_PIX * STEM_LDK];
   __shared__ float B[28 * 32];
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) {
       const int row = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const long long mg = m0 + row;
-      if (mg < M) y[(size_t)mg * Cout + co0 + li] = acc[m][r] + bv;
+      if (mg < M) st1(y + (size_t)mg * Cout + co0 + li, acc[m][r] + bv);
     }
 }
 
@@ -893,11 +894,11 @@ __device__ __forceinline__ float stem_pixel(const unsigned char* x, size_t i, in
   return ((float)x[i] / 255.0f - nm.mean[c]) / nm.std[c];
 }
 
-template <typename T>
+template <typename T, typename TO = float>
 __global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const T* __restrict__ x,
                                                                  const float* __restrict__ wf,
                                                                  const float* __restrict__ bias,
-                                                                 float* __restrict__ y, int N,
+                                                                 TO* __restrict__ y, int N,
                                                                  int H, int W, int Cout,
                                                                  float2* __restrict__ stats,
                                                                  const StemNorm nm) {
@@ -940,7 +941,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const T* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    y[(size_t)(m0 + row) * Cout + co0 + li] = acc[r] + bv;
+    st1(y + (size_t)(m0 + row) * Cout + co0 + li, acc[r] + bv);
   }
   if (stats) {   // fused layer pipeline: (mean, M2) of this 128-pixel tile per output column
     const float2 mine = wave_col_stats<1>([&](int, int r) { return acc[r] + bv; });
@@ -983,8 +984,8 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
                          y, N, H, W, Cout, (float2*)nullptr, StemNorm{});
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
-      hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, x0, wf, bias, y, N, H,
-                         W, Cout);
+      hipLaunchKernelGGL(conv_stem_fwd_kernel<float>, grid, dim3(256), 0, stream, x0, wf, bias, y,
+                         N, H, W, Cout);
     }
     UNET_CHECK_LAUNCH("conv_stem_fwd");
     return UNET_OK;
@@ -1063,7 +1064,9 @@ extern "C" int unet_conv3x3_fwd_bf16x3(const float* x0, int C0, const float* x1,
 static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total, int ci_offset,
                                  float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
                                  int accumulate, int prec, hipStream_t stream,
-                                 const uint16_t* wd3 = nullptr) {
+                                 const uint16_t* wd3 = nullptr, int b16 = 0) {
+  // b16: dy and dx are bf16 tensors (mixed-precision pipeline; prec is then 1)
+  const long long es = b16 ? 2 : 4;
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
   UNET_REQUIRE(prec != 3 || wd3, "conv3x3_bwd_data_bf16x3: the pre-split weight planes are null");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_data: stride %d unsupported", stride);
@@ -1077,14 +1080,17 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   UNET_REQUIRE((long long)9 * Cout * Cin_total * 4 < (1LL << 31),
                "conv3x3_bwd_data: weights exceed 2 GiB");
   {  // batch chunks keep dy inside the 2 GiB buffer-descriptor range
-    const int nmax = batch_chunk(N, (long long)Ho * Wo * Cout * 4);
+    const int nmax = batch_chunk(N, (long long)Ho * Wo * Cout * es);
     UNET_REQUIRE(nmax >= 1, "conv3x3_bwd_data: one image exceeds the 2 GiB buffer-descriptor range");
     if (nmax < N) {
       for (int nb = 0; nb < N; nb += nmax) {
         const int n = N - nb < nmax ? N - nb : nmax;
-        const int rc = conv3x3_bwd_data_impl(dy + (size_t)nb * Ho * Wo * Cout, wd, Cin_total,
-                                             ci_offset, dx + (size_t)nb * H * W * Ccols, n, H, W,
-                                             Cout, Ccols, stride, accumulate, prec, stream, wd3);
+        const int rc = conv3x3_bwd_data_impl(
+            reinterpret_cast<const float*>(reinterpret_cast<const char*>(dy) +
+                                           (size_t)nb * Ho * Wo * Cout * es),
+            wd, Cin_total, ci_offset,
+            reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (size_t)nb * H * W * Ccols * es),
+            n, H, W, Cout, Ccols, stride, accumulate, prec, stream, wd3, b16);
         if (rc != UNET_OK) return rc;
       }
       return UNET_OK;
@@ -1093,7 +1099,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   IgemmParams p{};
   p.src0 = dy; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
   p.w = wd; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
-  p.src0_bytes = (unsigned)((long long)N * Ho * Wo * Cout * 4);
+  p.src0_bytes = (unsigned)((long long)N * Ho * Wo * Cout * es);
   p.src1_bytes = 0;
   p.w_bytes = (unsigned)((long long)9 * Cout * Cin_total * 4);
   p.out = dx; p.ldo = Ccols; p.accumulate = accumulate;
@@ -1109,6 +1115,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     p.ntaps = 9;
     p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
+    if (b16) return dispatch_igemm_b16(p, stream, nullptr);
     if (prec == 1) return dispatch_igemm_bf16(p, stream);
     if (prec == 3) return dispatch_igemm_split(p, stream);
     if (rf_applicable(p) && (Cout == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
@@ -1122,7 +1129,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
     // one launch for all four parity classes when there are enough tiles to fill the chip
     const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
-    if (prec != 1 && !per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
+    if (prec != 1 && !b16 && !per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
   }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
@@ -1138,8 +1145,9 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
         }
       }
       p.ntaps = nt;
-      int rc = prec == 1 ? dispatch_igemm_bf16(p, stream)
-                         : (prec == 3 ? dispatch_igemm_split(p, stream) : dispatch_igemm(p, stream));
+      int rc = b16 ? dispatch_igemm_b16(p, stream, nullptr)
+                   : prec == 1 ? dispatch_igemm_bf16(p, stream)
+                   : (prec == 3 ? dispatch_igemm_split(p, stream) : dispatch_igemm(p, stream));
       if (rc != UNET_OK) return rc;
     }
   return UNET_OK;
@@ -1159,6 +1167,16 @@ extern "C" int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int 
                                           unet_stream_t stream) {
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
                                accumulate, 1, (hipStream_t)stream);
+}
+
+// dy and dx are bf16 tensors, bf16 matrix cores (mixed-precision pipeline)
+extern "C" int unet_conv3x3_bwd_data_b16(const uint16_t* dy, const float* wd, int Cin_total,
+                                         int ci_offset, uint16_t* dx, int N, int H, int W, int Cout,
+                                         int Ccols, int stride, int accumulate,
+                                         unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(reinterpret_cast<const float*>(dy), wd, Cin_total, ci_offset,
+                               reinterpret_cast<float*>(dx), N, H, W, Cout, Ccols, stride,
+                               accumulate, 1, (hipStream_t)stream, nullptr, 1);
 }
 
 extern "C" int unet_conv3x3_bwd_data_bf16x3(const float* dy, const float* wd,
@@ -1264,11 +1282,13 @@ extern "C" size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout
   return a > b ? a : b;
 }
 
-extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope,
-                                const float* w, const float* bias, int ksize, int stride, float* y,
-                                void* workspace, size_t workspace_bytes, int* stats_px_out, int N,
-                                int H, int W, int Cout, unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// b16: the layer tensors (sources other than the RGB image, and y) are bf16 in HBM and the
+// contraction runs on the bf16 matrix cores (mixed-precision pipeline); else fp32 / fp32 MFMA.
+static int conv_in_fwd_impl(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                            const float* w, const float* bias, int ksize, int stride, float* y,
+                            void* workspace, size_t workspace_bytes, int* stats_px_out, int N,
+                            int H, int W, int Cout, hipStream_t stream, int b16) {
+  const size_t es = b16 ? 2 : 4;   // bytes per activation element
   UNET_REQUIRE(s0 && s0->x && w && y && workspace && stats_px_out, "conv_in_fwd: null pointer");
   UNET_REQUIRE(ksize == 3 || ksize == 1, "conv_in_fwd: kernel size %d unsupported", ksize);
   UNET_REQUIRE(stride == 1 || (stride == 2 && ksize == 3), "conv_in_fwd: stride %d unsupported",
@@ -1286,15 +1306,26 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
     UNET_REQUIRE(C1 == 0 && stride == 1 && ksize == 3 && !s0->alpha,
                  "conv_in_fwd: the RGB stem is a plain stride-1 3x3 single source");
     const long long M = (long long)N * H * W;
+    __bf16* yh = reinterpret_cast<__bf16*>(y);
     if (W % STEM_ROW_PIX == 0) {
       dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
-      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel<float>, grid, dim3(256), 0, stream, s0->x, w,
-                         bias, y, N, H, W, Cout, reinterpret_cast<float2*>(workspace), StemNorm{});
+      if (b16)
+        hipLaunchKernelGGL((conv_stem_fwd_rows_kernel<float, __bf16>), grid, dim3(256), 0, stream,
+                           s0->x, w, bias, yh, N, H, W, Cout, reinterpret_cast<float2*>(workspace),
+                           StemNorm{});
+      else
+        hipLaunchKernelGGL((conv_stem_fwd_rows_kernel<float, float>), grid, dim3(256), 0, stream,
+                           s0->x, w, bias, y, N, H, W, Cout, reinterpret_cast<float2*>(workspace),
+                           StemNorm{});
       stats_px = STEM_ROW_PIX;
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
-      hipLaunchKernelGGL(conv_stem_fwd_kernel, grid, dim3(256), 0, stream, s0->x, w, bias, y, N, H,
-                         W, Cout);
+      if (b16)
+        hipLaunchKernelGGL(conv_stem_fwd_kernel<__bf16>, grid, dim3(256), 0, stream, s0->x, w, bias,
+                           yh, N, H, W, Cout);
+      else
+        hipLaunchKernelGGL(conv_stem_fwd_kernel<float>, grid, dim3(256), 0, stream, s0->x, w, bias,
+                           y, N, H, W, Cout);
     }
     UNET_CHECK_LAUNCH("conv_stem_fwd");
   } else {
@@ -1307,14 +1338,17 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
     const int taps = ksize * ksize;
     UNET_REQUIRE((long long)taps * Cout * Cin * 4 < (1LL << 31), "conv_in_fwd: weights exceed 2 GiB");
     // batch chunks keep each source inside the 2 GiB buffer-descriptor range
-    const int nmax = batch_chunk(N, (long long)H * W * (C0 > C1 ? C0 : C1) * 4);
+    const int nmax = batch_chunk(N, (long long)H * W * (C0 > C1 ? C0 : C1) * (long long)es);
     UNET_REQUIRE(nmax >= 1, "conv_in_fwd: one image exceeds the 2 GiB buffer-descriptor range");
     const bool chunked = nmax < N;
     for (int nb = 0; nb < N; nb += nmax) {
       const int n = (N - nb) < nmax ? (N - nb) : nmax;
       IgemmParams p{};
-      p.src0 = s0->x + (size_t)nb * H * W * C0;
-      p.src1 = s1 ? s1->x + (size_t)nb * H * W * C1 : nullptr;
+      p.src0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s0->x) +
+                                              (size_t)nb * H * W * C0 * es);
+      p.src1 = s1 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(s1->x) +
+                                                   (size_t)nb * H * W * C1 * es)
+                  : nullptr;
       p.C0 = C0; p.C1 = C1;
       p.act0_alpha = s0->alpha ? s0->alpha + (size_t)nb * C0 : nullptr;
       p.act0_beta = s0->alpha ? s0->beta + (size_t)nb * C0 : nullptr;
@@ -1322,10 +1356,12 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
       p.act1_beta = (s1 && s1->alpha) ? s1->beta + (size_t)nb * C1 : nullptr;
       p.slope = slope;
       p.w = w; p.tap_stride = Cout * Cin; p.n_off = 0; p.bias = bias;
-      p.src0_bytes = (unsigned)((long long)n * H * W * C0 * 4);
-      p.src1_bytes = (unsigned)((long long)n * H * W * C1 * 4);
+      p.src0_bytes = (unsigned)((long long)n * H * W * C0 * (long long)es);
+      p.src1_bytes = (unsigned)((long long)n * H * W * C1 * (long long)es);
       p.w_bytes = (unsigned)((long long)taps * Cout * Cin * 4);
-      p.out = y + (size_t)nb * Ho * Wo * Cout; p.ldo = Cout; p.accumulate = 0;
+      p.out = reinterpret_cast<float*>(reinterpret_cast<char*>(y) +
+                                       (size_t)nb * Ho * Wo * Cout * es);
+      p.ldo = Cout; p.accumulate = 0;
       p.N = n; p.Hin = H; p.Win = W;
       p.Hl = p.Hout = Ho; p.Wl = p.Wout = Wo;
       p.Ncols = Cout;
@@ -1338,7 +1374,10 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
         p.sin = 1; p.sout = 1; p.py = p.px = 0;
         p.ntaps = 1; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
         set_tap(p, 0, 0, 0, 0);
-        rc = dispatch_igemm(p, stream, &px);
+        rc = b16 ? dispatch_igemm_b16(p, stream, &px) : dispatch_igemm(p, stream, &px);
+      } else if (b16) {
+        fill_fwd_taps(p, stride);
+        rc = dispatch_igemm_b16(p, stream, &px);
       } else {
         fill_fwd_taps(p, stride);
         // K = 32: row-fused kernel with the weights resident in LDS; wider K: the patch kernel
@@ -1357,11 +1396,59 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
   return UNET_OK;
 }
 
+extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                                const float* w, const float* bias, int ksize, int stride, float* y,
+                                void* workspace, size_t workspace_bytes, int* stats_px_out, int N,
+                                int H, int W, int Cout, unet_stream_t stream) {
+  return conv_in_fwd_impl(s0, s1, slope, w, bias, ksize, stride, y, workspace, workspace_bytes,
+                          stats_px_out, N, H, W, Cout, (hipStream_t)stream, 0);
+}
+
+// Mixed-precision pipeline (BASELINE config 4): the sources (except the fp32 RGB image) and y
+// are bf16 tensors in HBM, the operands are contracted on the bf16 matrix cores with fp32
+// accumulation, the statistics come from the fp32 accumulators.  w / bias stay fp32 (master).
+extern "C" int unet_conv_in_fwd_b16(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                                    const float* w, const float* bias, int ksize, int stride,
+                                    uint16_t* y, void* workspace, size_t workspace_bytes,
+                                    int* stats_px_out, int N, int H, int W, int Cout,
+                                    unet_stream_t stream) {
+  return conv_in_fwd_impl(s0, s1, slope, w, bias, ksize, stride, reinterpret_cast<float*>(y),
+                          workspace, workspace_bytes, stats_px_out, N, H, W, Cout,
+                          (hipStream_t)stream, 1);
+}
+
+static int conv_in_stats_finalize_impl(const float* y, void* workspace, size_t workspace_bytes,
+                                       int stats_px, const float* gamma, const float* beta,
+                                       float eps, const float* mask, float* mean, float* rstd,
+                                       float* alpha_out, float* beta_out, int N, int HoWo, int Cout,
+                                       unet_stream_t stream, int b16);
+
 extern "C" int unet_conv_in_stats_finalize(const float* y, void* workspace, size_t workspace_bytes,
                                            int stats_px, const float* gamma, const float* beta,
                                            float eps, const float* mask, float* mean, float* rstd,
                                            float* alpha_out, float* beta_out, int N, int HoWo,
                                            int Cout, unet_stream_t stream) {
+  return conv_in_stats_finalize_impl(y, workspace, workspace_bytes, stats_px, gamma, beta, eps,
+                                     mask, mean, rstd, alpha_out, beta_out, N, HoWo, Cout, stream,
+                                     0);
+}
+
+extern "C" int unet_conv_in_stats_finalize_b16(const uint16_t* y, void* workspace,
+                                               size_t workspace_bytes, int stats_px,
+                                               const float* gamma, const float* beta, float eps,
+                                               const float* mask, float* mean, float* rstd,
+                                               float* alpha_out, float* beta_out, int N, int HoWo,
+                                               int Cout, unet_stream_t stream) {
+  return conv_in_stats_finalize_impl(reinterpret_cast<const float*>(y), workspace, workspace_bytes,
+                                     stats_px, gamma, beta, eps, mask, mean, rstd, alpha_out,
+                                     beta_out, N, HoWo, Cout, stream, 1);
+}
+
+static int conv_in_stats_finalize_impl(const float* y, void* workspace, size_t workspace_bytes,
+                                       int stats_px, const float* gamma, const float* beta,
+                                       float eps, const float* mask, float* mean, float* rstd,
+                                       float* alpha_out, float* beta_out, int N, int HoWo, int Cout,
+                                       unet_stream_t stream, int b16) {
   UNET_REQUIRE(y && workspace && mean && rstd, "conv_in_stats_finalize: null pointer");
   UNET_REQUIRE(stats_px >= 0 && (stats_px == 0 || HoWo % stats_px == 0),
                "conv_in_stats_finalize: %d-pixel tiles do not cover %d pixels", stats_px, HoWo);
@@ -1370,7 +1457,7 @@ extern "C" int unet_conv_in_stats_finalize(const float* y, void* workspace, size
                                   mean, rstd, alpha_out, beta_out, N, HoWo, Cout,
                                   (hipStream_t)stream);
   return unet_in_stats_masked(y, gamma, beta, eps, mask, mean, rstd, alpha_out, beta_out, workspace,
-                              workspace_bytes, N, HoWo, Cout, (hipStream_t)stream);
+                              workspace_bytes, N, HoWo, Cout, (hipStream_t)stream, b16);
 }
 
 // ---------------------------------------------------------------------------
@@ -1380,9 +1467,30 @@ extern "C" int unet_conv_in_stats_finalize(const float* y, void* workspace, size
 // resolution pixels with K = 9*Cout, i.e. a quarter of the FLOPs of the 3x3 data gradient on the
 // up-sampled grid, and it lands directly on the low-resolution tensor (no upsample2x_bwd pass).
 // ---------------------------------------------------------------------------
+static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
+                                    float* g, int N, int h, int w, int Cout, int Ccols,
+                                    int accumulate, unet_stream_t stream, int b16);
+
 extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin_total,
                                         int ci_offset, float* g, int N, int h, int w, int Cout,
                                         int Ccols, int accumulate, unet_stream_t stream) {
+  return conv3x3_up_bwd_data_impl(D, wd, Cin_total, ci_offset, g, N, h, w, Cout, Ccols, accumulate,
+                                  stream, 0);
+}
+
+extern "C" int unet_conv3x3_up_bwd_data_b16(const uint16_t* D, const float* wd, int Cin_total,
+                                            int ci_offset, uint16_t* g, int N, int h, int w,
+                                            int Cout, int Ccols, int accumulate,
+                                            unet_stream_t stream) {
+  return conv3x3_up_bwd_data_impl(reinterpret_cast<const float*>(D), wd, Cin_total, ci_offset,
+                                  reinterpret_cast<float*>(g), N, h, w, Cout, Ccols, accumulate,
+                                  stream, 1);
+}
+
+static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
+                                    float* g, int N, int h, int w, int Cout, int Ccols,
+                                    int accumulate, unet_stream_t stream, int b16) {
+  const long long es = b16 ? 2 : 4;
   UNET_REQUIRE(D && wd && g, "conv3x3_up_bwd_data: null pointer");
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
                    ci_offset + Ccols <= Cin_total && N > 0 && h > 0 && w > 0,
@@ -1391,14 +1499,17 @@ extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin
   UNET_REQUIRE((long long)9 * Cout * Cin_total * 4 < (1LL << 31),
                "conv3x3_up_bwd_data: weights exceed 2 GiB");
   {
-    const int nmax = batch_chunk(N, (long long)h * w * 9 * Cout * 4);
+    const int nmax = batch_chunk(N, (long long)h * w * 9 * Cout * es);
     UNET_REQUIRE(nmax >= 1, "conv3x3_up_bwd_data: one image exceeds the 2 GiB buffer-descriptor range");
     if (nmax < N) {
       for (int nb = 0; nb < N; nb += nmax) {
         const int n = N - nb < nmax ? N - nb : nmax;
-        const int rc = unet_conv3x3_up_bwd_data(D + (size_t)nb * h * w * 9 * Cout, wd, Cin_total,
-                                                ci_offset, g + (size_t)nb * h * w * Ccols, n, h, w,
-                                                Cout, Ccols, accumulate, stream);
+        const int rc = conv3x3_up_bwd_data_impl(
+            reinterpret_cast<const float*>(reinterpret_cast<const char*>(D) +
+                                           (size_t)nb * h * w * 9 * Cout * es),
+            wd, Cin_total, ci_offset,
+            reinterpret_cast<float*>(reinterpret_cast<char*>(g) + (size_t)nb * h * w * Ccols * es),
+            n, h, w, Cout, Ccols, accumulate, stream, b16);
         if (rc != UNET_OK) return rc;
       }
       return UNET_OK;
@@ -1408,7 +1519,7 @@ extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin
   p.src0 = D; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
   p.src0_pitch = 9 * Cout; p.tap_cstride = Cout;
   p.w = wd; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
-  p.src0_bytes = (unsigned)((long long)N * h * w * 9 * Cout * 4);
+  p.src0_bytes = (unsigned)((long long)N * h * w * 9 * Cout * es);
   p.src1_bytes = 0;
   p.w_bytes = (unsigned)((long long)9 * Cout * Cin_total * 4);
   p.out = g; p.ldo = Ccols; p.accumulate = accumulate;
@@ -1416,6 +1527,7 @@ extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin
   p.Ncols = Ccols; p.sin = 1; p.sout = 1; p.py = p.px = 0;
   p.ntaps = 9; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
   for (int t = 0; t < 9; ++t) set_tap(p, t, 0, 0, t);
+  if (b16) return dispatch_igemm_b16(p, (hipStream_t)stream, nullptr);
   return dispatch_igemm(p, (hipStream_t)stream);
 }
 

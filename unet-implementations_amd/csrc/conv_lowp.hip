@@ -15,7 +15,11 @@ namespace {
 // matrix rate, so the kernel turns load/L2-bound).  Same gather-GEMM, tap table, tiles and
 // epilogue as conv_igemm_kernel; LDS rows hold 32 bf16 + 8 pad (80 B: conflict-free b128).
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// TS / TO: storage type of the source / output activations (float, or __bf16 in the real
+// mixed-precision pipeline where the layer tensors live in HBM as bf16).  FUSED: activation on
+// load + statistics epilogue of the fused layer pipeline (IgemmParams), as conv_igemm_kernel.
+template <int BM, int BN, int WM, int WN, typename TS = float, typename TO = float,
+          bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmParams p) {
   constexpr int BK = 32;
   constexpr int LDA = BK + 8;  // bf16 elements per LDS row
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
   // ---- loaders: thread -> (row lrow + 32*i, 16-B segment lseg) for both tiles ----
   const int lrow = tid / SEGS, lseg = tid % SEGS;
   int a_nb[A_PASSES], a_iy[A_PASSES], a_ix[A_PASSES];
+  int a_img[FUSED ? A_PASSES : 1];   // FUSED: image of each staged row (its coefficient row)
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + lrow + ROWS * i;
@@ -57,10 +62,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
       a_nb[i] = n * p.Hin * p.Win;
       a_iy[i] = a * p.sin;
       a_ix[i] = b * p.sin;
+      if (FUSED) a_img[i] = n;
     } else {
       a_nb[i] = 0;
       a_iy[i] = -(1 << 24);
       a_ix[i] = 0;
+      if (FUSED) a_img[i] = 0;
     }
   }
   // Buffer descriptors: out-of-range lanes (zero padding, rows past M) get an offset beyond
@@ -85,6 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   const int KS = p.ntaps * (Ktot / BK);
+  constexpr int CP = FUSED ? A_PASSES : 1;
+  f32x4 ca[CP], cb[CP];
+  float cs = 1.f;
+  unsigned okm = 0;
 
   auto load_tiles = [&](int t, int chunk) {
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
@@ -94,17 +105,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
     const int c = chunk * BK;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
-    const int Cs = first ? p.C0 : p.C1;
-    const int coff = (first ? c : c - p.C0) + lseg * 4;
+    const int Cs = first ? (p.src0_pitch ? p.src0_pitch : p.C0) : p.C1;
+    const int cch = (first ? c : c - p.C0) + lseg * 4;     // channel within the K slice
+    const int coff = cch + wt * p.tap_cstride;
+    if (FUSED) {
+      const float* al = first ? p.act0_alpha : p.act1_alpha;
+      const float* be = first ? p.act0_beta : p.act1_beta;
+      const int Cc = first ? p.C0 : p.C1;
+      if (al) {   // uniform
+#pragma unroll
+        for (int i = 0; i < CP; ++i) {
+          ca[i] = *reinterpret_cast<const f32x4*>(al + (size_t)a_img[i] * Cc + cch);
+          cb[i] = *reinterpret_cast<const f32x4*>(be + (size_t)a_img[i] * Cc + cch);
+        }
+        cs = p.slope;
+      } else {    // plain source: z = v, slope 1 = identity
+#pragma unroll
+        for (int i = 0; i < CP; ++i) {
+          ca[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+          cb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        cs = 1.f;
+      }
+      okm = 0;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
       const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+      if (FUSED) okm |= (ok ? 1u : 0u) << i;
       // invalid lanes get bit 31 set: beyond num_records (< 2 GiB), the load returns 0
-      const unsigned off = ((unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 4u) |
-                           (ok ? 0u : 0x80000000u);
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-      ra[i] = __builtin_bit_cast(f32x4, v);
+      ra[i] = buf_ld4<TS>(rs, (unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff),
+                          ok ? 0u : 0x80000000u);
     }
     const unsigned woff = wrow_off + (unsigned)(wt * p.tap_stride + c) * 4u;
 #pragma unroll
@@ -122,7 +154,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
     __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
     __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[i]);
+    for (int i = 0; i < A_PASSES; ++i) {
+      if (FUSED) ra[i] = act4(ra[i], ca[i], cb[i], cs, (okm >> i) & 1u);
+      *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[i]);
+    }
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<bf16x4*>(Bb + ROWS * j * LDA) = to_bf16(rb[j]);
   };
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
     const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-      float* o[16];
+      TO* o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -201,9 +236,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
           const int b = rr - a * p.Wl;
           opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
         }
-        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
+        o[r] = mg < M ? reinterpret_cast<TO*>(p.out) + opix * p.ldo + col : nullptr;
       }
       store_block16(o, acc[m][n], bv, p.accumulate);
+    }
+  }
+  if (FUSED && p.stats) {   // uniform; statistics of the fp32 accumulators (before any rounding)
+    constexpr int WAVES_M = BM / WM;
+    float2* red = reinterpret_cast<float2*>(As);
+    static_assert(WAVES_M * BN * 4 <= 2 * A_TILE, "stats scratch fits in the A tiles");
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = n0 + wn0 + n * 32 + li;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][n][r] + bv; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out)) {
+      const int img = m0 / HlWl;   // the whole tile lies in this image (dispatcher check)
+      p.stats[((size_t)img * p.stats_tiles + (m0 - img * HlWl) / BM) * p.Ncols + n0 + tid] = out;
     }
   }
 }
@@ -438,6 +490,27 @@ int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+// bf16 STORAGE (the real mixed-precision pipeline): sources and output are bf16 tensors
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_b16(IgemmParams p, hipStream_t stream, int* stats_px) {
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 40 * sizeof(__bf16);
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
+  if (stats_px) {   // fused layer forward
+    const int HlWl = p.Hl * p.Wl;
+    const bool direct = p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout;
+    if (direct && p.stats && HlWl % BM == 0) { *stats_px = BM; p.stats_tiles = HlWl / BM; }
+    else { *stats_px = 0; p.stats = nullptr; }
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, true>),
+                       dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, false>),
+                       dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_igemm_b16");
+  return UNET_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_igemm_split(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * 3 * (size_t)(BM + BN) * 24 * sizeof(__bf16);
@@ -461,6 +534,19 @@ int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
     return launch_igemm_bf16<128, 64, 64, 32>(p, stream);
   if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_bf16<64, 64, 32, 32>(p, stream);
   return launch_igemm_bf16<128, 32, 32, 32>(p, stream);
+}
+
+// bf16-storage gather-GEMM (sources / output bf16 in HBM); stats_px != nullptr: the fused-layer
+// forward (activation on load, statistics epilogue where every tile lies in one image)
+int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px) {
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+    return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px);
+  if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+    return launch_igemm_b16<128, 64, 64, 32>(p, stream, stats_px);
+  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_b16<64, 64, 32, 32>(p, stream, stats_px);
+  return launch_igemm_b16<128, 32, 32, 32>(p, stream, stats_px);
 }
 
 int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {

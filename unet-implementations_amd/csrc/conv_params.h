@@ -72,19 +72,20 @@ inline void set_tap(IgemmParams& p, int t, int oy, int ox, int wt) {
 // range).  With `accumulate` all 16 old values are loaded before the first add, so the reads
 // overlap (a per-element load/add/store chain costs one HBM round trip per register).
 #ifdef __HIPCC__
-__device__ __forceinline__ void store_block16(float* const (&o)[16], const f32x16& acc, float bv,
+template <typename TO>
+__device__ __forceinline__ void store_block16(TO* const (&o)[16], const f32x16& acc, float bv,
                                               int accumulate) {
   if (accumulate) {
     float old[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) old[r] = o[r] ? *o[r] : 0.f;
+    for (int r = 0; r < 16; ++r) old[r] = o[r] ? ld1(o[r]) : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (o[r]) *o[r] = acc[r] + bv + old[r];
+      if (o[r]) st1(o[r], acc[r] + bv + old[r]);
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (o[r]) *o[r] = acc[r] + bv;
+      if (o[r]) st1(o[r], acc[r] + bv);
   }
 }
 #endif  // __HIPCC__
@@ -172,6 +173,7 @@ bool patch_split_applicable(const IgemmParams& p);
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream,           // conv_igemm.hip
                    int* stats_px = nullptr);
 int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream);     // conv_lowp.hip
+int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px);  // bf16 storage
 int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream);    // conv_lowp.hip
 
 }  // namespace unet_conv

@@ -46,6 +46,7 @@ struct WgradParams {
   const float* alpha;  // [N][Cx]
   const float* beta;   // [N][Cx]
   float slope;
+  int b16;             // x and dy are bf16 tensors (mixed-precision pipeline)
 };
 
 // Workgroup = 4 waves (one per SIMD, so co-resident workgroups load every SIMD alike).
@@ -53,7 +54,8 @@ struct WgradParams {
 // sub-block w % NSB for ALL nine taps (9 accumulator blocks = 144 VGPRs) and, when NSB < 4,
 // the pixel pairs q = w / NSB (mod NPP) of each segment - its sums then go to a slab of
 // their own (slab index sp*NPP + pp), folded by the ordinary slab reduction.
-template <int CI_T, int CO_T, int S, int STRIDE, bool ACT = false>
+template <int CI_T, int CO_T, int S, int STRIDE, bool ACT = false, typename TX = float,
+          typename TD = float>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
   constexpr int NSB = TI * TJ, NPP = 4 / NSB;
@@ -147,16 +149,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       const int iy = loy * STRIDE - 1 + (p_rc[k] >> 16), ix = lx0 * STRIDE - 1 + (p_rc[k] & 0xffff);
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       if (ACT) okm |= (ok ? 1u : 0u) << k;
-      const unsigned off = ((unsigned)(((ln * p.H + iy) * p.W + ix) * p.Cx + p_ch) * 4u) |
-                           (ok ? 0u : 0x80000000u);
-      rp[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+      rp[k] = buf_ld4<TX>(rsx, (unsigned)(((ln * p.H + iy) * p.W + ix) * p.Cx + p_ch),
+                          ok ? 0u : 0x80000000u);
     } else {
       constexpr int j = k - NLP;
       const int ox = lx0 + d_p[j];
       const bool ok = ox < p.Wo;
-      const unsigned off = ((unsigned)(((ln * p.Ho + loy) * p.Wo + ox) * p.Cout + d_ch[j]) * 4u) |
-                           (ok ? 0u : 0x80000000u);
-      rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+      rd[j] = buf_ld4<TD>(rsd, (unsigned)(((ln * p.Ho + loy) * p.Wo + ox) * p.Cout + d_ch[j]),
+                          ok ? 0u : 0x80000000u);
     }
   };
   auto act_slot = [&](auto kc) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // the flattened [N*h*w] pixel list.  Same slabs / reductions as conv_wgrad_kernel.
 // WgradParams: x = the low-resolution operand [Q][Cx], dy = D [Q][9*Cout], N*H*W = Q.
 // ---------------------------------------------------------------------------
-template <int CI_T, int CO_T, int S, bool ACT>
+template <int CI_T, int CO_T, int S, bool ACT, typename TX = float, typename TD = float>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
   constexpr int NSB = TI * TJ, NPP = 4 / NSB;
@@ -332,8 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
     if constexpr (k < NLA) {
       const int q = lq0 + a_px[k];
       const bool ok = q < Q && (NA4 % NT == 0 || tid < NA4);
-      const unsigned off = ((unsigned)(q * p.Cx + a_ch) * 4u) | (ok ? 0u : 0x80000000u);
-      ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+      ra[k] = buf_ld4<TX>(rsx, (unsigned)(q * p.Cx + a_ch), ok ? 0u : 0x80000000u);
       if (ACT) {
         const int n = ok ? q / HW : 0;
         ca[k] = *reinterpret_cast<const f32x4*>(p.alpha + (size_t)n * p.Cx + a_ch);
@@ -344,8 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
       constexpr int j = k - NLA;
       const int q = lq0 + b_px[j];
       const bool ok = q < Q;
-      const unsigned off = ((unsigned)(q * (9 * p.Cout) + b_col[j]) * 4u) | (ok ? 0u : 0x80000000u);
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+      rb[j] = buf_ld4<TD>(rsd, (unsigned)(q * (9 * p.Cout) + b_col[j]), ok ? 0u : 0x80000000u);
     }
   };
   auto act_slot = [&](auto kc) {
@@ -441,7 +439,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
 // reproduces the fp32 product to one fp32 rounding (see conv_igemm_split_kernel).
 // SB = single LDS stage (two barriers per segment) where the double-buffered planes would leave
 // one workgroup per CU (32x32 tile, 64-pixel segments, three planes: 50 KB instead of 100 KB).
-template <int CI_T, int CO_T, int S, int NPL, bool SB = false>
+template <int CI_T, int CO_T, int S, int NPL, bool SB = false, typename TX = float,
+          typename TD = float, bool ACT = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradParams p) {
   constexpr int STRIDE = 1;
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
@@ -503,27 +502,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
   }
 
   f32x4 rp[NLP], rd[NLD];
+  // ACT: coefficients of this thread's four channels (one channel group per thread), flags
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  unsigned okm = 0;
   auto load_stage = [&](int g) {
     const int xs = g % p.segs_per_row;
     const int r = g / p.segs_per_row;
     const int oy = r % p.Ho;
     const int n = r / p.Ho;
     const int x0 = xs * S;
+    if (ACT) {
+      const size_t o = (size_t)n * p.Cx + p_ch[0];
+      ca = *reinterpret_cast<const f32x4*>(p.alpha + o);
+      cb = *reinterpret_cast<const f32x4*>(p.beta + o);
+      okm = 0;
+    }
 #pragma unroll
     for (int k = 0; k < NLP; ++k) {
       const int iy = oy * STRIDE + p_r[k], ix = x0 * STRIDE + p_c[k];
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned off = ((unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + p_ch[k]) * 4u) |
-                           (ok ? 0u : 0x80000000u);
-      rp[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+      if (ACT) okm |= (ok ? 1u : 0u) << k;
+      rp[k] = buf_ld4<TX>(rsx, (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + p_ch[k]),
+                          ok ? 0u : 0x80000000u);
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int ox = x0 + d_p[k];
       const bool ok = ox < p.Wo;
-      const unsigned off = ((unsigned)(((n * p.Ho + oy) * p.Wo + ox) * p.Cout + d_ch[k]) * 4u) |
-                           (ok ? 0u : 0x80000000u);
-      rd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+      rd[k] = buf_ld4<TD>(rsd, (unsigned)(((n * p.Ho + oy) * p.Wo + ox) * p.Cout + d_ch[k]),
+                          ok ? 0u : 0x80000000u);
     }
   };
   auto to_bf16 = [](const f32x4 v) {
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
     for (int k = 0; k < NLP; ++k) {
       const int idx = tid + NT * k;
       const int pix = idx / (CI_T / 4), seg = idx - pix * (CI_T / 4);
+      if (ACT) rp[k] = act4(rp[k], ca, cb, p.slope, (okm >> k) & 1u);
       if (NT * (k + 1) <= NP4 || idx < NP4)
         put(base + (seg >> 3) * PSUB + pix * 32 + (seg & 7) * 4, rp[k]);
     }
@@ -710,8 +718,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 constexpr int SW_PIX = 128;  // pixels per stage
 constexpr int SW_LDK = 32;
 
+template <typename TD>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ dy,
+                                                              const TD* __restrict__ dy,
                                                               float* __restrict__ partial, int N,
                                                               int H, int W, int Cout,
                                                               int stages_per_block,
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const float* __res
       const int pix = i >> 3, seg = i & 7;
       const long long m = m0 + pix;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)m * Cout + co0 + seg * 4);
+      if (m < M) v = ld4(dy + (size_t)m * Cout + co0 + seg * 4);
       *reinterpret_cast<f32x4*>(D + pix * 32 + seg * 4) = v;
     }
     __syncthreads();
@@ -800,9 +809,9 @@ __device__ __forceinline__ float stem_px(const unsigned char* x, size_t i, int c
   return ((float)x[i] / 255.0f - nm.mean[c]) / nm.std[c];
 }
 
-template <typename T>
+template <typename T, typename TD = float>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_rows_kernel(
-    const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
+    const T* __restrict__ x, const TD* __restrict__ dy, float* __restrict__ partial, int N,
     int H, int W, int Cout, int stages_per_block, long long total_stages, const StemNormW nm) {
   __shared__ float Rw[3 * SWR_PITCH];
   __shared__ float D[SW_PIX * 32];      // [pix][co]
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_rows_kernel(
     for (int i = tid; i < SW_PIX * 8; i += 256) {
       const int pix = i >> 3, seg = i & 7;
       *reinterpret_cast<f32x4*>(D + pix * 32 + seg * 4) =
-          *reinterpret_cast<const f32x4*>(dy + (size_t)(m0 + pix) * Cout + co0 + seg * 4);
+          ld4(dy + (size_t)(m0 + pix) * Cout + co0 + seg * 4);
     }
     __syncthreads();
     // wave handles pixels [wave*32, wave*32+32): 16 pixel pairs
@@ -929,21 +938,25 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   return pl;
 }
 
-template <int CI_T, int CO_T, int S, int STRIDE, bool ACT>
+template <int CI_T, int CO_T, int S, int STRIDE, bool ACT, typename TS>
 int launch_wgrad_t(const WgradParams& p, hipStream_t stream);
 
 template <int CI_T, int CO_T, int S, int STRIDE>
 int launch_wgrad(const WgradParams& p, hipStream_t stream) {
-  if (p.alpha) return launch_wgrad_t<CI_T, CO_T, S, STRIDE, true>(p, stream);
-  return launch_wgrad_t<CI_T, CO_T, S, STRIDE, false>(p, stream);
+  if (p.b16) {
+    if (p.alpha) return launch_wgrad_t<CI_T, CO_T, S, STRIDE, true, __bf16>(p, stream);
+    return launch_wgrad_t<CI_T, CO_T, S, STRIDE, false, __bf16>(p, stream);
+  }
+  if (p.alpha) return launch_wgrad_t<CI_T, CO_T, S, STRIDE, true, float>(p, stream);
+  return launch_wgrad_t<CI_T, CO_T, S, STRIDE, false, float>(p, stream);
 }
 
-template <int CI_T, int CO_T, int S, int STRIDE, bool ACT>
+template <int CI_T, int CO_T, int S, int STRIDE, bool ACT, typename TS>
 int launch_wgrad_t(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = (S - 1) * STRIDE + 3;
   constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
   constexpr int NT = 256;
-  auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE, ACT>;
+  auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE, ACT, TS, TS>;
   UNET_SET_DYN_LDS(kern, lds);
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, p);
@@ -955,9 +968,24 @@ template <int CI_T, int CO_T, int S, int NPL = 1, bool SB = false>
 int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = S + 2;
   constexpr size_t lds = (SB ? 1 : 2) * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if constexpr (NPL == 1 && !SB) {
+    if (p.b16) {   // bf16 tensors in HBM, operand activated on load when p.alpha is set
+      if (p.alpha) {
+        auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, 1, false, __bf16, __bf16, true>;
+        UNET_SET_DYN_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+      } else {
+        auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, 1, false, __bf16, __bf16, false>;
+        UNET_SET_DYN_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+      }
+      UNET_CHECK_LAUNCH("conv_wgrad_bf16(b16)");
+      return UNET_OK;
+    }
+  }
   auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, NPL, SB>;
   UNET_SET_DYN_LDS(kern, lds);
-  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_wgrad_bf16");
   return UNET_OK;
@@ -967,7 +995,17 @@ template <int CI_T, int CO_T, int S>
 int launch_wgrad_taps(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)S * (CI_T + 9 * CO_T) * sizeof(float);
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
-  if (p.alpha) {
+  if (p.b16) {   // bf16 tensors in HBM (fp32 matrix cores: 1/4 of the FLOPs already)
+    if (p.alpha) {
+      auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, true, __bf16, __bf16>;
+      UNET_SET_DYN_LDS(kern, lds);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    } else {
+      auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, false, __bf16, __bf16>;
+      UNET_SET_DYN_LDS(kern, lds);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    }
+  } else if (p.alpha) {
     auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, true>;
     UNET_SET_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
@@ -1101,7 +1139,10 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                                 bool center_only, hipStream_t stream, int prec = 0,
                                 const float* act_alpha = nullptr, const float* act_beta = nullptr,
                                 float slope = 0.f, const unsigned char* x_u8 = nullptr,
-                                const float* u8_mean_std = nullptr) {
+                                const float* u8_mean_std = nullptr, int b16 = 0) {
+  // b16: x (except the RGB image) and dy are bf16 tensors; prec is then 1 (bf16 matrix cores
+  // for the stride-1 layers, fp32 matrix cores on bf16 storage for the rest)
+  const long long es = b16 ? 2 : 4;
   UNET_REQUIRE((x || x_u8) && dy && dw_oihw && workspace, "conv3x3_bwd_weight: null pointer");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_weight: stride %d unsupported", stride);
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
@@ -1123,14 +1164,28 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       UNET_REQUIRE(W % SW_PIX == 0, "stem_u8_bwd_weight: needs W %% %d == 0", SW_PIX);
       StemNormW nm;
       for (int c = 0; c < 3; ++c) { nm.mean[c] = u8_mean_std[c]; nm.std[c] = u8_mean_std[3 + c]; }
-      hipLaunchKernelGGL(conv_stem_wgrad_rows_kernel<unsigned char>, grid, dim3(256), 0, stream,
-                         x_u8, dy, ws, N, H, W, Cout, pl.stem_spb, pl.stem_stages, nm);
-    } else if (W % SW_PIX == 0)   // a 128-pixel stage never straddles image rows: raw-row form
-      hipLaunchKernelGGL(conv_stem_wgrad_rows_kernel<float>, grid, dim3(256), 0, stream, x, dy, ws,
-                         N, H, W, Cout, pl.stem_spb, pl.stem_stages, StemNormW{});
+      if (b16)
+        hipLaunchKernelGGL((conv_stem_wgrad_rows_kernel<unsigned char, __bf16>), grid, dim3(256), 0,
+                           stream, x_u8, reinterpret_cast<const __bf16*>(dy), ws, N, H, W, Cout,
+                           pl.stem_spb, pl.stem_stages, nm);
+      else
+        hipLaunchKernelGGL((conv_stem_wgrad_rows_kernel<unsigned char, float>), grid, dim3(256), 0,
+                           stream, x_u8, dy, ws, N, H, W, Cout, pl.stem_spb, pl.stem_stages, nm);
+    } else if (W % SW_PIX == 0) {  // a 128-pixel stage never straddles image rows: raw-row form
+      if (b16)
+        hipLaunchKernelGGL((conv_stem_wgrad_rows_kernel<float, __bf16>), grid, dim3(256), 0, stream,
+                           x, reinterpret_cast<const __bf16*>(dy), ws, N, H, W, Cout, pl.stem_spb,
+                           pl.stem_stages, StemNormW{});
+      else
+        hipLaunchKernelGGL((conv_stem_wgrad_rows_kernel<float, float>), grid, dim3(256), 0, stream,
+                           x, dy, ws, N, H, W, Cout, pl.stem_spb, pl.stem_stages, StemNormW{});
+    } else if (b16)
+      hipLaunchKernelGGL(conv_stem_wgrad_kernel<__bf16>, grid, dim3(256), 0, stream, x,
+                         reinterpret_cast<const __bf16*>(dy), ws, N, H, W, Cout, pl.stem_spb,
+                         pl.stem_stages);
     else
-      hipLaunchKernelGGL(conv_stem_wgrad_kernel, grid, dim3(256), 0, stream, x, dy, ws, N, H, W,
-                         Cout, pl.stem_spb, pl.stem_stages);
+      hipLaunchKernelGGL(conv_stem_wgrad_kernel<float>, grid, dim3(256), 0, stream, x, dy, ws, N, H,
+                         W, Cout, pl.stem_spb, pl.stem_stages);
     UNET_CHECK_LAUNCH("conv_stem_wgrad");
     const int n = 27 * Cout;
     const float* cur = ws;
@@ -1151,8 +1206,8 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                        dw_oihw, nslab, Cout);
     UNET_CHECK_LAUNCH("stem_wgrad_reduce");
   } else {
-    UNET_REQUIRE(!act_alpha || (act_beta && prec == 0),
-                 "conv_bwd_weight: activation on load is an fp32-path feature");
+    UNET_REQUIRE(!act_alpha || (act_beta && (prec == 0 || b16)),
+                 "conv_bwd_weight: activation on load needs the fp32 or the bf16-storage path");
     const size_t E = (size_t)9 * Cx * Cout;
     const int nmax = wgrad_batch_chunk(N, H, W, Cx, Cout, stride);
     int nslab = 0;
@@ -1160,14 +1215,18 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       const int nc = N - nb < nmax ? N - nb : nmax;
       const WgradPlan pc = make_plan(nc, H, W, Cx, Cout, stride, pprec);
       WgradParams p{};
-      p.x = x + (size_t)nb * H * W * Cx; p.dy = dy + (size_t)nb * Ho * Wo * Cout;
+      p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
+                                           (size_t)nb * H * W * Cx * es);
+      p.dy = reinterpret_cast<const float*>(reinterpret_cast<const char*>(dy) +
+                                            (size_t)nb * Ho * Wo * Cout * es);
+      p.b16 = b16;
       p.partial = ws + (size_t)nslab * E; p.Cx = Cx; p.Cout = Cout;
       p.N = nc; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
       p.segs_per_row = pc.segs_per_row; p.total_segs = pc.total_segs;
       p.segs_per_block = pc.segs_per_block; p.split = pc.split;
       p.ci_tiles = Cx / pc.ci_t; p.co_tiles = Cout / pc.co_t;
-      p.x_bytes = (unsigned)((long long)nc * H * W * Cx * 4);
-      p.dy_bytes = (unsigned)((long long)nc * Ho * Wo * Cout * 4);
+      p.x_bytes = (unsigned)((long long)nc * H * W * Cx * es);
+      p.dy_bytes = (unsigned)((long long)nc * Ho * Wo * Cout * es);
       p.alpha = act_alpha ? act_alpha + (size_t)nb * Cx : nullptr;
       p.beta = act_alpha ? act_beta + (size_t)nb * Cx : nullptr;
       p.slope = slope;
@@ -1199,6 +1258,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     }
     UNET_CHECK_LAUNCH("wgrad_reduce");
   }
+  UNET_REQUIRE(!(db && b16), "conv_bwd_weight: db is not produced on the bf16-storage path");
   if (db) {
     // the slab workspace is free again at this point of the stream; reuse its head as scratch
     const long long M = (long long)N * Ho * Wo;
@@ -1297,11 +1357,34 @@ extern "C" size_t unet_conv3x3_up_bwd_weight_workspace_bytes(int N, int h, int w
   return up_wgrad_ws_floats(N, h, w, Cx, Cout) * sizeof(float);
 }
 
+static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D, float* dw_oihw,
+                              int ci_offset, int Cin_total, void* workspace,
+                              size_t workspace_bytes, int N, int h, int w, int Cout,
+                              hipStream_t stream, int b16);
+
 extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, const float* D,
                                           float* dw_oihw, int ci_offset, int Cin_total,
                                           void* workspace, size_t workspace_bytes, int N, int h,
-                                          int w, int Cout, unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+                                          int w, int Cout, unet_stream_t stream) {
+  return up_bwd_weight_impl(x, slope, D, dw_oihw, ci_offset, Cin_total, workspace, workspace_bytes,
+                            N, h, w, Cout, (hipStream_t)stream, 0);
+}
+
+// x (activated on load) and D are bf16 tensors
+extern "C" int unet_conv3x3_up_bwd_weight_b16(const unet_act_src* x, float slope, const uint16_t* D,
+                                              float* dw_oihw, int ci_offset, int Cin_total,
+                                              void* workspace, size_t workspace_bytes, int N,
+                                              int h, int w, int Cout, unet_stream_t stream) {
+  return up_bwd_weight_impl(x, slope, reinterpret_cast<const float*>(D), dw_oihw, ci_offset,
+                            Cin_total, workspace, workspace_bytes, N, h, w, Cout,
+                            (hipStream_t)stream, 1);
+}
+
+static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D, float* dw_oihw,
+                              int ci_offset, int Cin_total, void* workspace,
+                              size_t workspace_bytes, int N, int h, int w, int Cout,
+                              hipStream_t stream, int b16) {
+  const long long es = b16 ? 2 : 4;
   UNET_REQUIRE(x && x->x && D && dw_oihw && workspace, "conv3x3_up_bwd_weight: null pointer");
   const int Cx = x->C;
   UNET_REQUIRE(Cx > 0 && Cx % 32 == 0 && Cout > 0 && Cout % 32 == 0 && N > 0 && h > 0 && w > 0,
@@ -1323,14 +1406,18 @@ extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, co
     const long long Q = (long long)nc * h * w;
     const WgradPlan pl = make_plan_taps(Q, Cx, Cout);
     WgradParams p{};
-    p.x = x->x + (size_t)nb * h * w * Cx; p.dy = D + (size_t)nb * h * w * 9 * Cout;
+    p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x->x) +
+                                         (size_t)nb * h * w * Cx * es);
+    p.dy = reinterpret_cast<const float*>(reinterpret_cast<const char*>(D) +
+                                          (size_t)nb * h * w * 9 * Cout * es);
+    p.b16 = b16;
     p.partial = ws + (size_t)nslab * E; p.Cx = Cx; p.Cout = Cout;
     p.N = nc; p.H = h; p.W = w; p.Ho = h; p.Wo = w;
     p.segs_per_row = 0; p.total_segs = pl.total_segs;
     p.segs_per_block = pl.segs_per_block; p.split = pl.split;
     p.ci_tiles = Cx / pl.ci_t; p.co_tiles = Cout / pl.co_t;
-    p.x_bytes = (unsigned)(Q * Cx * 4);
-    p.dy_bytes = (unsigned)(Q * 9 * Cout * 4);
+    p.x_bytes = (unsigned)(Q * Cx * es);
+    p.dy_bytes = (unsigned)(Q * 9 * Cout * es);
     p.alpha = x->alpha ? x->alpha + (size_t)nb * Cx : nullptr;
     p.beta = x->alpha ? x->beta + (size_t)nb * Cx : nullptr;
     p.slope = slope;
@@ -1359,6 +1446,24 @@ extern "C" int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, co
                      Cout, ci_offset, Cin_total);
   UNET_CHECK_LAUNCH("wgrad_reduce");
   return UNET_OK;
+}
+
+// Mixed-precision pipeline: x (activated on load) and dy are bf16 tensors; stride-1 layers on the
+// bf16 matrix cores, stride-2 layers and 16-pixel segments on the fp32 matrix cores; dw fp32.
+// The RGB image (x->C == 3) stays fp32.
+extern "C" int unet_conv_in_bwd_weight_b16(const unet_act_src* x, float slope, const uint16_t* dy,
+                                           float* dw_oihw, int ci_offset, int Cin_total, int ksize,
+                                           int stride, void* workspace, size_t workspace_bytes,
+                                           int N, int H, int W, int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x, "conv_in_bwd_weight_b16: null source");
+  UNET_REQUIRE(ksize == 3 || (ksize == 1 && stride == 1),
+               "conv_in_bwd_weight_b16: kernel %d / stride %d unsupported", ksize, stride);
+  UNET_REQUIRE(x->C == 3 ? !x->alpha : x->C % 32 == 0,
+               "conv_in_bwd_weight_b16: Cx %d unsupported (the RGB image is a plain operand)", x->C);
+  return conv_bwd_weight_impl(x->x, x->C, reinterpret_cast<const float*>(dy), dw_oihw, ci_offset,
+                              Cin_total, nullptr, workspace, workspace_bytes, N, H, W, Cout, stride,
+                              ksize == 1, (hipStream_t)stream, 1, x->alpha, x->beta, slope, nullptr,
+                              nullptr, 1);
 }
 
 // Weight gradient of the RGB stem from the uint8 image (normalised on load, W % 128 == 0);

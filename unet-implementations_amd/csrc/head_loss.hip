@@ -16,7 +16,8 @@ constexpr int HT = 256;  // pixels per head tile
 // 8 lanes per pixel, 4 channels per lane: a wave's load instruction reads 8 whole pixels
 // (1 KB contiguous), the 32-channel dot products are finished with three xor-shuffles inside
 // each 8-lane group; no LDS.  Lane 0 of a group writes the pixel's K logits (NCHW planes).
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a,
+template <typename TS>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const TS* __restrict__ a,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ logits, long long M,
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const long long m = m0 + it * 32 + (tid >> 3);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (m < M) {
-      v = *reinterpret_cast<const f32x4*>(a + (size_t)m * 32 + seg * 4);
+      v = ld4(a + (size_t)m * 32 + seg * 4);
       if (alpha) {
         const size_t o = (size_t)(m / HW) * 32 + seg * 4;
         v = act4(v, *reinterpret_cast<const f32x4*>(alpha + o),
@@ -72,10 +73,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------ head backward
 // partial[block][K*32 + K]: dw then db
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ a,
+template <typename TS>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const TS* __restrict__ a,
                                                        const float* __restrict__ dl,
                                                        const float* __restrict__ w,
-                                                       float* __restrict__ da,
+                                                       TS* __restrict__ da,
                                                        float* __restrict__ partial, long long M,
                                                        int HW, int K, long long tiles,
                                                        const float* __restrict__ alpha,
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int it = 0; it < HT / 32; ++it) {
       const long long m = m0 + it * 32 + grp;
       const long long mc = m < M ? m : M - 1;
-      av[it] = *reinterpret_cast<const f32x4*>(a + (size_t)mc * 32 + seg * 4);
+      av[it] = ld4(a + (size_t)mc * 32 + seg * 4);
       const long long n = one_image ? m0 / HW : mc / HW, pp = mc - n * HW;
       if (alpha) {   // uniform: the operand is a raw convolution output, activated on load
         if (!one_image) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
           }
           dbacc[k] += dv[it][k];
         }
-      if (m < M) *reinterpret_cast<f32x4*>(da + (size_t)m * 32 + seg * 4) = v;
+      if (m < M) st4(da + (size_t)m * 32 + seg * 4, v);
     }
   }
 #pragma unroll
@@ -515,7 +517,7 @@ extern "C" int unet_head1x1_fwd(const float* a, const float* w, const float* b, 
   UNET_REQUIRE(C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0,
                "head1x1_fwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
   const long long M = (long long)N * HW;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
+  hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
                      (hipStream_t)stream, a, w, b, logits, M, HW, K, (const float*)nullptr,
                      (const float*)nullptr, 0.f);
   UNET_CHECK_LAUNCH("head_fwd");
@@ -529,9 +531,23 @@ extern "C" int unet_head1x1_in_fwd(const unet_act_src* x, float slope, const flo
   UNET_REQUIRE(x->C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0 && (!x->alpha || x->beta),
                "head1x1_in_fwd: needs C == 32, K <= 4 (got C=%d K=%d)", x->C, K);
   const long long M = (long long)N * HW;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
+  hipLaunchKernelGGL(head_fwd_kernel<float>, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
                      (hipStream_t)stream, x->x, w, b, logits, M, HW, K, x->alpha, x->beta, slope);
   UNET_CHECK_LAUNCH("head_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_head1x1_in_fwd_b16(const unet_act_src* x, float slope, const float* w,
+                                       const float* b, float* logits, int N, int HW, int K,
+                                       unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && w && logits, "head1x1_in_fwd_b16: null pointer");
+  UNET_REQUIRE(x->C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0 && (!x->alpha || x->beta),
+               "head1x1_in_fwd_b16: needs C == 32, K <= 4 (got C=%d K=%d)", x->C, K);
+  const long long M = (long long)N * HW;
+  hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3((unsigned)ceil_div64(M, HT)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const __bf16*>(x->x), w, b, logits, M,
+                     HW, K, x->alpha, x->beta, slope);
+  UNET_CHECK_LAUNCH("head_fwd(b16)");
   return UNET_OK;
 }
 
@@ -544,7 +560,7 @@ extern "C" size_t unet_head1x1_bwd_workspace_bytes(int N, int HW, int C, int K) 
 static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w, float* da,
                             float* dw, float* db, void* workspace, size_t workspace_bytes, int N,
                             int HW, int C, int K, const float* alpha, const float* beta,
-                            float slope, unet_stream_t stream);
+                            float slope, unet_stream_t stream, int b16 = 0);
 
 extern "C" int unet_head1x1_bwd(const float* a, const float* dlogits, const float* w, float* da,
                                 float* dw, float* db, void* workspace, size_t workspace_bytes,
@@ -562,10 +578,20 @@ extern "C" int unet_head1x1_in_bwd(const unet_act_src* x, float slope, const flo
                           x->alpha, x->beta, slope, stream);
 }
 
+// x and da are bf16 tensors (mixed-precision pipeline); logits gradient and dw / db stay fp32
+extern "C" int unet_head1x1_in_bwd_b16(const unet_act_src* x, float slope, const float* dlogits,
+                                       const float* w, uint16_t* da, float* dw, float* db,
+                                       void* workspace, size_t workspace_bytes, int N, int HW,
+                                       int K, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && (!x->alpha || x->beta), "head1x1_in_bwd_b16: null source");
+  return head1x1_bwd_impl(x->x, dlogits, w, reinterpret_cast<float*>(da), dw, db, workspace,
+                          workspace_bytes, N, HW, x->C, K, x->alpha, x->beta, slope, stream, 1);
+}
+
 static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w, float* da,
                             float* dw, float* db, void* workspace, size_t workspace_bytes, int N,
                             int HW, int C, int K, const float* alpha, const float* beta,
-                            float slope, unet_stream_t stream) {
+                            float slope, unet_stream_t stream, int b16) {
   UNET_REQUIRE(a && dlogits && w && da && workspace, "head1x1_bwd: null pointer");
   UNET_REQUIRE(C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0,
                "head1x1_bwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
@@ -577,8 +603,13 @@ static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w
   const long long tiles = ceil_div64(M, HT);
   const int blocks = head_bwd_blocks(tiles);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dlogits,
-                     w, da, partial, M, HW, K, tiles, alpha, beta, slope);
+  if (b16)
+    hipLaunchKernelGGL(head_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(a), dlogits, w,
+                       reinterpret_cast<__bf16*>(da), partial, M, HW, K, tiles, alpha, beta, slope);
+  else
+    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a,
+                       dlogits, w, da, partial, M, HW, K, tiles, alpha, beta, slope);
   UNET_CHECK_LAUNCH("head_bwd");
   hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(K * 32 + K), dim3(256), 0, (hipStream_t)stream,
                      partial, dw, db, blocks, K);

@@ -28,7 +28,8 @@ __host__ __device__ inline int split_for(int N, int HW, int C) {
 
 // ---------------------------------------------------------------- statistics
 // grid (split, N); partial[n][s][c] = (mean, M2), count implied by the pixel range.
-__global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restrict__ y,
+template <typename TS>
+__global__ __launch_bounds__(kThreads) void in_stats_kernel(const TS* __restrict__ y,
                                                             float2* __restrict__ partial, int HW,
                                                             int C, int split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [groups][C][3]
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restr
   const int per = (HW + split - 1) / split;
   const int p_begin = s * per;
   const int p_end = min(p_begin + per, HW);
-  const float* base = y + (size_t)n * HW * C + c4 * 4;
+  const TS* base = y + (size_t)n * HW * C + c4 * 4;
 
   float cnt = 0.f;
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void in_stats_kernel(const float* __restr
       for (int j = 0; j < 8; ++j) {
         const int q = pp + j * groups;
         if (q < p_end) {
-          v[j] = *reinterpret_cast<const f32x4*>(base + (size_t)q * C);
+          v[j] = ld4(base + (size_t)q * C);
           ++k;
         } else {
           v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -230,8 +231,9 @@ __global__ __launch_bounds__(kThreads) void in_apply_fwd_kernel(
 
 // ---------------------------------------------------------------- backward
 // pass 1: per (n,c) S1 = sum gz, S2 = sum gz*xhat, gz = ga*mask*lrelu'(z)
+template <typename TS>
 __global__ __launch_bounds__(kThreads) void in_bwd_reduce_kernel(
-    const float* __restrict__ ga, const float* __restrict__ y, const float* __restrict__ mean,
+    const TS* __restrict__ ga, const TS* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mask, float slope,
     float2* __restrict__ partial, int HW, int C, int split) {
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(kThreads) void in_bwd_reduce_kernel(
     if (mask) mk = *reinterpret_cast<const f32x4*>(mask + (size_t)n * C + c);
     const size_t base = (size_t)n * HW * C + c;
     for (int pp = p_begin + grp; pp < p_end; pp += groups) {
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + (size_t)pp * C);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(ga + base + (size_t)pp * C);
+      const f32x4 yv = ld4(y + base + (size_t)pp * C);
+      const f32x4 gv = ld4(ga + base + (size_t)pp * C);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = (yv[k] - mu[k]) * rs[k];
@@ -329,11 +331,12 @@ __global__ void in_bwd_finalize2_kernel(const float2* __restrict__ sums, float* 
 }
 
 // pass 2: dy = gamma*rstd*(gz - c1 - xhat*c2); per-block column sums of dy -> dbias slabs
+template <typename TS>
 __global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
-    const float* ga /* may alias dy */, const float* __restrict__ y, const float* __restrict__ mean,
+    const TS* ga /* may alias dy */, const TS* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mask, float slope,
-    const float2* __restrict__ coef, float* dy, float* __restrict__ dbias_partial,
+    const float2* __restrict__ coef, TS* dy, float* __restrict__ dbias_partial,
     int HW, int C, int split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [groups][C]
   const int lpp = C >> 2;
@@ -362,8 +365,8 @@ __global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
     }
     const size_t base = (size_t)n * HW * C + c;
     for (int pp = p_begin + grp; pp < p_end; pp += groups) {
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + (size_t)pp * C);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(ga + base + (size_t)pp * C);
+      const f32x4 yv = ld4(y + base + (size_t)pp * C);
+      const f32x4 gv = ld4(ga + base + (size_t)pp * C);
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
         o[k] = g[k] * rs[k] * (gz - c1[k] - xh * c2[k]);
       }
       sd += o;
-      *reinterpret_cast<f32x4*>(dy + base + (size_t)pp * C) = o;
+      st4(dy + base + (size_t)pp * C, o);
     }
   }
   if (dbias_partial) {
@@ -446,14 +449,14 @@ extern "C" int unet_instnorm_stats(const float* y, const float* gamma, const flo
                                    void* workspace, size_t workspace_bytes, int N, int HW, int C,
                                    unet_stream_t stream_) {
   return unet_in_stats_masked(y, gamma, beta, eps, nullptr, mean, rstd, alpha, beta2, workspace,
-                              workspace_bytes, N, HW, C, (hipStream_t)stream_);
+                              workspace_bytes, N, HW, C, (hipStream_t)stream_, 0);
 }
 
 // stand-alone statistics pass; `mask` folds the dropout factor into alpha / beta2
 int unet_in_stats_masked(const float* y, const float* gamma, const float* beta, float eps,
                          const float* mask, float* mean, float* rstd, float* alpha, float* beta2,
                          void* workspace, size_t workspace_bytes, int N, int HW, int C,
-                         hipStream_t stream) {
+                         hipStream_t stream, int y_is_bf16) {
   UNET_REQUIRE(y && mean && rstd && workspace, "instnorm_stats: null pointer");
   UNET_REQUIRE(shape_ok(N, HW, C) && C <= 1024 && kThreads % (C / 4) == 0,
                "instnorm_stats: unsupported shape N=%d HW=%d C=%d", N, HW, C);
@@ -465,8 +468,12 @@ int unet_in_stats_masked(const float* y, const float* gamma, const float* beta, 
   const int groups = kThreads / (C / 4);
   float2* partial = reinterpret_cast<float2*>(workspace);
   const size_t lds = (size_t)groups * (C / 4 + 2 * C) * sizeof(float);
-  hipLaunchKernelGGL(in_stats_kernel, dim3(split, N), dim3(kThreads), lds, stream, y, partial, HW,
-                     C, split);
+  if (y_is_bf16)
+    hipLaunchKernelGGL(in_stats_kernel<__bf16>, dim3(split, N), dim3(kThreads), lds, stream,
+                       reinterpret_cast<const __bf16*>(y), partial, HW, C, split);
+  else
+    hipLaunchKernelGGL(in_stats_kernel<float>, dim3(split, N), dim3(kThreads), lds, stream, y,
+                       partial, HW, C, split);
   UNET_CHECK_LAUNCH("in_stats");
   hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
                      partial, gamma, beta, eps, mask, mean, rstd, alpha, beta2, N, HW, C, split);
@@ -504,13 +511,41 @@ extern "C" int unet_instnorm_lrelu_drop_fwd(const float* y, const float* alpha, 
   return UNET_OK;
 }
 
+template <typename TS>
+static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const float* mask, float slope,
+                             TS* dy, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                             size_t workspace_bytes, int N, int HW, int C, hipStream_t stream);
+
 extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, const float* mean,
                                             const float* rstd, const float* gamma,
                                             const float* beta, const float* mask, float slope,
                                             float* dy, float* dgamma, float* dbeta, float* dbias,
                                             void* workspace, size_t workspace_bytes, int N, int HW,
                                             int C, unet_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return instnorm_bwd_impl<float>(ga, y, mean, rstd, gamma, beta, mask, slope, dy, dgamma, dbeta,
+                                  dbias, workspace, workspace_bytes, N, HW, C, (hipStream_t)stream_);
+}
+
+// bf16 storage (mixed-precision pipeline): ga, y, dy are bf16 tensors, the arithmetic is fp32
+extern "C" int unet_instnorm_lrelu_drop_bwd_b16(const uint16_t* ga, const uint16_t* y,
+                                                const float* mean, const float* rstd,
+                                                const float* gamma, const float* beta,
+                                                const float* mask, float slope, uint16_t* dy,
+                                                float* dgamma, float* dbeta, float* dbias,
+                                                void* workspace, size_t workspace_bytes, int N,
+                                                int HW, int C, unet_stream_t stream_) {
+  return instnorm_bwd_impl<__bf16>(reinterpret_cast<const __bf16*>(ga),
+                                   reinterpret_cast<const __bf16*>(y), mean, rstd, gamma, beta,
+                                   mask, slope, reinterpret_cast<__bf16*>(dy), dgamma, dbeta, dbias,
+                                   workspace, workspace_bytes, N, HW, C, (hipStream_t)stream_);
+}
+
+template <typename TS>
+static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const float* mask, float slope,
+                             TS* dy, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                             size_t workspace_bytes, int N, int HW, int C, hipStream_t stream) {
   UNET_REQUIRE(ga && y && mean && rstd && gamma && beta && dy && workspace,
                "instnorm_lrelu_drop_bwd: null pointer");
   UNET_REQUIRE(shape_ok(N, HW, C) && kThreads % (C / 4) == 0,
@@ -532,7 +567,7 @@ extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, con
   ws += align_up((size_t)N * split * C * sizeof(float), 256);
   float* dbstage = reinterpret_cast<float*>(ws);
   const size_t lds2 = (size_t)groups * 2 * C * sizeof(float);
-  hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(split, N), dim3(kThreads), lds2, stream, ga, y,
+  hipLaunchKernelGGL(in_bwd_reduce_kernel<TS>, dim3(split, N), dim3(kThreads), lds2, stream, ga, y,
                      mean, rstd, gamma, beta, mask, slope, partial, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_reduce");
   hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
@@ -544,7 +579,7 @@ extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, con
     UNET_CHECK_LAUNCH("in_bwd_finalize2");
   }
   const size_t lds1 = (size_t)groups * C * sizeof(float);
-  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(split, N), dim3(kThreads), lds1, stream, ga, y, mean,
+  hipLaunchKernelGGL(in_bwd_apply_kernel<TS>, dim3(split, N), dim3(kThreads), lds1, stream, ga, y, mean,
                      rstd, gamma, beta, mask, slope, coef, dy, dbias ? dbp : nullptr, HW, C, split);
   UNET_CHECK_LAUNCH("in_bwd_apply");
   if (dbias) {

@@ -218,8 +218,9 @@ __device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float
 
 // alpha != nullptr (fused layer pipeline): x is a raw convolution output; its InstanceNorm +
 // LeakyReLU + dropout is applied to each of the four taps before they are blended.
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x,
-                                                             float* __restrict__ y, int h, int w,
+template <typename TS>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const TS* __restrict__ x,
+                                                             TS* __restrict__ y, int h, int w,
                                                              int C, long long total4,
                                                              const float* __restrict__ alpha,
                                                              const float* __restrict__ beta,
@@ -238,11 +239,11 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
     float wy0, wy1, wx0, wx1;
     up_taps(oy, h, y0, y1, wy0, wy1);
     up_taps(ox, w, x0, x1, wx0, wx1);
-    const float* b = x + (size_t)n * h * w * C + c;
-    f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x0) * C);
-    f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x1) * C);
-    f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x0) * C);
-    f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x1) * C);
+    const TS* b = x + (size_t)n * h * w * C + c;
+    f32x4 v00 = ld4(b + ((size_t)y0 * w + x0) * C);
+    f32x4 v01 = ld4(b + ((size_t)y0 * w + x1) * C);
+    f32x4 v10 = ld4(b + ((size_t)y1 * w + x0) * C);
+    f32x4 v11 = ld4(b + ((size_t)y1 * w + x1) * C);
     if (alpha) {   // uniform
       const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * C + c);
       const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (size_t)n * C + c);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
       v11 = unet_conv::act4(v11, al, be, slope, true);
     }
     const f32x4 o = (v00 * wx0 + v01 * wx1) * wy0 + (v10 * wx0 + v11 * wx1) * wy1;
-    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    st4(y + i * 4, o);
   }
 }
 
@@ -309,8 +310,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 // tensor) once dy has been reduced to the nine tensors D_tap.  This kernel writes
 // D[n][i][j][tap * C + c] (9C channels per low-resolution pixel) from dy[n][2h][2w][C].
 // One thread = one low-resolution pixel x 4 channels: 6 x 6 dy pixels in, 9 x 4 sums out.
-__global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const float* __restrict__ dy,
-                                                                  float* __restrict__ D, int h,
+template <typename TS>
+__global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const TS* __restrict__ dy,
+                                                                  TS* __restrict__ D, int h,
                                                                   int w, int C, long long total4) {
   const int lpp = C >> 2;
   const int H2 = 2 * h, W2 = 2 * w;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const float* _
     wx[1] = j == 0 ? 1.0f : 0.75f;
     wx[2] = j == w - 1 ? 1.0f : 0.75f;
     wx[3] = j < w - 1 ? 0.25f : 0.f;
-    const float* b = dy + (size_t)n * H2 * W2 * C + c;
+    const TS* b = dy + (size_t)n * H2 * W2 * C + c;
     f32x4 acc[3][3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -348,9 +350,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const float* _
 #pragma unroll
       for (int cc = 0; cc < 6; ++cc) {
         const int Rx = 2 * j - 2 + cc;
-        v[cc] = (unsigned)Rx < (unsigned)W2
-                    ? *reinterpret_cast<const f32x4*>(b + ((size_t)Ry * W2 + Rx) * C)
-                    : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[cc] = (unsigned)Rx < (unsigned)W2 ? ld4(b + ((size_t)Ry * W2 + Rx) * C)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       // column stencil: for tap kx, up column S = 2j-1+bb reads dy column S-(kx-1) = index
       // cc = bb + 2 - kx of v
@@ -377,12 +378,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const float* _
         for (int kx = 0; kx < 3; ++kx) acc[ky][kx] += colsum[kx] * wgt;
       }
     }
-    float* o = D + (size_t)pix * 9 * C + c;
+    TS* o = D + (size_t)pix * 9 * C + c;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-        *reinterpret_cast<f32x4*>(o + (size_t)(ky * 3 + kx) * C) = acc[ky][kx];
+      for (int kx = 0; kx < 3; ++kx) st4(o + (size_t)(ky * 3 + kx) * C, acc[ky][kx]);
   }
 }
 
@@ -490,7 +490,7 @@ extern "C" int unet_upsample2x_fwd(const float* x, float* y, int N, int h, int w
   UNET_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
                "upsample2x_fwd: bad argument");
   const long long total4 = (long long)N * 4 * h * w * (C / 4);
-  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+  hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(stream_grid(total4)), dim3(256), 0,
                      (hipStream_t)stream, x, y, h, w, C, total4, (const float*)nullptr,
                      (const float*)nullptr, 0.f);
   UNET_CHECK_LAUNCH("upsample2x_fwd");
@@ -503,9 +503,22 @@ extern "C" int unet_upsample2x_in_fwd(const unet_act_src* x, float slope, float*
                    (!x->alpha || x->beta),
                "upsample2x_in_fwd: bad argument");
   const long long total4 = (long long)N * 4 * h * w * (x->C / 4);
-  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+  hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(stream_grid(total4)), dim3(256), 0,
                      (hipStream_t)stream, x->x, up, h, w, x->C, total4, x->alpha, x->beta, slope);
   UNET_CHECK_LAUNCH("upsample2x_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_upsample2x_in_fwd_b16(const unet_act_src* x, float slope, uint16_t* up, int N,
+                                          int h, int w, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && up && N > 0 && h > 0 && w > 0 && x->C > 0 && x->C % 4 == 0 &&
+                   (!x->alpha || x->beta),
+               "upsample2x_in_fwd_b16: bad argument");
+  const long long total4 = (long long)N * 4 * h * w * (x->C / 4);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel<__bf16>, dim3(stream_grid(total4)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const __bf16*>(x->x),
+                     reinterpret_cast<__bf16*>(up), h, w, x->C, total4, x->alpha, x->beta, slope);
+  UNET_CHECK_LAUNCH("upsample2x_fwd(b16)");
   return UNET_OK;
 }
 
@@ -525,9 +538,21 @@ extern "C" int unet_upsample2x_bwd_taps(const float* dy, float* D, int N, int h,
   UNET_REQUIRE(dy && D && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
                "upsample2x_bwd_taps: bad argument");
   const long long total4 = (long long)N * h * w * (C / 4);
-  hipLaunchKernelGGL(upsample2x_bwd_taps_kernel, dim3(stream_grid(total4)), dim3(256), 0,
+  hipLaunchKernelGGL(upsample2x_bwd_taps_kernel<float>, dim3(stream_grid(total4)), dim3(256), 0,
                      (hipStream_t)stream, dy, D, h, w, C, total4);
   UNET_CHECK_LAUNCH("upsample2x_bwd_taps");
+  return UNET_OK;
+}
+
+extern "C" int unet_upsample2x_bwd_taps_b16(const uint16_t* dy, uint16_t* D, int N, int h, int w,
+                                            int C, unet_stream_t stream) {
+  UNET_REQUIRE(dy && D && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
+               "upsample2x_bwd_taps_b16: bad argument");
+  const long long total4 = (long long)N * h * w * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_taps_kernel<__bf16>, dim3(stream_grid(total4)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const __bf16*>(dy),
+                     reinterpret_cast<__bf16*>(D), h, w, C, total4);
+  UNET_CHECK_LAUNCH("upsample2x_bwd_taps(b16)");
   return UNET_OK;
 }
 

@@ -77,6 +77,14 @@ def _f32(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+def _b16(shape, like):
+    return torch.empty(shape, dtype=torch.bfloat16, device=like.device)
+
+
+def _is_b16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
 def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
@@ -208,6 +216,17 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     N, Ho, Wo, Cout = dy.shape
     cin_total = wd.shape[1]
     assert wd.shape[0] == 9 and wd.shape[2] == Cout
+    if _is_b16(dy):     # mixed-precision pipeline: bf16 tensors, bf16 matrix cores
+        dx = out if out is not None else _b16((N, H, W, ccols), dy)
+        assert dx.shape == (N, H, W, ccols) and _is_b16(dx)
+        t0 = _timer.begin() if _timer is not None else None
+        check(lib().unet_conv3x3_bwd_data_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx),
+                                              N, H, W, Cout, ccols, stride,
+                                              1 if accumulate else 0, _stream()))
+        if t0 is not None:
+            _timer.end("conv_igemm_bf16", 2.0 * N * Ho * Wo * 9 * ccols * Cout,
+                       1 if stride == 1 else 4, t0)
+        return dx
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
     t0 = _timer.begin() if _timer is not None else None
@@ -316,13 +335,15 @@ def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma,
     N, H, W, C = y.shape
     dy = ga if out is None else out
     ws = _ws(lib().unet_instnorm_workspace_bytes(N, H * W, C), y)
+    fn = lib().unet_instnorm_lrelu_drop_bwd_b16 if _is_b16(y) else lib().unet_instnorm_lrelu_drop_bwd
+    if _is_b16(y) != _is_b16(ga):
+        raise TypeError("ga and y must share their storage type")
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_instnorm_lrelu_drop_bwd(_ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd),
-                                             _ptr(gamma), _ptr(beta), _ptr(mask), slope, _ptr(dy),
-                                             _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws),
-                                             ws.numel(), N, H * W, C, _stream()))
+    check(fn(_ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(mask),
+             slope, _ptr(dy), _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws), ws.numel(), N,
+             H * W, C, _stream()))
     if t0 is not None:   # reduce pass: ga + y; apply pass: ga + y in, dy out (+ tiny finalizers)
-        _timer.end("instnorm_bwd", 0.0, 5, t0, nbytes=4.0 * 5 * y.numel())
+        _timer.end("instnorm_bwd", 0.0, 5, t0, nbytes=y.element_size() * 5 * y.numel())
     return dy
 
 
@@ -379,10 +400,12 @@ def _act(a):
     return a, ctypes.byref(st)
 
 
-def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask):
+def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b16=False):
     """Fused layer forward: y = conv(cat(act(s0), act(s1))) + bias and the InstanceNorm
     statistics of y.  Returns (y, st) with st = [mean, rstd, alpha, beta] as [4, N, Cout];
-    alpha / beta carry the dropout `mask` [N, Cout] (or None) folded in."""
+    alpha / beta carry the dropout `mask` [N, Cout] (or None) folded in.
+    b16: the mixed-precision pipeline - y (and the sources other than the fp32 RGB image) are
+    bf16 tensors, bf16 matrix cores, fp32 statistics."""
     u8 = s0 if isinstance(s0, U8Image) else None
     if u8 is None:
         s0, r0 = _act(s0)
@@ -394,9 +417,17 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask):
     Cout = w.shape[1] if ksize == 3 else w.shape[0]
     assert (w.shape[0] == 9 and w.shape[2] == C0 + C1) if ksize == 3 else w.shape[1] == C0 + C1
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = _f32((N, Ho, Wo, Cout), s0.x)
+    if b16:
+        for src in (s0, s1):
+            if src is not None and src.shape[3] != 3 and not _is_b16(src.x):
+                raise TypeError("the bf16 pipeline takes bf16 layer tensors")
+        if u8 is not None:
+            raise NotImplementedError("uint8 stem on the bf16 pipeline")
+    y = (_b16 if b16 else _f32)((N, Ho, Wo, Cout), s0.x)
     st = _f32((4, N, Cout), s0.x)
     ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, stride), s0.x)
+    fwd = lib().unet_conv_in_fwd_b16 if b16 else lib().unet_conv_in_fwd
+    fin = lib().unet_conv_in_stats_finalize_b16 if b16 else lib().unet_conv_in_stats_finalize
     px = ctypes.c_int(0)
     t0 = _timer.begin() if _timer is not None else None
     if u8 is not None:
@@ -405,15 +436,13 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask):
         check(lib().unet_stem_u8_fwd(_ptr(u8.x), m3, s3, _ptr(w), _ptr(bias), _ptr(y), _ptr(ws),
                                      ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     else:
-        check(lib().unet_conv_in_fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y),
-                                     _ptr(ws), ws.numel(), ctypes.byref(px), N, H, W, Cout,
-                                     _stream()))
+        check(fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y), _ptr(ws),
+                  ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     if t0 is not None:   # the convolution launch alone (its epilogue includes the statistics)
-        _timer.end("conv_stem_fwd" if C0 == 3 else "conv_igemm",
+        _timer.end("conv_stem_fwd" if C0 == 3 else ("conv_igemm_bf16" if b16 else "conv_igemm"),
                    2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout, 1, t0)
-    check(lib().unet_conv_in_stats_finalize(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma),
-                                            _ptr(beta), eps, _ptr(mask), _ptr(st[0]), _ptr(st[1]),
-                                            _ptr(st[2]), _ptr(st[3]), N, Ho * Wo, Cout, _stream()))
+    check(fin(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma), _ptr(beta), eps, _ptr(mask),
+              _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), N, Ho * Wo, Cout, _stream()))
     return y, st
 
 
@@ -435,12 +464,13 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
     Cout = dy.shape[3]
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride), dy)
+    b16 = _is_b16(dy)
+    fn = lib().unet_conv_in_bwd_weight_b16 if b16 else lib().unet_conv_in_bwd_weight
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv_in_bwd_weight(rx, slope, _ptr(dy), _ptr(dw_oihw), ci_offset,
-                                        dw_oihw.shape[1], ksize, stride, _ptr(ws), ws.numel(), N,
-                                        H, W, Cout, _stream()))
+    check(fn(rx, slope, _ptr(dy), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], ksize, stride,
+             _ptr(ws), ws.numel(), N, H, W, Cout, _stream()))
     if t0 is not None:
-        _timer.end("conv_stem_wgrad" if Cx == 3 else "conv_wgrad",
+        _timer.end("conv_stem_wgrad" if Cx == 3 else ("conv_wgrad_bf16" if b16 else "conv_wgrad"),
                    2.0 * N * dy.shape[1] * dy.shape[2] * ksize * ksize * Cx * Cout, 2, t0)
     return dw_oihw
 
@@ -448,22 +478,28 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
 def upsample2x_in_fwd(x, slope):
     x, rx = _act(x)
     N, h, w, C = x.shape
-    up = _f32((N, 2 * h, 2 * w, C), x.x)
+    b16 = _is_b16(x.x)
+    up = (_b16 if b16 else _f32)((N, 2 * h, 2 * w, C), x.x)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_upsample2x_in_fwd(rx, slope, _ptr(up), N, h, w, _stream()))
+    fn = lib().unet_upsample2x_in_fwd_b16 if b16 else lib().unet_upsample2x_in_fwd
+    check(fn(rx, slope, _ptr(up), N, h, w, _stream()))
     if t0 is not None:
-        _timer.end("upsample2x_fwd", 0.0, 1, t0, nbytes=4.0 * (x.x.numel() + up.numel()))
+        _timer.end("upsample2x_fwd", 0.0, 1, t0,
+                   nbytes=x.x.element_size() * (x.x.numel() + up.numel()))
     return up
 
 
 def upsample2x_bwd_taps(dy):
     """D[N, h, w, 9*C] = the nine transposed-upsampled shifts of dy[N, 2h, 2w, C] (tap-major)."""
     N, H2, W2, C = dy.shape
-    D = _f32((N, H2 // 2, W2 // 2, 9 * C), dy)
+    b16 = _is_b16(dy)
+    D = (_b16 if b16 else _f32)((N, H2 // 2, W2 // 2, 9 * C), dy)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_upsample2x_bwd_taps(_ptr(dy), _ptr(D), N, H2 // 2, W2 // 2, C, _stream()))
+    fn = lib().unet_upsample2x_bwd_taps_b16 if b16 else lib().unet_upsample2x_bwd_taps
+    check(fn(_ptr(dy), _ptr(D), N, H2 // 2, W2 // 2, C, _stream()))
     if t0 is not None:   # reads dy once, writes 9/4 of it
-        _timer.end("upsample2x_bwd_taps", 0.0, 1, t0, nbytes=4.0 * dy.numel() * (1 + 9 / 4))
+        _timer.end("upsample2x_bwd_taps", 0.0, 1, t0,
+                   nbytes=dy.element_size() * dy.numel() * (1 + 9 / 4))
     return D
 
 
@@ -474,12 +510,13 @@ def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
     Cout = D.shape[3] // 9
     assert D.shape[:3] == x.shape[:3] and dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     ws = _ws(lib().unet_conv3x3_up_bwd_weight_workspace_bytes(N, h, w, Cx, Cout), D)
+    fn = lib().unet_conv3x3_up_bwd_weight_b16 if _is_b16(D) else lib().unet_conv3x3_up_bwd_weight
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv3x3_up_bwd_weight(rx, slope, _ptr(D), _ptr(dw_oihw), ci_offset,
-                                           dw_oihw.shape[1], _ptr(ws), ws.numel(), N, h, w, Cout,
-                                           _stream()))
+    check(fn(rx, slope, _ptr(D), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], _ptr(ws), ws.numel(),
+             N, h, w, Cout, _stream()))
     if t0 is not None:   # algorithmic FLOPs: the 3x3 weight gradient on the up-sampled grid
-        _timer.end("conv_wgrad", 2.0 * N * 4 * h * w * 9 * Cx * Cout, 2, t0,
+        _timer.end("conv_wgrad_bf16" if _is_b16(D) else "conv_wgrad",
+                   2.0 * N * 4 * h * w * 9 * Cx * Cout, 2, t0,
                    executed=2.0 * N * h * w * 9 * Cx * Cout)
     return dw_oihw
 
@@ -490,12 +527,15 @@ def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False):
     Cout = C9 // 9
     cin_total = wd.shape[1]
     assert wd.shape[0] == 9 and wd.shape[2] == Cout
-    g = out if out is not None else _f32((N, h, w, ccols), D)
+    b16 = _is_b16(D)
+    g = out if out is not None else (_b16 if b16 else _f32)((N, h, w, ccols), D)
+    fn = lib().unet_conv3x3_up_bwd_data_b16 if b16 else lib().unet_conv3x3_up_bwd_data
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_conv3x3_up_bwd_data(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w,
-                                         Cout, ccols, 1 if accumulate else 0, _stream()))
+    check(fn(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,
+             1 if accumulate else 0, _stream()))
     if t0 is not None:   # algorithmic FLOPs: the 3x3 data gradient on the up-sampled grid
-        _timer.end("conv_igemm", 2.0 * N * 4 * h * w * 9 * ccols * Cout, 1, t0,
+        _timer.end("conv_igemm_bf16" if b16 else "conv_igemm",
+                   2.0 * N * 4 * h * w * 9 * ccols * Cout, 1, t0,
                    executed=2.0 * N * h * w * 9 * ccols * Cout)
     return g
 
@@ -505,11 +545,12 @@ def head1x1_in_fwd(x, slope, w, b):
     N, H, W, C = x.shape
     K = w.shape[0]
     logits = _f32((N, K, H, W), x.x)
+    fn = lib().unet_head1x1_in_fwd_b16 if _is_b16(x.x) else lib().unet_head1x1_in_fwd
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_head1x1_in_fwd(rx, slope, _ptr(w), _ptr(b), _ptr(logits), N, H * W, K,
-                                    _stream()))
+    check(fn(rx, slope, _ptr(w), _ptr(b), _ptr(logits), N, H * W, K, _stream()))
     if t0 is not None:
-        _timer.end("head_fwd", 0.0, 1, t0, nbytes=4.0 * (x.x.numel() + logits.numel()))
+        _timer.end("head_fwd", 0.0, 1, t0,
+                   nbytes=x.x.element_size() * x.x.numel() + 4.0 * logits.numel())
     return logits
 
 
@@ -519,11 +560,13 @@ def head1x1_in_bwd(x, slope, dlogits, w, dw, db):
     K = w.shape[0]
     da = torch.empty_like(x.x)
     ws = _ws(lib().unet_head1x1_bwd_workspace_bytes(N, H * W, C, K), x.x)
+    fn = lib().unet_head1x1_in_bwd_b16 if _is_b16(x.x) else lib().unet_head1x1_in_bwd
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().unet_head1x1_in_bwd(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw),
-                                    _ptr(db), _ptr(ws), ws.numel(), N, H * W, K, _stream()))
+    check(fn(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw), _ptr(db), _ptr(ws),
+             ws.numel(), N, H * W, K, _stream()))
     if t0 is not None:
-        _timer.end("head_bwd", 0.0, 2, t0, nbytes=4.0 * (2 * da.numel() + dlogits.numel()))
+        _timer.end("head_bwd", 0.0, 2, t0,
+                   nbytes=da.element_size() * 2 * da.numel() + 4.0 * dlogits.numel())
     return da
 
 

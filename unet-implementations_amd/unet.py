@@ -473,9 +473,14 @@ class _UNetFunction(torch.autograd.Function):
                                   wd3=wd3 if l.ksize == 3 else None))
             return a
 
-        fused = bf16 == "fp32" and model.fused_pipeline and \
-            len({l.slope for l in layers}) == 1
+        # The fused pipeline serves the fp32 mode and the mixed-precision mode ("bf16": there the
+        # layer tensors themselves are bf16 in HBM); 0 <= slope <= 1 (lrelu(z) = max(z, slope z)),
+        # one slope for the whole net.  Anything else runs the stand-alone passes.
         slope = layers[0].slope
+        fused = bf16 in ("fp32", "bf16") and model.fused_pipeline and \
+            len({l.slope for l in layers}) == 1 and 0.0 <= slope <= 1.0 and \
+            not (bf16 == "bf16" and fusion is not None)
+        b16 = fused and bf16 == "bf16"
 
         def run_layer_fused(l, s0, s1):
             """s0 / s1: ops.Act operands; returns the Act of this layer's output."""
@@ -488,7 +493,8 @@ class _UNetFunction(torch.autograd.Function):
                 wk, wd = table.wf[k], table.wd[k]
             m = mask_of[id(l)]
             y, st = ops.conv_in_fwd(s0, s1, slope, wk, l.conv.bias.detach(), l.ksize, l.stride,
-                                    l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps, m)
+                                    l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps, m,
+                                    b16=b16)
             if need_grad:
                 saved.append(dict(layer=l, x0=s0, x1=s1, y=y, st=st, mask=m, wd=wd, wd3=None))
             return ops.Act(y, st[2], st[3])
@@ -503,7 +509,7 @@ class _UNetFunction(torch.autograd.Function):
                 saved[-1]["x0_low"] = low
             return out
 
-        if isinstance(x, ops.U8Image) and not fused:
+        if isinstance(x, ops.U8Image) and (not fused or b16):
             raise RuntimeError("the uint8 stem needs the fused fp32 pipeline")
         if fused:
             run_layer = run_layer_fused
