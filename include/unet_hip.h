@@ -337,6 +337,19 @@ int unet_conv_in_stats_finalize(const float* y, void* workspace, size_t workspac
                                 const float* mask, float* mean, float* rstd, float* alpha_out,
                                 float* beta_out, int N, int HoWo, int Cout, unet_stream_t stream);
 
+/* First convolution of a decoder stage with the bilinear 2x up-sampling done in the loader:
+ *   y[N][H][W][Cout] = conv3x3(cat(upsample2x(act(low)), act(skip))) + bias,
+ * low->x = [N][H/2][W/2][C0] raw, skip->x = [N][H][W][C1] raw: UpBlock.forward
+ * (Our_UNet/models/unet.py:215-231) without the up-sampled tensor and without the concatenation.
+ * Covers the shapes the patch-staged kernel tiles (unet_conv_up_in_fwd_supported != 0; H % 4,
+ * W % 32, channels % 32, >= 512 tiles); otherwise use unet_upsample2x_in_fwd + unet_conv_in_fwd.
+ * Workspace, *stats_px_out and the statistics finalize as unet_conv_in_fwd (stride 1). */
+int unet_conv_up_in_fwd_supported(int N, int H, int W, int C0, int C1, int Cout);
+int unet_conv_up_in_fwd(const unet_act_src* low, const unet_act_src* skip, float slope,
+                        const float* wf, const float* bias, float* y, void* workspace,
+                        size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
+                        unet_stream_t stream);
+
 /* RGB stem straight from the dataset's uint8 HWC image [N][H][W][3]: the normalisation
  * ((v / 255) - mean[c]) / std[c] of PetSegmentationDataset.__getitem__ (Our_UNet/src/train.py:
  * 303-308) happens in the loaders of the first convolution and of its weight gradient, so the

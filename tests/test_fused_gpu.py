@@ -399,3 +399,49 @@ def test_reference_batch_size_32_layer_runs(ua):
                                   0, 3, 1)
         acc += dwq
     check(dw[:, :C0], acc[:, :C0], 1e-5, "dw over the 2 GiB operand")
+
+
+# --------------------------------------------------------------------------- up-sampling in the loader
+UPFWD_CASES = [  # (N, H, W, C0, C1, Cout, act0, act1): H, W = output (skip) size
+    (1, 256, 256, 64, 32, 128, True, True),      # 128-column tile
+    (1, 256, 256, 32, 32, 64, True, True),       # 64-column tile
+    (2, 256, 256, 64, 32, 32, True, False),      # 32 columns x 8 rows; plain skip
+    (8, 32, 32, 64, 32, 512, True, True),        # small maps: every tile touches an image border
+    (1, 256, 256, 32, 0, 64, False, True),       # no skip source, plain low-resolution operand
+]
+
+
+@pytest.mark.parametrize("case", UPFWD_CASES)
+def test_conv_up_in_fwd(ua, case):
+    """conv3x3(cat(upsample2x(act(low)), act(skip))) with the bilinear gather in the patch loader
+    against F.interpolate + torch.cat + F.conv2d (Our_UNet/models/unet.py:215-231), statistics
+    included."""
+    N, H, W, C0, C1, Cout, act0, act1 = case
+    low = rnd(N, C0, H // 2, W // 2, seed=1)
+    skip = rnd(N, C1, H, W, seed=2) if C1 else None
+    c0 = coeffs(N, C0, 10) if act0 else None
+    c1 = coeffs(N, C1, 20) if (act1 and C1) else None
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=(2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma, beta = rnd(Cout, seed=5) * 0.2 + 1.0, rnd(Cout, seed=6) * 0.2
+    a0 = act_ref(low, *c0) if c0 else low.double()
+    parts = [F.interpolate(a0, scale_factor=2, mode="bilinear", align_corners=False)]
+    if C1:
+        parts.append(act_ref(skip, *c1) if c1 else skip.double())
+    y_ref = F.conv2d(torch.cat(parts, 1), w.double(), b.double(), padding=1)
+    wf, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    s_low = make_src(ua, low, c0)
+    if not C1:
+        pytest.skip("single-source form is not exposed")
+    s_skip = make_src(ua, skip, c1)
+    assert ua.ops.conv_up_in_fwd_supported(s_low, s_skip, Cout)
+    y, st = ua.ops.conv_up_in_fwd(s_low, s_skip, SLOPE, wf, b.to(DEV), gamma.to(DEV), beta.to(DEV),
+                                  1e-5, None)
+    check(from_nhwc(y), y_ref, 2e-5, "y")
+    assert (st[0].cpu().double() - y_ref.mean(dim=(2, 3))).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), 1.0 / torch.sqrt(y_ref.var(dim=(2, 3), unbiased=False) + 1e-5), 5e-5, "rstd")
+    # and it is the same as the two-kernel path (materialised up-sampling)
+    up = ua.ops.Act(ua.ops.upsample2x_in_fwd(s_low, SLOPE))
+    y2, _ = ua.ops.conv_in_fwd(up, s_skip, SLOPE, wf, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV),
+                               1e-5, None)
+    check(y, y2, 2e-6, "fused vs materialised up-sampling")

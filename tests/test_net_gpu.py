@@ -322,7 +322,10 @@ def test_train_step_drives_loss_down(ua):
 
 
 def test_bf16_matmul_mode_tracks_fp32(ua):
-    """matmul_precision="bf16" (BASELINE config 4): no reference numerics exist for it (the
+    """matmul_precision="bf16" on the STAND-ALONE pipeline (fused_pipeline = False: bf16 MFMA
+    operands, fp32 tensors in HBM; the default bf16 mode with bf16 tensors in HBM is covered by
+    tests/test_bf16_gpu.py against the oracle's emulation of its rounding points).
+    BASELINE config 4: no reference numerics exist for it (the
     reference's AMP is fp16 autocast), so it is held to a bf16-sized tolerance against the
     fp32 path on the same weights, inputs and masks, and must train.
 
@@ -340,6 +343,7 @@ def test_bf16_matmul_mode_tracks_fp32(ua):
         model.load_state_dict(sd0)
         model = model.to(DEV).train()
         model.matmul_precision = mode
+        model.fused_pipeline = mode == "fp32"
         model.dropout_mask_override = masks
         logits = model(img.to(DEV))
         loss = ua.SimpleLoss()(logits, tgt.to(DEV))
@@ -356,6 +360,7 @@ def test_bf16_matmul_mode_tracks_fp32(ua):
     # and it trains
     model = ua.create_model(DEV).train()
     model.matmul_precision = "bf16"
+    model.fused_pipeline = False
     opt = ua.create_optimizer(model)
     lossf = ua.get_loss_function()
     img, tgt = O.synthetic_batch(3, 2, 64, 64)

@@ -79,6 +79,9 @@ SIGNATURES = {
     "unet_conv_in_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "unet_conv_in_fwd": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,
                               _i, _p]),
+    "unet_conv_up_in_fwd_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_conv_up_in_fwd": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i, _i,
+                                 _p]),
     "unet_conv_in_stats_finalize": (_i, [_p, _p, _sz, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i,
                                          _p]),
     "unet_stem_u8_fwd": (_i, [_p, _c.POINTER(_f), _c.POINTER(_f), _p, _p, _p, _p, _sz,

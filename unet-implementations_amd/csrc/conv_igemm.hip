@@ -1558,3 +1558,62 @@ extern "C" int unet_stem_u8_fwd(const uint8_t* image_hwc, const float* mean3, co
   *stats_px_out = STEM_ROW_PIX;
   return UNET_OK;
 }
+
+// ---------------------------------------------------------------------------
+// y = conv3x3(cat(upsample2x(act(low)), act(skip))) + bias with the bilinear up-sampling done in
+// the patch loader (conv_patch.hip conv_patch_up_kernel): UpBlock.forward without the up-sampled
+// tensor and without the concatenation (Our_UNet/models/unet.py:215-231).  low->x is
+// [N][H/2][W/2][C0], skip->x [N][H][W][C1]; workspace / *stats_px_out as unet_conv_in_fwd.
+// ---------------------------------------------------------------------------
+extern "C" int unet_conv_up_in_fwd_supported(int N, int H, int W, int C0, int C1, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 32 || C0 < 32 || C0 % 32 || C1 < 0 || C1 % 32 ||
+      Cout % 32)
+    return 0;
+  const long long M = (long long)N * H * W, mt = M / 128;
+  if ((long long)H * W * (C0 > 4 * C1 ? C0 / 4 : C1) * 4 * N >= (1LL << 31)) return 0;
+  if (Cout % 128 == 0 && mt * (Cout / 128) >= 512) return 1;
+  if (Cout % 64 == 0 && mt * (Cout / 64) >= 512) return 1;
+  if (Cout == 32 && H % 8 == 0 && M / 256 >= 512) return 1;
+  return 0;
+}
+
+extern "C" int unet_conv_up_in_fwd(const unet_act_src* low, const unet_act_src* skip, float slope,
+                                   const float* wf, const float* bias, float* y, void* workspace,
+                                   size_t workspace_bytes, int* stats_px_out, int N, int H, int W,
+                                   int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(low && low->x && wf && y && workspace && stats_px_out,
+               "conv_up_in_fwd: null pointer");
+  const int C0 = low->C, C1 = skip ? skip->C : 0;
+  UNET_REQUIRE(C1 == 0 || skip->x, "conv_up_in_fwd: skip source is null");
+  UNET_REQUIRE((!low->alpha || low->beta) && (!skip || !skip->alpha || skip->beta),
+               "conv_up_in_fwd: alpha without beta");
+  UNET_REQUIRE(H % 2 == 0 && W % 2 == 0 && unet_conv_up_in_fwd_supported(N, H, W, C0, C1, Cout),
+               "conv_up_in_fwd: shape N=%d %dx%d (%d+%d)->%d has no fused-upsample tile (query "
+               "unet_conv_up_in_fwd_supported and fall back to unet_upsample2x_in_fwd)",
+               N, H, W, C0, C1, Cout);
+  if (workspace_bytes < unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1)) {
+    unet_set_error("conv_up_in_fwd: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  IgemmParams p{};
+  p.src0 = low->x; p.src1 = skip ? skip->x : nullptr; p.C0 = C0; p.C1 = C1;
+  p.act0_alpha = low->alpha; p.act0_beta = low->alpha ? low->beta : nullptr;
+  p.act1_alpha = skip ? skip->alpha : nullptr;
+  p.act1_beta = (skip && skip->alpha) ? skip->beta : nullptr;
+  p.slope = slope;
+  p.w = wf; p.tap_stride = Cout * (C0 + C1); p.n_off = 0; p.bias = bias;
+  p.src0_bytes = (unsigned)((long long)N * (H / 2) * (W / 2) * C0 * 4);
+  p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 4);
+  p.w_bytes = (unsigned)((long long)9 * Cout * (C0 + C1) * 4);
+  p.out = y; p.ldo = Cout; p.accumulate = 0;
+  p.N = N; p.Hin = H; p.Win = W; p.Hl = p.Hout = H; p.Wl = p.Wout = W;
+  p.Ncols = Cout;
+  p.stats = reinterpret_cast<float2*>(workspace);
+  fill_fwd_taps(p, 1);
+  int px = 0;
+  const int rc = launch_patch_up_auto(p, (hipStream_t)stream, &px);
+  UNET_REQUIRE(rc != 1, "conv_up_in_fwd: no tile fits");
+  if (rc != UNET_OK) return rc;
+  *stats_px_out = px;
+  return UNET_OK;
+}

@@ -168,6 +168,7 @@ __device__ __forceinline__ bool block_col_stats(float2* red, int wave_m, int col
 bool patch_f32_applicable(const IgemmParams& p);              // conv_patch.hip
 int launch_patch_f32_auto(const IgemmParams& p, hipStream_t stream,    // returns 1 if no tile fits
                           int* stats_px = nullptr);
+int launch_patch_up_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
 int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream);
 bool patch_split_applicable(const IgemmParams& p);
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream,           // conv_igemm.hip

@@ -9,8 +9,20 @@
 #include "conv_params.h"
 #include <stdlib.h>
 
+#include <utility>
+
 namespace unet_conv {
 namespace {
+
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E)
+template <int B, int... I, typename F>
+__device__ __forceinline__ void for_range_p_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, typename F>
+__device__ __forceinline__ void for_range_p(F&& f) {
+  for_range_p_impl<B>(std::make_integer_sequence<int, (E > B ? E - B : 0)>{}, f);
+}
 
 // ---------------------------------------------------------------------------
 // Patch-staged split-bf16 kernel: stride-1 3x3 convolution (forward and data gradient) whose
@@ -461,6 +473,308 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
   }
 }
 
+// ---------------------------------------------------------------------------
+// First convolution of a decoder stage: y = conv3x3(cat(upsample2x(act(low)), act(skip))) with the
+// bilinear up-sampling done INSIDE the patch loader (Our_UNet/models/unet.py:215-231: the
+// reference materialises both the up-sampled tensor and the concatenation).  Source 0 is the
+// LOW-resolution raw tensor [N][H/2][W/2][C0]; per 32-channel chunk of it the (TH/2+2) x 18
+// low-resolution pixels under the tile's patch are activated and staged into a small LDS
+// scratch (coordinates clamped to the image: the align_corners=False stencil at exact 2x is
+// {0.75, 0.25} with edge clamping), and every high-resolution patch pixel is blended from its
+// 2 x 2 low-resolution neighbours with PyTorch's operation order
+//   wy0 * (wx0 * p00 + wx1 * p01) + wy1 * (wx0 * p10 + wx1 * p11)
+// (parity of the pixel picks 0.75 / 0.25); zero padding is applied after the blend.
+// The nine taps are unrolled so the staging work of the NEXT chunk is spread behind this
+// chunk's MFMAs: tap 0 issues the loads, tap 2 activates + writes the low-resolution scratch,
+// taps 3..7 blend, tap 8 writes the patch.  Chunks of source 1 (the skip tensor) are staged as
+// in conv_patch_f32_kernel.  Always the fused-layer form (activation on load, statistics).
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN, int TH>
+__global__ __launch_bounds__(256, 2) void conv_patch_up_kernel(const IgemmParams p) {
+  constexpr int BK = 32, LDA = BK + 4;
+  constexpr int TW = 32, PW = TW + 2;
+  constexpr int PPIX = (TH + 2) * PW;
+  constexpr int P_SLOTS = PPIX * 8;
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = BN * LDA;
+  constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2, LPIX = LH * LW;
+  constexpr int L_SLOTS = LPIX * 8, L_PASSES = (L_SLOTS + 255) / 256;
+  constexpr int BPER = (P_PASSES + 4) / 5;     // patch slots blended per tap (taps 3..7)
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                          // [pixel][LDA]
+  float* Bs = smem + PPIX * LDA;             // [buf][BN][LDA]
+  float* Ls = Bs + 2 * B_TILE;               // [low pixel][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+  const int seg = tid & 7;                   // this thread's 4 channels of a chunk (every pass)
+
+  const int H = p.Hin, W = p.Win, h = H >> 1, w = W >> 1;
+  const int tiles_n = p.Ncols / BN, tiles_x = W / TW, tiles_y = H / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int Ktot = p.C0 + p.C1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  // Slot geometry is DERIVED per use from two registers (a pass advances 32 pixels: 256 threads
+  // x 4 channels of a 32-channel pixel) instead of held in per-slot arrays: this kernel carries
+  // the patch, the low-resolution scratch values and the weight panel in registers at once.
+  const int pix0 = tid >> 3;                 // patch pixel of pass 0 (pass i: + 32 i)
+  // (the empty asm hides the value from loop-invariant code motion, which would otherwise
+  // rebuild the per-slot arrays in registers and spill)
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto patch_slot = [&](int i, int& prow, int& pcol) {   // false: past the patch (last pass)
+    const int pix = opaque(pix0) + 32 * i;
+    prow = pix / PW;
+    pcol = pix - prow * PW;
+    return pix < PPIX;
+  };
+  auto low_slot = [&](int j, int& lpix) {    // clamped global pixel index (x4) of scratch slot j
+    lpix = opaque(pix0) + 32 * j;
+    const int lp = lpix < LPIX ? lpix : LPIX - 1;
+    const int lr = lp / LW, lc = lp - lr * LW;
+    int gy = (y0 >> 1) - 1 + lr, gx = (x0 >> 1) - 1 + lc;
+    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+    return ((n * h + gy) * w + gx) * 4;
+  };
+  const unsigned wslot_off0 = (unsigned)((p.n_off + n0 + pix0) * Ktot + seg * 4) * 4u;
+  const int wslot_lds0 = pix0 * LDA + seg * 4;
+  static_assert(BN % 32 == 0, "weight rows advance 32 per pass");
+
+  f32x4 pr[P_PASSES], rb[B_PASSES], lr4[L_PASSES];
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+
+  auto load_coef = [&](const float* al, const float* be, int Cs, int cch) {
+    if (al) {   // uniform
+      const size_t o = (size_t)n * Cs + cch + seg * 4;
+      ca = *reinterpret_cast<const f32x4*>(al + o);
+      cb = *reinterpret_cast<const f32x4*>(be + o);
+      cs = p.slope;
+    } else {    // plain source: z = v, slope 1 = identity
+      ca = f32x4{1.f, 1.f, 1.f, 1.f};
+      cb = f32x4{0.f, 0.f, 0.f, 0.f};
+      cs = 1.f;
+    }
+  };
+  // next chunk from source 0 (low resolution) / source 1 (skip tensor, as conv_patch_f32_kernel)
+  auto load_low = [&](int chunk) {
+    const unsigned cbytes = (unsigned)(chunk * BK + seg * 4) * 4u;
+#pragma unroll
+    for (int j = 0; j < L_PASSES; ++j) {
+      int lpix;
+      const int lin = low_slot(j, lpix);
+      lr4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rs0, (unsigned)(lin * p.C0) + cbytes, 0, 0));
+    }
+    load_coef(p.act0_alpha, p.act0_beta, p.C0, chunk * BK);
+  };
+  auto load_skip = [&](int chunk) {
+    const int c = chunk * BK - p.C0;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      int prow, pcol;
+      const bool in = patch_slot(i, prow, pcol);
+      const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+      const bool ok = in && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const unsigned off = (unsigned)(((n * H + iy) * W + ix) * 4 * p.C1) +
+                           (unsigned)(c + seg * 4) * 4u;
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rs1, ok ? off : 0x80000000u, 0, 0));
+    }
+    load_coef(p.act1_alpha, p.act1_beta, p.C1, c);
+  };
+  auto store_low = [&]() {     // activation of the low-resolution pixels, then the scratch
+#pragma unroll
+    for (int j = 0; j < L_PASSES; ++j) {
+      const int lpix = pix0 + 32 * j;
+      if (lpix < LPIX)
+        *reinterpret_cast<f32x4*>(Ls + lpix * LDA + seg * 4) = act4f(lr4[j], ca, cb, cs, 1.f);
+    }
+  };
+  auto slot_ok = [&](int i) {   // 1 inside the image, 0 for a zero-padding (or surplus) slot
+    int prow, pcol;
+    const bool in = patch_slot(i, prow, pcol);
+    const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+    return (in && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? 1.f : 0.f;
+  };
+  auto blend_slot = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    int prow, pcol;
+    patch_slot(i, prow, pcol);
+    const float* L = Ls + (((prow >> 1) * LW + (pcol >> 1)) * LDA + seg * 4);
+    const f32x4 p00 = *reinterpret_cast<const f32x4*>(L);
+    const f32x4 p01 = *reinterpret_cast<const f32x4*>(L + LDA);
+    const f32x4 p10 = *reinterpret_cast<const f32x4*>(L + LW * LDA);
+    const f32x4 p11 = *reinterpret_cast<const f32x4*>(L + LW * LDA + LDA);
+    // odd patch row = even image row 2k: taps (k-1, k) weigh (0.25, 0.75); even patch row =
+    // odd image row: (0.75, 0.25); columns alike (y0, x0 are even)
+    const float wy1 = (prow & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+    const float wx1 = (pcol & 1) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+    pr[i] = ((p00 * wx0 + p01 * wx1) * wy0 + (p10 * wx0 + p11 * wx1) * wy1) * slot_ok(i);
+  };
+  auto act_skip_slot = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    pr[i] = act4f(pr[i], ca, cb, cs, slot_ok(i));
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const int pix = pix0 + 32 * i;
+      if (pix < PPIX) *reinterpret_cast<f32x4*>(Ps + pix * LDA + seg * 4) = pr[i];
+    }
+  };
+  auto load_b = [&](int t, int chunk) {
+    const unsigned woff = wslot_off0 + (unsigned)(t * p.tap_stride + chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsw, woff + (unsigned)(32 * j * Ktot) * 4u, 0, 0));
+  };
+  auto store_b = [&](int buf) {
+    float* Bb = Bs + buf * B_TILE + wslot_lds0;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + 32 * j * LDA) = rb[j];
+  };
+
+  const int chunks = Ktot / BK;
+  const int up_chunks = p.C0 / BK;           // >= 1: chunk 0 always comes from source 0
+  // ---- prologue: chunk 0 staged start to finish
+  load_low(0);
+  load_b(0, 0);
+  store_low();
+  store_b(0);
+  __syncthreads();
+  for_range_p<0, P_PASSES>(blend_slot);
+  store_patch();
+  __syncthreads();
+
+  const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 4 * lh;
+  const int b_lane = (wn0 + li) * LDA + 4 * lh;
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const int nxt = chunk + 1 < chunks ? chunk + 1 : chunk;   // the last chunk re-stages itself
+    const bool nxt_up = nxt < up_chunks;                       // uniform
+    for_range_p<0, 9>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      const int buf = (chunk + t) & 1;                         // 9 steps per chunk
+      load_b(t == 8 ? 0 : t + 1, t == 8 ? nxt : chunk);
+      if constexpr (t == 0) {
+        if (nxt_up) load_low(nxt);
+        else load_skip(nxt);
+      }
+      constexpr int oy = t / 3 - 1, ox = t % 3 - 1;
+      const float* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
+      const float* Bb = Bs + buf * B_TILE + b_lane;
+      f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * PW * LDA);
+#pragma unroll
+      for (int nb = 0; nb < TN; ++nb) b[0][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA);
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        const int cur = kk & 1, nx = cur ^ 1;
+        if (kk + 1 < BK / 8) {
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+            a[nx][m] = *reinterpret_cast<const f32x4*>(Ab + m * PW * LDA + (kk + 1) * 8);
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            b[nx][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA + (kk + 1) * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int nb = 0; nb < TN; ++nb)
+              acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][nb][r],
+                                                                acc[m][nb], 0, 0, 0);
+        // the next chunk's staging work, one piece per tap behind the first k-group's MFMAs
+        if (kk == 0) {
+          if constexpr (t == 2) {
+            if (nxt_up) store_low();
+          }
+          if constexpr (t >= 3 && t <= 7) {
+            constexpr int s0 = (t - 3) * BPER;
+            constexpr int s1 = s0 + BPER < P_PASSES ? s0 + BPER : P_PASSES;
+            if (nxt_up) for_range_p<s0, s1>(blend_slot);
+            else for_range_p<s0, s1>(act_skip_slot);
+          }
+        }
+      }
+      store_b(buf ^ 1);
+      if constexpr (t == 8) {    // every wave is done with this chunk's patch
+        __syncthreads();
+        store_patch();
+      }
+      __syncthreads();
+    });
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      float* o = p.out + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv;
+    }
+  }
+  if (p.stats) {   // uniform; the K loop ended on a barrier: the patch area is free scratch
+    constexpr int WAVES_M = 4 / WAVES_N;
+    float2* red = reinterpret_cast<float2*>(Ps);
+    static_assert(WAVES_M * BN * 2 <= PPIX * LDA, "stats scratch fits in the patch area");
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const int col = n0 + wn0 + nb * 32 + li;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r] + bv; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
+      p.stats[((size_t)n * p.stats_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
+  }
+}
+
+template <int BN, int WM, int WN, int TH>
+int launch_patch_up(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((TH + 2) * 34) * 36 + 2 * (size_t)BN * 36 +
+                          (size_t)((TH / 2 + 2) * 18) * 36) * sizeof(float);
+  auto kern = conv_patch_up_kernel<BN, WM, WN, TH>;
+  UNET_SET_DYN_LDS(kern, lds);
+  const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_up");
+  return UNET_OK;
+}
+
 template <int BN, int WM, int WN, int TH>
 int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds =
@@ -527,6 +841,30 @@ int launch_patch_f32_auto(const IgemmParams& p0, hipStream_t stream, int* stats_
     if (!fused) return launch_patch_f32<32, 64, 32, 8>(p, stream);
     *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
     return launch_patch_f32<32, 64, 32, 8, true, true>(p, stream);
+  }
+  return 1;
+}
+
+// conv3x3(cat(upsample2x(act(src0 at half resolution)), act(src1))): the up-sampling in the
+// loader.  Same tile choice as launch_patch_f32_auto; returns 1 when no tile fits (the caller
+// then materialises the up-sampled operand).
+int launch_patch_up_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+  IgemmParams p = p0;
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  const long long mt = M / 128;
+  if (p.Hin % 4 != 0 || p.Win % 32 != 0 || p.C0 % 32 != 0 || p.C1 % 32 != 0 || p.C0 < 32) return 1;
+  if (nc % 128 == 0 && mt * (nc / 128) >= 512) {
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_up<128, 64, 64, 4>(p, stream);
+  }
+  if (nc % 64 == 0 && mt * (nc / 64) >= 512) {
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_up<64, 64, 32, 4>(p, stream);
+  }
+  if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 512) {
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_patch_up<32, 64, 32, 8>(p, stream);
   }
   return 1;
 }

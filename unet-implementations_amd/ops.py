@@ -446,6 +446,36 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
     return y, st
 
 
+def conv_up_in_fwd_supported(low, skip, Cout):
+    N, H, W, C1 = skip.shape
+    return bool(lib().unet_conv_up_in_fwd_supported(N, H, W, low.shape[3], C1, Cout))
+
+
+def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask):
+    """y = conv3x3(cat(upsample2x(act(low)), act(skip))) + bias with the up-sampling in the
+    loader, plus the InstanceNorm statistics of y (as conv_in_fwd)."""
+    low, rl = _act(low)
+    skip, rs = _act(skip)
+    N, H, W, C1 = skip.shape
+    C0 = low.shape[3]
+    assert low.shape[1] * 2 == H and low.shape[2] * 2 == W and low.shape[0] == N
+    Cout = wf.shape[1]
+    assert wf.shape[0] == 9 and wf.shape[2] == C0 + C1
+    y = _f32((N, H, W, Cout), skip.x)
+    st = _f32((4, N, Cout), skip.x)
+    ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1), skip.x)
+    px = ctypes.c_int(0)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().unet_conv_up_in_fwd(rl, rs, slope, _ptr(wf), _ptr(bias), _ptr(y), _ptr(ws),
+                                    ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
+    if t0 is not None:
+        _timer.end("conv_igemm", 2.0 * N * H * W * 9 * (C0 + C1) * Cout, 1, t0)
+    check(lib().unet_conv_in_stats_finalize(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma),
+                                            _ptr(beta), eps, _ptr(mask), _ptr(st[0]), _ptr(st[1]),
+                                            _ptr(st[2]), _ptr(st[3]), N, H * W, Cout, _stream()))
+    return y, st
+
+
 def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
     """Weight gradient of a fused layer: dw[:, ci_offset : ci_offset + Cx] = act(x) (x) dy."""
     if isinstance(x, U8Image):

@@ -503,6 +503,18 @@ class _UNetFunction(torch.autograd.Function):
             """First conv of a decoder stage: conv3x3(cat(upsample2x(act(low)), act(skip))).
             The up-sampled tensor only lives for this call: backward works on `low`
             (ops.conv3x3_up_bwd_weight / _data)."""
+            w = l.conv.weight
+            if not b16 and l.ksize == 3 and ops.conv_up_in_fwd_supported(low, skip, w.shape[0]):
+                # the bilinear gather runs inside the conv's patch loader: no up-sampled tensor
+                k = packed[id(w)]
+                m = mask_of[id(l)]
+                y, st = ops.conv_up_in_fwd(low, skip, slope, table.wf[k], l.conv.bias.detach(),
+                                           l.norm.weight.detach(), l.norm.bias.detach(),
+                                           l.norm.eps, m)
+                if need_grad:
+                    saved.append(dict(layer=l, x0=None, x1=skip, y=y, st=st, mask=m,
+                                      wd=table.wd[k], wd3=None, x0_low=low))
+                return ops.Act(y, st[2], st[3])
             out = run_layer_fused(l, ops.Act(ops.upsample2x_in_fwd(low, slope)), skip)
             if need_grad:
                 saved[-1]["x0"] = None
