@@ -197,7 +197,9 @@ int unet_instnorm_lrelu_drop_fwd(const float* y, const float* alpha, const float
                                  unet_stream_t stream);
 
 /* Backward of the block above: from ga = dL/da produce dy = dL/dy (may alias ga),
- * dgamma[C], dbeta[C] and dbias[C] = sum dy (the conv bias gradient; may be NULL). */
+ * dgamma[C], dbeta[C] and dbias[C] = the gradient of the conv bias in front of the norm (may be
+ * NULL) = sum over pixels of dy, evaluated in closed form from the reduction sums: it is
+ * identically zero under InstanceNorm (the reference's autograd value is rounding noise). */
 int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta,
                                  const float* mask, float slope, float* dy, float* dgamma,

@@ -66,7 +66,11 @@ static inline hipError_t unet_set_max_dyn_lds(const void* kern, size_t bytes,
 int unet_in_finalize_tiles(const void* partial, int tiles, int px_per_tile, const float* gamma,
                            const float* beta, float eps, const float* mask, float* mean,
                            float* rstd, float* alpha, float* beta2, int N, int HW, int C,
-                           hipStream_t stream);
+                           hipStream_t stream, void* grp_scratch = nullptr);
+// bytes of `grp_scratch` (group sums of the two-level statistics finalize)
+static inline size_t unet_in_finalize_scratch_bytes(int N, int C) {
+  return (size_t)N * 16 * C * 2 * sizeof(float);
+}
 int unet_in_stats_masked(const float* y, const float* gamma, const float* beta, float eps,
                          const float* mask, float* mean, float* rstd, float* alpha, float* beta2,
                          void* workspace, size_t workspace_bytes, int N, int HW, int C,

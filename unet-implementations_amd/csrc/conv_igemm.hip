@@ -1277,7 +1277,8 @@ size_t stats_partial_bytes(int N, int HoWo, int Cout) {
 extern "C" size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout, int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || stride < 1) return 0;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const size_t a = stats_partial_bytes(N, Ho * Wo, Cout);
+  const size_t a = stats_partial_bytes(N, Ho * Wo, Cout) +
+                   align_up(unet_in_finalize_scratch_bytes(N, Cout), 256);
   const size_t b = unet_instnorm_workspace_bytes(N, Ho * Wo, Cout);
   return a > b ? a : b;
 }
@@ -1452,10 +1453,12 @@ static int conv_in_stats_finalize_impl(const float* y, void* workspace, size_t w
   UNET_REQUIRE(y && workspace && mean && rstd, "conv_in_stats_finalize: null pointer");
   UNET_REQUIRE(stats_px >= 0 && (stats_px == 0 || HoWo % stats_px == 0),
                "conv_in_stats_finalize: %d-pixel tiles do not cover %d pixels", stats_px, HoWo);
-  if (stats_px > 0)
+  if (stats_px > 0)   // the group scratch sits behind the summaries in the workspace
     return unet_in_finalize_tiles(workspace, HoWo / stats_px, stats_px, gamma, beta, eps, mask,
                                   mean, rstd, alpha_out, beta_out, N, HoWo, Cout,
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream,
+                                  reinterpret_cast<char*>(workspace) +
+                                      stats_partial_bytes(N, HoWo, Cout));
   return unet_in_stats_masked(y, gamma, beta, eps, mask, mean, rstd, alpha_out, beta_out, workspace,
                               workspace_bytes, N, HoWo, Cout, (hipStream_t)stream, b16);
 }
