@@ -403,6 +403,41 @@ int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin_total, int
                              float* g, int N, int h, int w, int Cout, int Ccols, int accumulate,
                              unet_stream_t stream);
 
+/* Data gradient whose output g = dL/da_l is FINAL for layer l (not a partial sum that another
+ * call still accumulates into): the epilogue can also emit the two reductions of layer l's
+ * InstanceNorm + LeakyReLU + dropout backward, S1 = sum gz and S2 = sum gz * xhat per tile,
+ * which saves the pass that would re-read g and y_l (unet_instnorm_lrelu_drop_bwd's first half).
+ * `bs` describes layer l; on return bs->tiles_out = summaries per image (0: this shape / kernel
+ * has no such epilogue - run unet_instnorm_lrelu_drop_bwd as usual).  bs->partial needs
+ * N * ceil(H*W / 64) * C * 8 bytes.  Consume with unet_instnorm_lrelu_drop_bwd_partials. */
+typedef struct unet_bwd_stats {
+  const float* y;      /* raw conv output of layer l, same shape as the gradient being written */
+  const float* mean;   /* [N][C] */
+  const float* rstd;   /* [N][C] */
+  const float* gamma;  /* [C] */
+  const float* beta;   /* [C] */
+  const float* mask;   /* [N][C] dropout factors or NULL */
+  float slope;
+  void* partial;
+  size_t partial_bytes;
+  int tiles_out;
+} unet_bwd_stats;
+int unet_conv3x3_bwd_data_bs(const float* dy, const float* wd, int Cin_total, int ci_offset,
+                             float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
+                             int accumulate, unet_bwd_stats* bs, unet_stream_t stream);
+int unet_conv3x3_up_bwd_data_bs(const float* D, const float* wd, int Cin_total, int ci_offset,
+                                float* g, int N, int h, int w, int Cout, int Ccols, int accumulate,
+                                unet_bwd_stats* bs, unet_stream_t stream);
+/* unet_instnorm_lrelu_drop_bwd with the reductions already summarised per tile
+ * (partial[(n * tiles + t) * C + c] = (S1, S2)). */
+int unet_instnorm_lrelu_drop_bwd_partials(const float* ga, const float* y, const float* mean,
+                                          const float* rstd, const float* gamma,
+                                          const float* beta, const float* mask, float slope,
+                                          float* dy, float* dgamma, float* dbeta, float* dbias,
+                                          const void* partial, int tiles, void* workspace,
+                                          size_t workspace_bytes, int N, int HW, int C,
+                                          unet_stream_t stream);
+
 /* ---- mixed precision with bf16 activations in HBM (BASELINE config 4) ----------------------
  * The reference's AMP path is fp16 autocast + GradScaler (Our_UNet/src/train.py:638-652); the
  * MI355X form is bf16 (fp32's exponent range: no loss scaling).  The *_b16 entry points are the

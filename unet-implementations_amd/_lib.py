@@ -29,6 +29,16 @@ class ActSrc(ctypes.Structure):
 
 _ps = _c.POINTER(ActSrc)
 
+
+class BwdStats(ctypes.Structure):
+    """`unet_bwd_stats` of include/unet_hip.h: the layer whose InstanceNorm-backward reductions a
+    data-gradient epilogue emits."""
+    _fields_ = [("y", _p), ("mean", _p), ("rstd", _p), ("gamma", _p), ("beta", _p), ("mask", _p),
+                ("slope", _f), ("partial", _p), ("partial_bytes", _sz), ("tiles_out", _i)]
+
+
+_pbs = _c.POINTER(BwdStats)
+
 # name -> (restype, argtypes); mirrors include/unet_hip.h one to one
 SIGNATURES = {
     "unet_last_error": (_c.c_char_p, []),
@@ -90,6 +100,10 @@ SIGNATURES = {
                                      _i, _i, _p]),
     "unet_conv_in_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
+    "unet_conv3x3_bwd_data_bs": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
+    "unet_conv3x3_up_bwd_data_bs": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _pbs, _p]),
+    "unet_instnorm_lrelu_drop_bwd_partials": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p,
+                                                   _p, _i, _p, _sz, _i, _i, _i, _p]),
     "unet_conv_in_fwd_b16": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i), _i, _i,
                                   _i, _i, _p]),
     "unet_conv_in_stats_finalize_b16": (_i, [_p, _p, _sz, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i,

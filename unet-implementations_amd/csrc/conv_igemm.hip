@@ -262,8 +262,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
         }
         o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
       }
-      store_block16(o, acc[m][n], bv, p.accumulate);
+      if (!FUSED && p.bs_partial) {   // uniform: keep the FINAL values for the reductions below
+        if (p.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] += bv + (o[r] ? *o[r] : 0.f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] += bv;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (o[r]) *o[r] = acc[m][n][r];
+      } else {
+        store_block16(o, acc[m][n], bv, p.accumulate);
+      }
     }
+  }
+  if (!FUSED && p.bs_partial) {   // uniform: reductions of the next backward stage (IgemmParams);
+    // needs every tile inside one image and all rows valid (dispatcher check)
+    constexpr int WAVES_M = BM / WM;
+    float2* red = reinterpret_cast<float2*>(As);
+    const int img = m0 / HlWl;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = n0 + wn0 + n * 32 + li;
+      const BwdCoef cf = bwd_coef(p, img, col);
+      const float2 mine = wave_bwd_stats<TM>(
+          cf, p.slope, [&](int m, int r) { return acc[m][n][r]; },
+          [&](int m, int r) {
+            const int mg = m0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            size_t opix = (size_t)mg;
+            if (!direct) {
+              const int nn = mg / HlWl;
+              const int rr = mg - nn * HlWl;
+              const int a = rr / p.Wl;
+              const int b = rr - a * p.Wl;
+              opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
+            }
+            return p.bs_y[opix * p.ldo + col];
+          });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_sums<BN, WAVES_M>(red, out))
+      p.bs_partial[((size_t)img * p.bs_tiles + p.bs_tile0 + (m0 - img * HlWl) / BM) * p.Ncols + n0 +
+                   tid] = out;
   }
   if (FUSED && p.stats) {   // uniform; the K loop ended on a barrier: the A tiles are free scratch
     constexpr int WAVES_M = BM / WM;
@@ -537,10 +580,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
           const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           o[r] = p.out + (size_t)(m0 + row) * p.ldo + col;
         }
-        store_block16(o, acc[m][n], bv, p.accumulate);
+        if (!FUSED && p.bs_partial) {   // uniform: final values kept for the reductions below
+          if (p.accumulate) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[m][n][r] += bv + *o[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] += bv;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) *o[r] = acc[m][n][r];
+        } else {
+          store_block16(o, acc[m][n], bv, p.accumulate);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        }
       }
+    }
+    if (!FUSED && p.bs_partial) {   // uniform.  `red` is rewritten one tile (>= 3 barriers) later
+      constexpr int WAVES_M = BM / WM;
+      const int img = m0 / HW;
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = wn0 + n * 32 + li;
+        const BwdCoef cf = bwd_coef(p, img, col);
+        const float2 mine = wave_bwd_stats<TM>(
+            cf, p.slope, [&](int m, int r) { return acc[m][n][r]; },
+            [&](int m, int r) {
+              const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              return p.bs_y[(size_t)(m0 + row) * p.ldo + col];
+            });
+        if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+      }
+      float2 out;
+      if (block_col_sums<BN, WAVES_M>(red, out))
+        p.bs_partial[((size_t)img * p.bs_tiles + (m0 - img * HW) / BM) * p.Ncols + tid] = out;
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     }
   }
 }
@@ -550,7 +630,7 @@ int launch_igemm_rf(const IgemmParams& p, int flip, hipStream_t stream, int* sta
   constexpr int LDA = 36;
   constexpr size_t lds = (PW ? (size_t)(2 * (BM + 2) + 9 * BN) * LDA * sizeof(float)
                              : 2 * (size_t)((BM + 2) + 3 * BN) * LDA * sizeof(float)) +
-                         (FUSED ? (size_t)(BM / WM) * BN * sizeof(float2) : 0);
+                         (size_t)(BM / WM) * BN * sizeof(float2);   // statistics scratch
   auto kern = conv_igemm_rf_kernel<BM, BN, WM, WN, PW, FUSED>;
   UNET_SET_DYN_LDS(kern, lds);
   IgemmParams q = p;
@@ -558,6 +638,10 @@ int launch_igemm_rf(const IgemmParams& p, int flip, hipStream_t stream, int* sta
   if (FUSED && stats_px) {
     if (q.stats) { *stats_px = BM; q.stats_tiles = p.Hin * p.Win / BM; }
     else *stats_px = 0;
+  }
+  if (!FUSED) {   // data gradient: stats_px doubles as the BSTATS tile report
+    if (stats_px && q.bs_partial) { *stats_px = BM; q.bs_tiles = p.Hin * p.Win / BM; q.bs_tile0 = 0; }
+    else q.bs_partial = nullptr;
   }
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int ntiles = (int)(M / BM);
@@ -738,6 +822,9 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(const IgemmParams
     const int b = rr - a * p.Wl;
     base[r] = mg < M ? ((size_t)nn * p.Hout + 2 * a) * p.Wout + 2 * b : ~(size_t)0;
   }
+  float s1 = 0.f, s2 = 0.f;
+  BwdCoef cf{};
+  if (p.bs_partial) cf = bwd_coef(p, m0 / HlWl, col);   // uniform; tiles lie inside one image
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float* o[16];
@@ -746,7 +833,35 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(const IgemmParams
       o[r] = base[r] != ~(size_t)0
                  ? p.out + (base[r] + (size_t)(c >> 1) * p.Wout + (c & 1)) * p.ldo + col
                  : nullptr;
-    store_block16(o, acc[c], 0.f, p.accumulate);
+    if (p.bs_partial) {   // uniform: final values (all rows valid here) + the next stage's sums
+      if (p.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] += *o[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) *o[r] = acc[c][r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y = p.bs_y[o[r] - p.out];
+        const float z = fmaf(y, cf.A, cf.B0);
+        const float gz = acc[c][r] * cf.mk * (z > 0.f ? 1.f : p.slope);
+        s1 += gz;
+        s2 = fmaf(gz, (y - cf.mu) * cf.rs, s2);
+      }
+    } else {
+      store_block16(o, acc[c], 0.f, p.accumulate);
+    }
+  }
+  if (p.bs_partial) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    float2* red = reinterpret_cast<float2*>(smem);   // the pipeline ended on a barrier
+    if (lh == 0) red[wave * BN + li] = float2{s1, s2};
+    float2 out;
+    if (block_col_sums<BN, 4>(red, out)) {
+      const int img = m0 / HlWl;
+      p.bs_partial[((size_t)img * p.bs_tiles + (m0 - img * HlWl) / BM) * p.Ncols + n0 + tid] = out;
+    }
   }
 }
 
@@ -774,11 +889,25 @@ static int launch_igemm_fused(IgemmParams p, hipStream_t stream, int* stats_px) 
   return launch_igemm<BM, BN, WM, WN, 32, true>(p, stream);
 }
 
-int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px) {
+// plain gather-GEMM launch; with bs_px (data gradient whose output is final for a layer) the
+// BSTATS epilogue runs where every tile lies inside one image, else *bs_px = 0
+template <int BM, int BN, int WM, int WN>
+static int launch_igemm_bs(IgemmParams p, hipStream_t stream, int* bs_px) {
+  if (bs_px) {
+    const int HlWl = p.Hl * p.Wl;
+    if (p.bs_partial && HlWl % BM == 0) { *bs_px = BM; p.bs_tiles = HlWl / BM * (p.sout * p.sout); }
+    else { *bs_px = 0; p.bs_partial = nullptr; }
+  } else {
+    p.bs_partial = nullptr;
+  }
+  return launch_igemm<BM, BN, WM, WN>(p, stream);
+}
+
+int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int* bs_px) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   if (patch_f32_applicable(p)) {   // conv_patch.hip; 1 = no tile shape fits this launch
-    const int rc = launch_patch_f32_auto(p, stream, stats_px);
+    const int rc = launch_patch_f32_auto(p, stream, stats_px, bs_px);
     if (rc != 1) return rc;
   }
   if (stats_px) {
@@ -788,6 +917,14 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px) {
       return launch_igemm_fused<128, 64, 64, 32>(p, stream, stats_px);
     if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_fused<64, 64, 32, 32>(p, stream, stats_px);
     return launch_igemm_fused<128, 32, 32, 32>(p, stream, stats_px);
+  }
+  if (bs_px) {   // per-class launches of one stride-2 gradient pass bs_tile0 themselves
+    if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
+      return launch_igemm_bs<128, 128, 64, 64>(p, stream, bs_px);
+    if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
+      return launch_igemm_bs<128, 64, 64, 32>(p, stream, bs_px);
+    if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
+    return launch_igemm_bs<128, 32, 32, 32>(p, stream, bs_px);
   }
   // Largest tile that still yields >= 256 workgroups (one per CU); otherwise the
   // small 64x64 tile.
@@ -1064,9 +1201,14 @@ extern "C" int unet_conv3x3_fwd_bf16x3(const float* x0, int C0, const float* x1,
 static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total, int ci_offset,
                                  float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
                                  int accumulate, int prec, hipStream_t stream,
-                                 const uint16_t* wd3 = nullptr, int b16 = 0) {
+                                 const uint16_t* wd3 = nullptr, int b16 = 0,
+                                 unet_bwd_stats* bs = nullptr) {
   // b16: dy and dx are bf16 tensors (mixed-precision pipeline; prec is then 1)
   const long long es = b16 ? 2 : 4;
+  if (bs) bs->tiles_out = 0;
+  const bool use_bs = bs && prec == 0 && !b16 && bs->y && bs->mean && bs->rstd && bs->gamma &&
+                      bs->beta && bs->partial &&
+                      bs->partial_bytes >= (size_t)N * ceil_div(H * W, 64) * Ccols * sizeof(float2);
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
   UNET_REQUIRE(prec != 3 || wd3, "conv3x3_bwd_data_bf16x3: the pre-split weight planes are null");
   UNET_REQUIRE(stride == 1 || stride == 2, "conv3x3_bwd_data: stride %d unsupported", stride);
@@ -1082,7 +1224,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   {  // batch chunks keep dy inside the 2 GiB buffer-descriptor range
     const int nmax = batch_chunk(N, (long long)Ho * Wo * Cout * es);
     UNET_REQUIRE(nmax >= 1, "conv3x3_bwd_data: one image exceeds the 2 GiB buffer-descriptor range");
-    if (nmax < N) {
+    if (nmax < N) {   // chunked batches have no single tile layout: no BSTATS epilogue
       for (int nb = 0; nb < N; nb += nmax) {
         const int n = N - nb < nmax ? N - nb : nmax;
         const int rc = conv3x3_bwd_data_impl(
@@ -1110,6 +1252,12 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   p.w3_plane = 9 * Cout * Cin_total;
   p.w3_bytes = (unsigned)((long long)3 * p.w3_plane * 2);
   p.sin = 1;
+  int bs_px = 0;
+  if (use_bs) {
+    p.bs_y = bs->y; p.bs_mean = bs->mean; p.bs_rstd = bs->rstd; p.bs_gamma = bs->gamma;
+    p.bs_beta = bs->beta; p.bs_mask = bs->mask; p.slope = bs->slope;
+    p.bs_partial = reinterpret_cast<float2*>(bs->partial);
+  }
   if (stride == 1) {
     p.Hl = H; p.Wl = W; p.sout = 1; p.py = p.px = 0;
     p.ntaps = 9;
@@ -1118,10 +1266,14 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     if (b16) return dispatch_igemm_b16(p, stream, nullptr);
     if (prec == 1) return dispatch_igemm_bf16(p, stream);
     if (prec == 3) return dispatch_igemm_split(p, stream);
+    int rc;
     if (rf_applicable(p) && (Cout == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
-      return (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream)
-                          : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream);
-    return dispatch_igemm(p, stream);
+      rc = (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream, &bs_px)
+                        : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream, &bs_px);
+    else
+      rc = dispatch_igemm(p, stream, nullptr, use_bs ? &bs_px : nullptr);
+    if (rc == UNET_OK && use_bs && bs_px > 0) bs->tiles_out = H * W / bs_px;
+    return rc;
   }
   // stride 2: dx[2a+py][2b+px] = sum over ky with (py+1-ky) even of dy[a + (py+1-ky)/2][..]
   p.Hl = H / 2; p.Wl = W / 2; p.sout = 2;
@@ -1129,8 +1281,16 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
     // one launch for all four parity classes when there are enough tiles to fill the chip
     const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
-    if (prec != 1 && !b16 && !per_class && tiles >= 512) { p.py = p.px = 0; p.ntaps = 9; return launch_dgrad_s2(p, stream); }
+    if (prec != 1 && !b16 && !per_class && tiles >= 512) {
+      p.py = p.px = 0; p.ntaps = 9;
+      if (use_bs && (p.Hl * p.Wl) % 128 == 0) p.bs_tiles = p.Hl * p.Wl / 128;
+      else p.bs_partial = nullptr;
+      const int rc = launch_dgrad_s2(p, stream);
+      if (rc == UNET_OK && p.bs_partial) bs->tiles_out = p.bs_tiles;   // 512 output pixels each
+      return rc;
+    }
   }
+  int class_tiles = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       p.py = py; p.px = px;
@@ -1145,11 +1305,19 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
         }
       }
       p.ntaps = nt;
+      int bpx = 0;
+      p.bs_tile0 = (py * 2 + px) * (class_tiles > 0 ? class_tiles : 0);
       int rc = b16 ? dispatch_igemm_b16(p, stream, nullptr)
                    : prec == 1 ? dispatch_igemm_bf16(p, stream)
-                   : (prec == 3 ? dispatch_igemm_split(p, stream) : dispatch_igemm(p, stream));
+                   : (prec == 3 ? dispatch_igemm_split(p, stream)
+                                : dispatch_igemm(p, stream, nullptr, use_bs ? &bpx : nullptr));
       if (rc != UNET_OK) return rc;
+      if (use_bs) {
+        if (bpx == 0) { p.bs_partial = nullptr; class_tiles = -1; }   // no epilogue: give up on it
+        else if (class_tiles == 0) class_tiles = p.Hl * p.Wl / bpx;
+      }
     }
+  if (use_bs && class_tiles > 0 && p.bs_partial) bs->tiles_out = 4 * class_tiles;
   return UNET_OK;
 }
 
@@ -1167,6 +1335,14 @@ extern "C" int unet_conv3x3_bwd_data_bf16(const float* dy, const float* wd, int 
                                           unet_stream_t stream) {
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
                                accumulate, 1, (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_bwd_data_bs(const float* dy, const float* wd, int Cin_total,
+                                        int ci_offset, float* dx, int N, int H, int W, int Cout,
+                                        int Ccols, int stride, int accumulate, unet_bwd_stats* bs,
+                                        unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
+                               accumulate, 0, (hipStream_t)stream, nullptr, 0, bs);
 }
 
 // dy and dx are bf16 tensors, bf16 matrix cores (mixed-precision pipeline)
@@ -1472,7 +1648,16 @@ static int conv_in_stats_finalize_impl(const float* y, void* workspace, size_t w
 // ---------------------------------------------------------------------------
 static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
                                     float* g, int N, int h, int w, int Cout, int Ccols,
-                                    int accumulate, unet_stream_t stream, int b16);
+                                    int accumulate, unet_stream_t stream, int b16,
+                                    unet_bwd_stats* bs = nullptr);
+
+extern "C" int unet_conv3x3_up_bwd_data_bs(const float* D, const float* wd, int Cin_total,
+                                           int ci_offset, float* g, int N, int h, int w, int Cout,
+                                           int Ccols, int accumulate, unet_bwd_stats* bs,
+                                           unet_stream_t stream) {
+  return conv3x3_up_bwd_data_impl(D, wd, Cin_total, ci_offset, g, N, h, w, Cout, Ccols, accumulate,
+                                  stream, 0, bs);
+}
 
 extern "C" int unet_conv3x3_up_bwd_data(const float* D, const float* wd, int Cin_total,
                                         int ci_offset, float* g, int N, int h, int w, int Cout,
@@ -1492,8 +1677,13 @@ extern "C" int unet_conv3x3_up_bwd_data_b16(const uint16_t* D, const float* wd, 
 
 static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
                                     float* g, int N, int h, int w, int Cout, int Ccols,
-                                    int accumulate, unet_stream_t stream, int b16) {
+                                    int accumulate, unet_stream_t stream, int b16,
+                                    unet_bwd_stats* bs) {
   const long long es = b16 ? 2 : 4;
+  if (bs) bs->tiles_out = 0;
+  const bool use_bs = bs && !b16 && bs->y && bs->mean && bs->rstd && bs->gamma && bs->beta &&
+                      bs->partial &&
+                      bs->partial_bytes >= (size_t)N * ceil_div(h * w, 64) * Ccols * sizeof(float2);
   UNET_REQUIRE(D && wd && g, "conv3x3_up_bwd_data: null pointer");
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Ccols > 0 && Ccols % 32 == 0 && ci_offset >= 0 &&
                    ci_offset + Ccols <= Cin_total && N > 0 && h > 0 && w > 0,
@@ -1531,7 +1721,15 @@ static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_tot
   p.ntaps = 9; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
   for (int t = 0; t < 9; ++t) set_tap(p, t, 0, 0, t);
   if (b16) return dispatch_igemm_b16(p, (hipStream_t)stream, nullptr);
-  return dispatch_igemm(p, (hipStream_t)stream);
+  int bs_px = 0;
+  if (use_bs) {
+    p.bs_y = bs->y; p.bs_mean = bs->mean; p.bs_rstd = bs->rstd; p.bs_gamma = bs->gamma;
+    p.bs_beta = bs->beta; p.bs_mask = bs->mask; p.slope = bs->slope;
+    p.bs_partial = reinterpret_cast<float2*>(bs->partial);
+  }
+  const int rc = dispatch_igemm(p, (hipStream_t)stream, nullptr, use_bs ? &bs_px : nullptr);
+  if (rc == UNET_OK && use_bs && bs_px > 0) bs->tiles_out = h * w / bs_px;
+  return rc;
 }
 
 // RGB stem straight from the dataset's uint8 HWC image: normalisation fused into the loader

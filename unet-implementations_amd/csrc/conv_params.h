@@ -51,6 +51,20 @@ struct IgemmParams {
   // low-resolution data gradient of conv3x3(upsample2x(.)) stored as 9*Cout channels per pixel.
   int tap_cstride;
   int src0_pitch;
+  // BSTATS (data-gradient instantiations): the output g = dL/da_l of this launch is FINAL for
+  // layer l, so the epilogue also emits the two reductions of that layer's InstanceNorm +
+  // LeakyReLU + dropout backward (what in_bwd_reduce_kernel would read g and y again for):
+  //   S1 = sum gz,  S2 = sum gz * xhat,   gz = g * mask * lrelu'(z),  z = y * A + B0,
+  // per (image, tile, column) into bs_partial[(n * bs_tiles + tile) * Ncols + col].
+  const float* bs_y;       // raw conv output y_l, same shape as `out`
+  const float* bs_mean;    // [N][Ncols]
+  const float* bs_rstd;    // [N][Ncols]
+  const float* bs_gamma;   // [Ncols]
+  const float* bs_beta;    // [Ncols]
+  const float* bs_mask;    // [N][Ncols] or nullptr
+  float2* bs_partial;
+  int bs_tiles;            // tiles per image
+  int bs_tile0;            // first tile index of this launch (per-class stride-2 launches)
 };
 
 // The kernels address their operands through buffer descriptors (free zero padding), whose
@@ -139,6 +153,50 @@ __device__ __forceinline__ float2 wave_col_stats(F&& val) {
   return float2{mean, m2};
 }
 
+// Per-lane part of the BSTATS epilogue for one output column: `g(m, r)` = final gradient
+// values this lane holds, `yv(m, r)` = the raw conv output at the same positions.  Returns the
+// wave's (S1, S2) for the column (both 32-lane halves summed).
+struct BwdCoef { float A, B0, mu, rs, mk; };
+__device__ __forceinline__ BwdCoef bwd_coef(const IgemmParams& p, int n, int col) {
+  const size_t i = (size_t)n * p.Ncols + col;
+  BwdCoef c;
+  c.mu = p.bs_mean[i];
+  c.rs = p.bs_rstd[i];
+  c.A = p.bs_gamma[col] * c.rs;
+  c.B0 = p.bs_beta[col] - c.mu * c.A;      // same expression as the forward / in_bwd kernels
+  c.mk = p.bs_mask ? p.bs_mask[i] : 1.f;
+  return c;
+}
+template <int TM, typename G, typename Y>
+__device__ __forceinline__ float2 wave_bwd_stats(const BwdCoef c, float slope, G&& g, Y&& yv) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float y = yv(m, r);
+      const float z = fmaf(y, c.A, c.B0);
+      const float gz = g(m, r) * c.mk * (z > 0.f ? 1.f : slope);
+      s1 += gz;
+      s2 = fmaf(gz, (y - c.mu) * c.rs, s2);
+    }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  return float2{s1, s2};
+}
+// block-level sum of the waves' (S1, S2) per column (fixed order); thread c < BN gets the result
+template <int BN, int WAVES_M>
+__device__ __forceinline__ bool block_col_sums(float2* red, float2& out) {
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c >= BN) return false;
+  float a = red[c].x, b = red[c].y;
+#pragma unroll
+  for (int k = 1; k < WAVES_M; ++k) { a += red[k * BN + c].x; b += red[k * BN + c].y; }
+  out = float2{a, b};
+  return true;
+}
+
 // Block-level finish of the statistics epilogue: `mine` = this wave's summary (32*TM pixels) of
 // column `col_local` (0..BN-1); waves_m waves cover different pixels of the same columns.  red
 // = LDS scratch of waves_m * BN float2 that no other wave is still reading.  Thread c < BN
@@ -167,12 +225,12 @@ __device__ __forceinline__ bool block_col_stats(float2* red, int wave_m, int col
 // ---- dispatchers implemented in the other translation units -------------------------------
 bool patch_f32_applicable(const IgemmParams& p);              // conv_patch.hip
 int launch_patch_f32_auto(const IgemmParams& p, hipStream_t stream,    // returns 1 if no tile fits
-                          int* stats_px = nullptr);
+                          int* stats_px = nullptr, int* bs_px = nullptr);
 int launch_patch_up_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
 int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream);
 bool patch_split_applicable(const IgemmParams& p);
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream,           // conv_igemm.hip
-                   int* stats_px = nullptr);
+                   int* stats_px = nullptr, int* bs_px = nullptr);
 int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream);     // conv_lowp.hip
 int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px);  // bf16 storage
 int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream);    // conv_lowp.hip

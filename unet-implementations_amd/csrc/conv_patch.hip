@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
 // per chunk; zero padding stays zero).  STATS: the epilogue emits the tile's per-column
 // (mean, M2) for the InstanceNorm that follows this convolution.
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParams p) {
   constexpr int BK = 32, LDA = BK + 4;
   constexpr int TW = 32, PW = TW + 2;
@@ -441,19 +441,38 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
       float* o = p.out + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
-      if (p.accumulate) {
+      if (p.accumulate) {        // uniform: all 16 reads in flight before the first add
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv + old[r];
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv + old[r];
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv;
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r];
     }
+  }
+  if (BSTATS && p.bs_partial) {   // uniform: reductions of the NEXT backward stage (IgemmParams)
+    constexpr int WAVES_M = 4 / WAVES_N;
+    float2* red = reinterpret_cast<float2*>(Ps);   // the K loop ended on a barrier
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const int col = n0 + wn0 + nb * 32 + li;
+      const BwdCoef cf = bwd_coef(p, n, col);
+      const float* yb = p.bs_y + (((size_t)n * H + (y0 + wrow0)) * W + x0 + 4 * lh) * p.ldo + col;
+      const float2 mine = wave_bwd_stats<TM>(
+          cf, p.slope, [&](int m, int r) { return acc[m][nb][r]; },
+          [&](int m, int r) {
+            return yb[((size_t)m * W + (r & 3) + 8 * (r >> 2)) * p.ldo];
+          });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_sums<BN, WAVES_M>(red, out))
+      p.bs_partial[((size_t)n * p.bs_tiles + p.bs_tile0 + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
   }
   if (STATS && p.stats) {   // uniform
     // the K loop ended on a barrier: the patch area is free scratch
@@ -462,9 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
     static_assert(WAVES_M * BN * 2 <= PPIX * LDA, "stats scratch fits in the patch area");
 #pragma unroll
     for (int nb = 0; nb < TN; ++nb) {
-      const int col = n0 + wn0 + nb * 32 + li;
-      const float bv = p.bias ? p.bias[col] : 0.f;
-      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r] + bv; });
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r]; });  // acc already holds + bias
       if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
     }
     float2 out;
@@ -787,10 +804,10 @@ int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false>
 int launch_patch_f32(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = ((size_t)((TH + 2) * 34) * 36 + 2 * (size_t)BN * 36) * sizeof(float);
-  auto kern = conv_patch_f32_kernel<BN, WM, WN, TH, ACT, STATS>;
+  auto kern = conv_patch_f32_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS>;
   UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
@@ -821,12 +838,30 @@ bool patch_f32_applicable(const IgemmParams& p) {
 // shape fits (too few tiles): the caller falls back to the gather-GEMM.
 // stats_px != nullptr selects the fused-layer instantiation (activation on load, statistics
 // epilogue into p.stats) and receives the number of pixels per statistics tile.
-int launch_patch_f32_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+// bs_px != nullptr (data gradient whose output is final for a layer): the BSTATS epilogue
+// (p.bs_*) runs and *bs_px receives the pixels per reduction tile.
+int launch_patch_f32_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px, int* bs_px) {
   IgemmParams p = p0;
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   const long long mt = M / 128;
   const bool fused = stats_px != nullptr;
+  if (!fused && bs_px && p.bs_partial) {
+    p.bs_tile0 = 0;
+    if (nc % 128 == 0 && mt * (nc / 128) >= 512) {
+      *bs_px = 128; p.bs_tiles = p.Hin * p.Win / 128;
+      return launch_patch_f32<128, 64, 64, 4, false, false, true>(p, stream);
+    }
+    if (nc % 64 == 0 && mt * (nc / 64) >= 512) {
+      *bs_px = 128; p.bs_tiles = p.Hin * p.Win / 128;
+      return launch_patch_f32<64, 64, 32, 4, false, false, true>(p, stream);
+    }
+    if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 512) {
+      *bs_px = 256; p.bs_tiles = p.Hin * p.Win / 256;
+      return launch_patch_f32<32, 64, 32, 8, false, false, true>(p, stream);
+    }
+    return 1;
+  }
   if (nc % 128 == 0 && mt * (nc / 128) >= 512) {
     if (!fused) return launch_patch_f32<128, 64, 64, 4>(p, stream);
     *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;

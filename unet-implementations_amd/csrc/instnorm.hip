@@ -563,7 +563,22 @@ template <typename TS>
 static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* mask, float slope,
                              TS* dy, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                             size_t workspace_bytes, int N, int HW, int C, hipStream_t stream);
+                             size_t workspace_bytes, int N, int HW, int C, hipStream_t stream,
+                             const float2* ext_partial = nullptr, int ext_tiles = 0);
+
+extern "C" int unet_instnorm_lrelu_drop_bwd_partials(const float* ga, const float* y,
+                                                     const float* mean, const float* rstd,
+                                                     const float* gamma, const float* beta,
+                                                     const float* mask, float slope, float* dy,
+                                                     float* dgamma, float* dbeta, float* dbias,
+                                                     const void* partial, int tiles,
+                                                     void* workspace, size_t workspace_bytes,
+                                                     int N, int HW, int C, unet_stream_t stream) {
+  UNET_REQUIRE(partial && tiles > 0, "instnorm_lrelu_drop_bwd_partials: no summaries");
+  return instnorm_bwd_impl<float>(ga, y, mean, rstd, gamma, beta, mask, slope, dy, dgamma, dbeta,
+                                  dbias, workspace, workspace_bytes, N, HW, C, (hipStream_t)stream,
+                                  reinterpret_cast<const float2*>(partial), tiles);
+}
 
 extern "C" int unet_instnorm_lrelu_drop_bwd(const float* ga, const float* y, const float* mean,
                                             const float* rstd, const float* gamma,
@@ -593,7 +608,8 @@ template <typename TS>
 static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* mask, float slope,
                              TS* dy, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                             size_t workspace_bytes, int N, int HW, int C, hipStream_t stream) {
+                             size_t workspace_bytes, int N, int HW, int C, hipStream_t stream,
+                             const float2* ext_partial, int ext_tiles) {
   UNET_REQUIRE(ga && y && mean && rstd && gamma && beta && dy && workspace,
                "instnorm_lrelu_drop_bwd: null pointer");
   UNET_REQUIRE(shape_ok(N, HW, C) && kThreads % (C / 4) == 0,
@@ -615,11 +631,16 @@ static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const
   ws += align_up((size_t)N * split * C * sizeof(float), 256);
   float* dbstage = reinterpret_cast<float*>(ws);
   const size_t lds2 = (size_t)groups * 2 * C * sizeof(float);
-  hipLaunchKernelGGL(in_bwd_reduce_kernel<TS>, dim3(split, N), dim3(kThreads), lds2, stream, ga, y,
-                     mean, rstd, gamma, beta, mask, slope, partial, HW, C, split);
-  UNET_CHECK_LAUNCH("in_bwd_reduce");
-  hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
-                     partial, coef, sums, HW, C, split);
+  if (ext_partial) {   // the producer of ga already summarised the reductions per tile
+    hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
+                       ext_partial, coef, sums, HW, C, ext_tiles);
+  } else {
+    hipLaunchKernelGGL(in_bwd_reduce_kernel<TS>, dim3(split, N), dim3(kThreads), lds2, stream, ga,
+                       y, mean, rstd, gamma, beta, mask, slope, partial, HW, C, split);
+    UNET_CHECK_LAUNCH("in_bwd_reduce");
+    hipLaunchKernelGGL(in_bwd_finalize1_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0, stream,
+                       partial, coef, sums, HW, C, split);
+  }
   UNET_CHECK_LAUNCH("in_bwd_finalize1");
   const size_t lds1 = (size_t)groups * C * sizeof(float);
   // block (0, 0) of the apply launch also emits dgamma / dbeta / dbias from `sums`

@@ -8,7 +8,7 @@ import torch
 
 import ctypes
 
-from ._lib import ActSrc, check, lib
+from ._lib import ActSrc, BwdStats, check, lib
 
 
 def _stream():
@@ -210,9 +210,30 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None, bf16=False, wf3=None):
     return y
 
 
+class NextNorm:
+    """Layer l as seen by the producer of g = dL/da_l: raw output y, statistics, affine
+    parameters, dropout mask.  A data gradient whose output is FINAL for layer l takes one and
+    leaves the per-tile reductions of l's InstanceNorm backward in `.partial` / `.tiles`
+    (tiles == 0: that launch had no such epilogue)."""
+
+    __slots__ = ("y", "st", "gamma", "beta", "mask", "slope", "partial", "tiles")
+
+    def __init__(self, y, st, gamma, beta, mask, slope):
+        self.y, self.st, self.gamma, self.beta, self.mask, self.slope = y, st, gamma, beta, mask, slope
+        self.partial, self.tiles = None, 0
+
+    def c_struct(self):
+        N, H, W, C = self.y.shape
+        nbytes = N * ((H * W + 63) // 64) * C * 8
+        self.partial = torch.empty(nbytes, dtype=torch.uint8, device=self.y.device)
+        return BwdStats(_ptr(self.y), _ptr(self.st[0]), _ptr(self.st[1]), _ptr(self.gamma),
+                        _ptr(self.beta), _ptr(self.mask), self.slope, _ptr(self.partial), nbytes, 0)
+
+
 def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False,
-                     bf16=False, wd3=None):
-    """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols)."""
+                     bf16=False, wd3=None, nxt=None):
+    """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols).
+    nxt (NextNorm, fp32 path): dx is final for that layer - also emit its backward reductions."""
     N, Ho, Wo, Cout = dy.shape
     cin_total = wd.shape[1]
     assert wd.shape[0] == 9 and wd.shape[2] == Cout
@@ -229,8 +250,18 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
         return dx
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
-    t0 = _timer.begin() if _timer is not None else None
     pr = _prec(bf16)
+    if nxt is not None and pr == 0:
+        bs = nxt.c_struct()
+        t0 = _timer.begin() if _timer is not None else None
+        check(lib().unet_conv3x3_bwd_data_bs(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N,
+                                             H, W, Cout, ccols, stride, 1 if accumulate else 0,
+                                             ctypes.byref(bs), _stream()))
+        nxt.tiles = bs.tiles_out
+        if t0 is not None:
+            _timer.end("conv_igemm", 2.0 * N * Ho * Wo * 9 * ccols * Cout, 1, t0)
+        return dx
+    t0 = _timer.begin() if _timer is not None else None
     fn = getattr(lib(), "unet_conv3x3_bwd_data" + _SUFFIX[pr])
     if pr == 3:
         if wd3 is None:
@@ -330,11 +361,21 @@ def instnorm_lrelu_drop_fwd(y, alpha, beta2, mask, slope, out=None):
 
 
 def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma, dbeta, dbias,
-                            out=None):
-    """Returns dy (in place over `ga` unless `out` is given)."""
+                            out=None, partials=None):
+    """Returns dy (in place over `ga` unless `out` is given).  partials = (buffer, tiles): the
+    reductions were already summarised per tile by the producer of ga (NextNorm)."""
     N, H, W, C = y.shape
     dy = ga if out is None else out
     ws = _ws(lib().unet_instnorm_workspace_bytes(N, H * W, C), y)
+    if partials is not None and not _is_b16(y):
+        t0 = _timer.begin() if _timer is not None else None
+        check(lib().unet_instnorm_lrelu_drop_bwd_partials(
+            _ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(mask), slope,
+            _ptr(dy), _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(partials[0]), partials[1],
+            _ptr(ws), ws.numel(), N, H * W, C, _stream()))
+        if t0 is not None:   # apply pass only: ga + y in, dy out
+            _timer.end("instnorm_bwd", 0.0, 2, t0, nbytes=4.0 * 3 * y.numel())
+        return dy
     fn = lib().unet_instnorm_lrelu_drop_bwd_b16 if _is_b16(y) else lib().unet_instnorm_lrelu_drop_bwd
     if _is_b16(y) != _is_b16(ga):
         raise TypeError("ga and y must share their storage type")
@@ -551,8 +592,9 @@ def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
     return dw_oihw
 
 
-def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False):
-    """g[N, h, w, ccols] (+)= dL/d(low-res operand) of conv3x3(upsample2x(.)) from D."""
+def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False, nxt=None):
+    """g[N, h, w, ccols] (+)= dL/d(low-res operand) of conv3x3(upsample2x(.)) from D.
+    nxt (NextNorm): g is final for that layer - also emit its backward reductions."""
     N, h, w, C9 = D.shape
     Cout = C9 // 9
     cin_total = wd.shape[1]
@@ -561,8 +603,15 @@ def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False):
     g = out if out is not None else (_b16 if b16 else _f32)((N, h, w, ccols), D)
     fn = lib().unet_conv3x3_up_bwd_data_b16 if b16 else lib().unet_conv3x3_up_bwd_data
     t0 = _timer.begin() if _timer is not None else None
-    check(fn(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,
-             1 if accumulate else 0, _stream()))
+    if nxt is not None and not b16:
+        bs = nxt.c_struct()
+        check(lib().unet_conv3x3_up_bwd_data_bs(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N,
+                                                h, w, Cout, ccols, 1 if accumulate else 0,
+                                                ctypes.byref(bs), _stream()))
+        nxt.tiles = bs.tiles_out
+    else:
+        check(fn(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,
+                 1 if accumulate else 0, _stream()))
     if t0 is not None:   # algorithmic FLOPs: the 3x3 data gradient on the up-sampled grid
         _timer.end("conv_igemm_bf16" if b16 else "conv_igemm",
                    2.0 * N * 4 * h * w * 9 * ccols * Cout, 1, t0,

@@ -593,6 +593,7 @@ class _UNetFunction(torch.autograd.Function):
         touched = set()      # ids of parameters whose gradient this backward produced
         head = model.segmentation_output
         fused, slope = ctx.fused, ctx.slope
+        b16_bwd = ctx.bf16 == "bf16"
         hw = head.weight.detach().view(head.out_channels, -1)
         if fused:
             g = ops.head1x1_in_bwd(ctx.last, slope, dlogits, hw,
@@ -637,9 +638,21 @@ class _UNetFunction(torch.autograd.Function):
             dbg = getattr(model, "_debug_capture", None)
             if dbg is not None:
                 dbg.append((l.name, "ga", g_a.clone()))
+            nn_ = rec.pop("nxt", None)     # reductions left by the kernel that produced g_a
             dy = ops.instnorm_lrelu_drop_bwd(g_a, rec["y"], st[0], st[1], l.norm.weight.detach(),
                                              l.norm.bias.detach(), rec["mask"], l.slope,
-                                             gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias))
+                                             gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias),
+                                             partials=(nn_.partial, nn_.tiles)
+                                             if nn_ is not None and nn_.tiles > 0 else None)
+            # dx0 of this layer is the final gradient of the previous layer's output (the skip
+            # halves dx1 are accumulated into later, by the encoder): its producer also emits
+            # that layer's InstanceNorm-backward reductions
+            nxt = None
+            if fused and not b16_bwd and need_dx and i > 0:
+                pr_ = saved[i - 1]
+                pl_ = pr_["layer"]
+                nxt = ops.NextNorm(pr_["y"], pr_["st"], pl_.norm.weight.detach(),
+                                   pl_.norm.bias.detach(), pr_["mask"], pl_.slope)
             if dbg is not None:
                 dbg.append((l.name, "dy", dy.clone()))
             x0, x1 = rec["x0"], rec["x1"]
@@ -654,7 +667,9 @@ class _UNetFunction(torch.autograd.Function):
                 if want_dw:
                     ops.conv3x3_up_bwd_weight(low, slope, D, dw, 0)
                     ops.conv_in_bwd_weight(x1, slope, dy, dw, C0, 3, 1)
-                g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0) if need_dx else None
+                g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0, nxt=nxt) if need_dx else None
+                if nxt is not None:
+                    saved[i - 1]["nxt"] = nxt
                 dx1 = None
                 if need_dx1:
                     dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], x1.shape[1],
@@ -681,7 +696,10 @@ class _UNetFunction(torch.autograd.Function):
             N, H, W, C0 = x0.shape
             if need_dx:
                 dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
-                                           accumulate=dx0_acc, bf16=ctx.bf16, wd3=rec["wd3"])
+                                           accumulate=dx0_acc, bf16=ctx.bf16, wd3=rec["wd3"],
+                                           nxt=nxt)
+                if nxt is not None:
+                    saved[i - 1]["nxt"] = nxt
             if x1 is not None and need_dx1:
                 dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], H, W, l.stride,
                                            bf16=ctx.bf16, wd3=rec["wd3"])
