@@ -445,3 +445,71 @@ def test_conv_up_in_fwd(ua, case):
     y2, _ = ua.ops.conv_in_fwd(up, s_skip, SLOPE, wf, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV),
                                1e-5, None)
     check(y, y2, 2e-6, "fused vs materialised up-sampling")
+
+
+# --------------------------------------------------------------------------- reductions from the producer
+def _next_norm(ua, N, C, H, W, seed):
+    """A layer l as the producer of dL/da_l sees it: raw output, statistics, affine, mask."""
+    y = to_nhwc(rnd(N, C, H, W, seed=seed) * 1.5 + 0.3)
+    gamma, beta = (rnd(C, seed=seed + 1) * 0.2 + 1.0).to(DEV), (rnd(C, seed=seed + 2) * 0.2).to(DEV)
+    st = ua.ops.instnorm_stats(y, gamma, beta, 1e-5)
+    mask = ((torch.rand(N, C, generator=torch.Generator().manual_seed(seed + 3)) < 0.8).float()
+            / 0.8).to(DEV)
+    return y, st, gamma, beta, mask
+
+
+def _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask):
+    """InstanceNorm backward from the producer's summaries vs the stand-alone reduction pass."""
+    C = y.shape[3]
+    outs = []
+    for partials in ((nn.partial, nn.tiles), None):
+        dg, db, dbias = (torch.empty(C, device=DEV) for _ in range(3))
+        dy = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), y, st[0], st[1], gamma, beta, mask, SLOPE, dg,
+                                            db, dbias, partials=partials)
+        outs.append((dy, dg, db))
+    for a, b, what in zip(outs[0], outs[1], ("dy", "dgamma", "dbeta")):
+        check(a, b, 2e-5, what + " (producer summaries vs reduction pass)")
+
+
+BS_DGRAD = [  # (N, H, W, Cout, Ccols, stride, accumulate): H, W = size of dx
+    (1, 256, 256, 32, 64, 1, False),     # patch-staged 64 columns
+    (1, 256, 256, 64, 128, 1, True),     # patch-staged 128 columns, accumulate (skip gradient)
+    (1, 128, 128, 32, 32, 1, False),     # row-fused, K = 32
+    (2, 16, 16, 64, 64, 1, False),       # gather-GEMM 64x64
+    (2, 256, 256, 32, 64, 2, True),      # stride-2 one-launch kernel, accumulate
+    (2, 32, 32, 64, 64, 2, False),       # stride-2 per-class launches
+    (3, 4, 4, 32, 32, 1, False),         # tiles span images: no epilogue, tiles == 0
+]
+
+
+@pytest.mark.parametrize("case", BS_DGRAD)
+def test_data_gradient_emits_next_norm_reductions(ua, case):
+    N, H, W, Cout, Ccols, stride, acc = case
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = to_nhwc(rnd(N, Cout, Ho, Wo, seed=1))
+    w = rnd(Cout, Ccols, 3, 3, seed=2, scale=0.1)
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    y, st, gamma, beta, mask = _next_norm(ua, N, Ccols, H, W, 10)
+    base = to_nhwc(rnd(N, Ccols, H, W, seed=3)) if acc else None
+    ref = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, stride,
+                                  out=base.clone() if acc else None, accumulate=acc)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, stride, out=base.clone() if acc else None,
+                                accumulate=acc, nxt=nn)
+    assert torch.equal(g, ref)
+    if H * W < 64:
+        assert nn.tiles == 0
+        return
+    assert nn.tiles > 0
+    _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
+
+
+def test_low_resolution_gradient_emits_reductions(ua):
+    N, h, w, Cx, Cout = 2, 16, 32, 64, 32
+    D = ua.ops.upsample2x_bwd_taps(to_nhwc(rnd(N, Cout, 2 * h, 2 * w, seed=1)))
+    _, wd = ua.ops.pack_conv3x3_weights(rnd(Cout, Cx, 3, 3, seed=2, scale=0.1).to(DEV))
+    y, st, gamma, beta, mask = _next_norm(ua, N, Cx, h, w, 20)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx, nxt=nn)
+    assert torch.equal(g, ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx)) and nn.tiles > 0
+    _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
