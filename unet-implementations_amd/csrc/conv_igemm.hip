@@ -29,8 +29,13 @@ namespace {
 // p.stats the epilogue emits the tile's per-column (mean, M2); the statistics need every tile
 // inside ONE image (Hl*Wl % BM == 0, checked by the dispatcher), the activation does not (each
 // staged row carries its own image's coefficients).
-template <int BM, int BN, int WM, int WN, int BK, bool FUSED = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p) {
+//
+// KG > 1 (deep layers: M = N*16*16 rows leave one 64x64 tile per CU, and a lone 4-wave block
+// cannot hide the load latency of its K loop): KG groups of four waves share the tile, group g
+// runs K steps [g, g+1) * KS / KG through its own pair of LDS stages, and the partial
+// accumulators are summed through LDS in group order before the common epilogue.
+template <int BM, int BN, int WM, int WN, int BK, bool FUSED = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int LDA = BK + 4;  // 144-B (80-B) rows: conflict-free ds_read_b128 across 16 rows
   constexpr int SEGS = BK / 4;         // 16-B segments per tile row
   constexpr int ROWS = 256 / SEGS;     // tile rows covered by one loader pass
@@ -41,16 +46,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   constexpr int B_PASSES = BN / ROWS;
   constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;
-  float* Bs = smem + 2 * A_TILE;
+  // K group: uniform per wave, kept in an SGPR so the K-step bookkeeping stays scalar
+  const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  const bool lead = KG == 1 || grp == 0;
+  float* As = smem + grp * 2 * (A_TILE + B_TILE);
+  float* Bs = As + 2 * A_TILE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
   const int tiles_n = p.Ncols / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  if (KG > 1 && p.n_group) {   // column groups outermost (tiles_n % n_group == 0)
+    const int tiles_m = gridDim.x / tiles_n;
+    const int per_group = tiles_m * p.n_group;
+    const int ng = bid / per_group, r = bid - ng * per_group;
+    tm = r / p.n_group;
+    tn = ng * p.n_group + (r - tm * p.n_group);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int HlWl = p.Hl * p.Wl;
   const int M = p.N * HlWl;
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const int KS = p.ntaps * (Ktot / BK);
+  const int KS = p.ntaps * (Ktot / BK) / KG;   // K steps of this group (the launcher checks % KG)
 
   // FUSED: coefficients of this thread's four channels per staged row, in-image flags
   constexpr int CP = FUSED ? A_PASSES : 1;
@@ -168,6 +183,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   };
 
   int t_next = 0, chunk_next = 0;
+  if (KG > 1) {   // tap-fastest order: step = chunk * ntaps + t
+    chunk_next = grp * KS / p.ntaps;
+    t_next = grp * KS - chunk_next * p.ntaps;
+  }
   auto advance = [&](bool on) {  // branch-free: keeps the K step a single basic block
     const int tn = t_next + 1;
     const bool wrap = tn == p.ntaps;
@@ -222,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
 #ifdef UNET_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    store_tiles(buf ^ 1);
+    // FUSED: the activation arithmetic on the staged rows must not drift above the MFMAs (it
+    // would wait for this step's buffer loads before the matrix work that is meant to hide them)
+    if (!FUSED) store_tiles(buf ^ 1);
     // Pin the software pipeline (hipcc otherwise sinks every read to just before its first
     // use): fragment reads run one k-group ahead of the MFMAs, the next tile's buffer loads
     // issue behind the first MFMA group, the LDS writes of the staged tile come last.
@@ -235,8 +256,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
       if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
+    if (FUSED) {
+      __builtin_amdgcn_sched_barrier(0);
+      store_tiles(buf ^ 1);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
+    }
     __syncthreads();
+  }
+
+  // the K loop ended on a barrier: every LDS stage is free scratch from here on
+  float* scratch = smem;
+  if (KG > 1) {   // partial sums of groups 1.. in [group][wave][register][lane] order
+    constexpr int PART = 256 * 16 * TM * TN;
+    static_assert((KG - 1) * PART + 2 * (BM / WM) * BN <= KG * 2 * (A_TILE + B_TILE),
+                  "partial sums + reduction scratch fit in the stages");
+    if (!lead) {
+      float* dst = smem + (grp - 1) * PART + wave * 64 * 16 * TM * TN + lane;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((m * TN + n) * 16 + r) * 64] = acc[m][n][r];
+    }
+    __syncthreads();
+    if (lead) {
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float* src = smem + (g - 1) * PART + wave * 64 * 16 * TM * TN + lane;
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] += src[((m * TN + n) * 16 + r) * 64];
+      }
+    }
+    scratch = smem + (KG - 1) * PART;
   }
 
   // ---- epilogue: D row = (reg&3) + 8*(reg>>2) + 4*lh, column = li ----
@@ -251,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int mg = m0 + row;
+        const int mg = lead ? m0 + row : M;   // the other K groups store nothing
         size_t opix = (size_t)mg;
         if (!direct) {
           const int nn = mg / HlWl;
@@ -281,13 +338,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   if (!FUSED && p.bs_partial) {   // uniform: reductions of the next backward stage (IgemmParams);
     // needs every tile inside one image and all rows valid (dispatcher check)
     constexpr int WAVES_M = BM / WM;
-    float2* red = reinterpret_cast<float2*>(As);
+    float2* red = reinterpret_cast<float2*>(scratch);
     const int img = m0 / HlWl;
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = n0 + wn0 + n * 32 + li;
       const BwdCoef cf = bwd_coef(p, img, col);
-      const float2 mine = wave_bwd_stats<TM>(
+      float2 mine = float2{0.f, 0.f};
+      if (lead) mine = wave_bwd_stats<TM>(
           cf, p.slope, [&](int m, int r) { return acc[m][n][r]; },
           [&](int m, int r) {
             const int mg = m0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -301,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
             }
             return p.bs_y[opix * p.ldo + col];
           });
-      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+      if (lh == 0 && lead) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
     }
     float2 out;
     if (block_col_sums<BN, WAVES_M>(red, out))
@@ -310,14 +368,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   }
   if (FUSED && p.stats) {   // uniform; the K loop ended on a barrier: the A tiles are free scratch
     constexpr int WAVES_M = BM / WM;
-    float2* red = reinterpret_cast<float2*>(As);
+    float2* red = reinterpret_cast<float2*>(scratch);
     static_assert(WAVES_M * BN * 2 <= 2 * A_TILE, "stats scratch fits in the A tiles");
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = n0 + wn0 + n * 32 + li;
       const float bv = p.bias ? p.bias[col] : 0.f;
       const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][n][r] + bv; });
-      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+      if (lh == 0 && lead) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
     }
     float2 out;
     if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
@@ -328,15 +386,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const IgemmParams p)
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32, bool FUSED = false>
+template <int BM, int BN, int WM, int WN, int BK = 32, bool FUSED = false, int KG = 1>
 int launch_igemm(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDA = BK + 4;
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDA * sizeof(float);
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, FUSED>;
+  constexpr size_t lds = KG * 2 * (size_t)(BM + BN) * LDA * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS stages of every K group fit one CU");
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, FUSED, KG>;
   UNET_SET_DYN_LDS(kern, lds);
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KG), lds, stream, p);
   UNET_CHECK_LAUNCH("conv_igemm");
   return UNET_OK;
 }
@@ -549,6 +608,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_rf_kernel(const IgemmParams
         if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
       }
+      // FUSED: keep the activation arithmetic (and its wait for this step's loads) behind the MFMAs
+      if (FUSED) __builtin_amdgcn_sched_barrier(0);
       store_tiles(buf ^ 1);
       __syncthreads();
     }
@@ -880,18 +941,29 @@ int launch_dgrad_s2(const IgemmParams& p, hipStream_t stream) {
 // stats_px != nullptr: the fused-layer call (activation on load; statistics epilogue into
 // p.stats when every tile lies inside one image, reported as *stats_px = pixels per statistics
 // tile, else *stats_px = 0 and the caller runs the stand-alone statistics kernel).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KG = 1>
 static int launch_igemm_fused(IgemmParams p, hipStream_t stream, int* stats_px) {
   const int HlWl = p.Hl * p.Wl;
   const bool direct = p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout;
   if (direct && p.stats && HlWl % BM == 0) { *stats_px = BM; p.stats_tiles = HlWl / BM; }
   else { *stats_px = 0; p.stats = nullptr; }
-  return launch_igemm<BM, BN, WM, WN, 32, true>(p, stream);
+  return launch_igemm<BM, BN, WM, WN, 32, true, KG>(p, stream);
+}
+
+// Deep layers (at most one 64x64 tile per CU): number of K groups per block (1 = no split).
+static int deep_k_groups(const IgemmParams& p) {
+  static const int forced = getenv("UNET_IGEMM_KG") ? atoi(getenv("UNET_IGEMM_KG")) : 0;
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  if (p.Ncols % 64 != 0 || ceil_div64(M, 64) * (p.Ncols / 64) > 256) return 1;
+  const int ks = p.ntaps * ((p.C0 + p.C1) / 32);
+  int kg = forced ? forced : 4;
+  while (kg > 1 && (ks % kg != 0 || ks / kg < 4)) kg >>= 1;
+  return kg;
 }
 
 // plain gather-GEMM launch; with bs_px (data gradient whose output is final for a layer) the
 // BSTATS epilogue runs where every tile lies inside one image, else *bs_px = 0
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KG = 1>
 static int launch_igemm_bs(IgemmParams p, hipStream_t stream, int* bs_px) {
   if (bs_px) {
     const int HlWl = p.Hl * p.Wl;
@@ -900,7 +972,23 @@ static int launch_igemm_bs(IgemmParams p, hipStream_t stream, int* bs_px) {
   } else {
     p.bs_partial = nullptr;
   }
-  return launch_igemm<BM, BN, WM, WN>(p, stream);
+  return launch_igemm<BM, BN, WM, WN, 32, false, KG>(p, stream);
+}
+
+static int deep_n_group(const IgemmParams& p) {
+  static const int forced = getenv("UNET_IGEMM_NGROUP") ? atoi(getenv("UNET_IGEMM_NGROUP")) : -1;
+  const int tiles_n = p.Ncols / 64;
+  int g = forced >= 0 ? forced : 0;
+  if (g <= 0 || tiles_n % g != 0) return 0;
+  return g;
+}
+
+static int launch_igemm_deep(IgemmParams p, hipStream_t stream, int* bs_px) {
+  const int kg = deep_k_groups(p);
+  p.n_group = deep_n_group(p);
+  return kg == 4   ? launch_igemm_bs<64, 64, 32, 32, 4>(p, stream, bs_px)
+         : kg == 2 ? launch_igemm_bs<64, 64, 32, 32, 2>(p, stream, bs_px)
+                   : launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
 }
 
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int* bs_px) {
@@ -915,7 +1003,14 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
       return launch_igemm_fused<128, 128, 64, 64>(p, stream, stats_px);
     if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
       return launch_igemm_fused<128, 64, 64, 32>(p, stream, stats_px);
-    if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_fused<64, 64, 32, 32>(p, stream, stats_px);
+    if (nc % 64 == 0 && M <= 128 * 256) {
+      const int kg = deep_k_groups(p);
+      IgemmParams q = p;
+      q.n_group = deep_n_group(p);
+      return kg == 4   ? launch_igemm_fused<64, 64, 32, 32, 4>(q, stream, stats_px)
+             : kg == 2 ? launch_igemm_fused<64, 64, 32, 32, 2>(q, stream, stats_px)
+                       : launch_igemm_fused<64, 64, 32, 32>(q, stream, stats_px);
+    }
     return launch_igemm_fused<128, 32, 32, 32>(p, stream, stats_px);
   }
   if (bs_px) {   // per-class launches of one stride-2 gradient pass bs_tile0 themselves
@@ -923,7 +1018,7 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
       return launch_igemm_bs<128, 128, 64, 64>(p, stream, bs_px);
     if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
       return launch_igemm_bs<128, 64, 64, 32>(p, stream, bs_px);
-    if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
+    if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_deep(p, stream, bs_px);
     return launch_igemm_bs<128, 32, 32, 32>(p, stream, bs_px);
   }
   // Largest tile that still yields >= 256 workgroups (one per CU); otherwise the
@@ -934,7 +1029,7 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
                 : launch_igemm<128, 128, 64, 64>(p, stream);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
     return launch_igemm<128, 64, 64, 32>(p, stream);
-  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm<64, 64, 32, 32>(p, stream);
+  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_deep(p, stream, nullptr);
   return launch_igemm<128, 32, 32, 32>(p, stream);
 }
 

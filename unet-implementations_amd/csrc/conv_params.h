@@ -65,6 +65,10 @@ struct IgemmParams {
   float2* bs_partial;
   int bs_tiles;            // tiles per image
   int bs_tile0;            // first tile index of this launch (per-class stride-2 launches)
+  // gather-GEMM tile order: consecutive block ids (one XCD's share after the remap) walk all row
+  // tiles of n_group column tiles before the next column group; 0 = every column tile of a row
+  // tile first.  Deep layers (weights >> activations) keep an XCD on few weight panels this way.
+  int n_group;
 };
 
 // The kernels address their operands through buffer descriptors (free zero padding), whose
