@@ -71,9 +71,14 @@ FWD_CASES = [
     (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # patch-staged, 128 columns (two sources)
     (1, 256, 256, 64, 0, 64, 1, 3, True, False),     # patch-staged, 64 columns
     (2, 256, 256, 32, 32, 32, 1, 3, False, True),    # patch-staged, 32 columns x 8 rows; plain src0
-    (1, 128, 128, 32, 0, 32, 1, 3, True, False),     # row-fused, weights resident (K = 32)
+    (1, 128, 128, 32, 0, 32, 1, 3, True, False),     # 32 -> 32 channel kernel (weights in registers)
+    (2, 256, 256, 32, 0, 32, 1, 3, True, False),     # the same, two tiles per persistent workgroup
+    (3, 64, 96, 32, 0, 32, 1, 3, False, False),      # the same, 72 tiles (plain walk), plain source
+    (1, 12, 128, 32, 0, 32, 1, 3, True, False),      # row-fused, weights resident (H % 8 != 0)
     (1, 12, 128, 64, 0, 32, 1, 3, True, False),      # row-fused, streamed weights
-    (2, 256, 256, 32, 0, 128, 2, 3, True, False),    # gather-GEMM 128x128, stride 2
+    (2, 256, 256, 32, 0, 128, 2, 3, True, False),    # stride 2, patch-staged 64 columns
+    (2, 264, 512, 32, 0, 128, 2, 3, True, False),    # stride 2, patch-staged 128 columns, H != W
+    (2, 256, 256, 32, 32, 256, 2, 3, False, True),   # stride 2, patch-staged, plain + activated source
     (2, 256, 256, 32, 0, 64, 2, 3, True, False),     # gather-GEMM 128x64 tiles, stride 2
     (2, 16, 16, 64, 0, 64, 1, 3, True, False),       # gather-GEMM 64x64, two K groups
     (2, 16, 16, 128, 0, 128, 1, 3, True, False),     # deep layer: four K groups per block
@@ -478,7 +483,9 @@ def _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask):
 BS_DGRAD = [  # (N, H, W, Cout, Ccols, stride, accumulate): H, W = size of dx
     (1, 256, 256, 32, 64, 1, False),     # patch-staged 64 columns
     (1, 256, 256, 64, 128, 1, True),     # patch-staged 128 columns, accumulate (skip gradient)
-    (1, 128, 128, 32, 32, 1, False),     # row-fused, K = 32
+    (1, 128, 128, 32, 32, 1, False),     # 32 -> 32 channel kernel
+    (2, 256, 256, 32, 32, 1, True),      # the same, two tiles per workgroup, accumulate
+    (1, 12, 128, 32, 32, 1, False),      # row-fused, K = 32
     (2, 16, 16, 64, 64, 1, False),       # gather-GEMM 64x64, two K groups
     (2, 16, 16, 128, 128, 1, True),      # four K groups, accumulate
     (2, 32, 32, 128, 128, 2, False),     # stride-2 per-class launches with 4 / 2 / 2 / 1 K groups

@@ -1,0 +1,287 @@
+// conv_c32.hip — the 32 -> 32 channel 3x3 stride-1 convolutions of the full-resolution stages
+// (forward of enc0.3 / dec4.3, and the data gradients that produce 32 channels:
+// Our_UNet/models/unet.py:106-115 at 512x512) on the fp32 matrix cores.
+//
+// K = 9 * 32 and 32 output columns leave one 32x32 accumulator block per wave and only 144
+// MFMAs per 32 output pixels, so the per-tile overheads (barriers, load latency, epilogue)
+// decide the rate.  This kernel removes them structurally:
+//   * persistent workgroup of EIGHT waves (512 threads, one per CU, two waves per SIMD) walking
+//     8 x 32-pixel tiles; wave w owns tile row w;
+//   * the whole weight tensor lives in REGISTERS: lane (li, lh) keeps its B fragments of all
+//     nine taps (9 x 4 f32x4 = 144 VGPRs), so the K loop issues no weight traffic at all;
+//   * the (8+2) x 34 x 32-channel input patch is staged once per tile and serves all nine taps;
+//     two LDS patch buffers: the next tile's patch is loaded at the start of a tile, rides in
+//     registers through the tile's 144 MFMAs per wave (>= 3.8 us: HBM latency is covered) and
+//     is written to the other buffer after them - ONE barrier per tile;
+//   * statistics (forward) and the next layer's InstanceNorm-backward sums (data gradient):
+//     every wave leaves its row's summary in LDS and 32 lanes merge the eight rows (fixed
+//     order) AFTER the tile's barrier, so the 256-pixel summaries cost no barrier of their own.
+// FUSED = the fused-layer forward (activation on load, bias, statistics); otherwise the data
+// gradient form (optional accumulate, optional BSTATS epilogue).
+#include "conv_params.h"
+#include <stdlib.h>
+
+#include <utility>
+
+namespace unet_conv {
+namespace {
+
+template <int B, int... I, typename F>
+__device__ __forceinline__ void for_range_c_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, typename F>
+__device__ __forceinline__ void for_range_c(F&& f) {
+  for_range_c_impl<B>(std::make_integer_sequence<int, (E > B ? E - B : 0)>{}, f);
+}
+
+constexpr int C32_TH = 8, C32_TW = 32, C32_PW = C32_TW + 2, C32_PH = C32_TH + 2;
+constexpr int C32_LDA = 36;
+constexpr int C32_PPIX = C32_PH * C32_PW;          // 340 patch pixels
+constexpr int C32_SLOTS = C32_PPIX * 8;            // f32x4 slots
+constexpr int C32_PASSES = (C32_SLOTS + 511) / 512;
+constexpr size_t C32_LDS = 2 * (size_t)C32_PPIX * C32_LDA * sizeof(float) +
+                           2 * 8 * 32 * sizeof(float2);   // + per-wave summaries of two tiles
+
+template <bool FUSED>
+__global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, int ntiles) {
+  constexpr int LDA = C32_LDA, PW = C32_PW, P_PASSES = C32_PASSES;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tile row of this wave
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = p.Hin, W = p.Win;
+  const int tiles_x = W / C32_TW, tiles_y = H / C32_TH;
+
+  // persistent walk: the workgroups of one XCD (blockIdx % 8) cover a contiguous eighth of the
+  // tile sequence (halo rows stay in that XCD's L2)
+  const int G = gridDim.x;
+  int t_first, t_stride, t_end;
+  if ((ntiles & 7) == 0 && (G & 7) == 0) {
+    const int per = ntiles >> 3, xcd = blockIdx.x & 7;
+    t_first = xcd * per + (blockIdx.x >> 3);
+    t_stride = G >> 3;
+    t_end = (xcd + 1) * per;
+  } else {
+    t_first = blockIdx.x; t_stride = G; t_end = ntiles;
+  }
+  if (t_first >= t_end) return;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+
+  // ---- weights: this lane's B fragments of every tap, for the whole kernel ----
+  f32x4 wb[9][4];
+  int tap_off[9];   // patch offset of tap t (floats), uniform
+  for_range_c<0, 9>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
+    const int wt = (int)(e >> 4);
+    tap_off[t] = (oy * PW + ox) * LDA;
+    const float* wp = p.w + (size_t)wt * p.tap_stride + (size_t)(p.n_off + li) * 32 + 4 * lh;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) wb[t][kg] = *reinterpret_cast<const f32x4*>(wp + kg * 8);
+  });
+
+  // ---- patch slots of this thread (constant across tiles) ----
+  int pp_rel[P_PASSES], pp_lds[P_PASSES], pp_rc[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = tid + 512 * i;
+    const bool valid = slot < C32_SLOTS;
+    const int pix = valid ? slot >> 3 : 0, seg = slot & 7;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    pp_rel[i] = ((prow * W + pcol) * 32 + seg * 4) * 4;   // bytes from the patch origin
+    pp_lds[i] = pix * LDA + seg * 4;
+    pp_rc[i] = valid ? (prow | (pcol << 8)) : (1 << 20);  // invalid: fails both range checks
+  }
+
+  f32x4 pr[P_PASSES];
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
+  unsigned okm = 0;
+  auto tile_pos = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % tiles_x;
+    const int r = tile / tiles_x;
+    const int ty = r % tiles_y;
+    n = r / tiles_y; y0 = ty * C32_TH; x0 = tx * C32_TW;
+  };
+  auto load_patch = [&](int tile) {
+    int n, y0, x0;
+    tile_pos(tile, n, y0, x0);
+    const int base = ((n * H + y0 - 1) * W + x0 - 1) * 128;   // bytes; may be negative at borders
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const int prow = pp_rc[i] & 0xff, pcol = pp_rc[i] >> 8;
+      const bool ok = (unsigned)(y0 - 1 + prow) < (unsigned)H && (unsigned)(x0 - 1 + pcol) < (unsigned)W;
+      okm |= (ok ? 1u : 0u) << i;
+      const unsigned off = ok ? (unsigned)(base + pp_rel[i]) : 0x80000000u;
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+    }
+    if (FUSED) {
+      if (p.act0_alpha) {   // uniform
+        const size_t o = (size_t)n * 32 + (tid & 7) * 4;
+        ca = *reinterpret_cast<const f32x4*>(p.act0_alpha + o);
+        cb = *reinterpret_cast<const f32x4*>(p.act0_beta + o);
+        cs = p.slope;
+      }
+    }
+  };
+  auto store_patch = [&](int buf) {
+    float* Pb = smem + buf * (C32_PPIX * LDA);
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      if (FUSED) pr[i] = act4(pr[i], ca, cb, cs, (okm >> i) & 1u);
+      if (512 * (i + 1) <= C32_SLOTS || tid + 512 * i < C32_SLOTS)
+        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = pr[i];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // row summaries of the tile in patch buffer b: red[b][wave][column]
+  float2* red = reinterpret_cast<float2*>(smem + 2 * C32_PPIX * LDA);
+  const bool summaries = FUSED ? p.stats != nullptr : p.bs_partial != nullptr;   // uniform
+
+  load_patch(t_first);
+  store_patch(0);
+  __syncthreads();
+
+  const int a_lane = ((wave + 1) * PW + li + 1) * LDA + 4 * lh;
+  int buf = 0;
+  for (int tile = t_first; tile < t_end; tile += t_stride, buf ^= 1) {
+    const int nxt = tile + t_stride;
+    const bool more = nxt < t_end;
+    if (more) load_patch(nxt);   // uniform
+    int n, y0, x0;
+    tile_pos(tile, n, y0, x0);
+    const int y = y0 + wave;
+    const size_t pix0o = ((size_t)n * H + y) * W + x0 + 4 * lh;   // first output pixel of this lane
+
+    // ---- 9 taps x 4 k-groups x 4 MFMAs from the staged patch; A fragments one group ahead ----
+    const float* P = smem + buf * (C32_PPIX * LDA) + a_lane;
+    f32x4 a[2];
+    a[0] = *reinterpret_cast<const f32x4*>(P + tap_off[0]);
+    for_range_c<0, 36>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int t = g / 4, kg = g % 4;
+      constexpr int cur = g & 1, nx = cur ^ 1;
+      if constexpr (g + 1 < 36) {
+        constexpr int t1 = (g + 1) / 4, kg1 = (g + 1) % 4;
+        a[nx] = *reinterpret_cast<const f32x4*>(P + tap_off[t1] + kg1 * 8);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][r], wb[t][kg][r], acc, 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue of this wave's row: D row (pixel) (reg&3) + 8*(reg>>2) + 4*lh, column li ----
+    float* o = p.out + pix0o * p.ldo + li;
+    if (FUSED) {
+      const float bv = p.bias ? p.bias[li] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += bv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[r];
+      if (p.stats) {   // uniform
+        const float2 mine = wave_col_stats<1>([&](int, int r) { return acc[r]; });
+        if (lh == 0) red[(buf * 8 + wave) * 32 + li] = mine;
+      }
+    } else {
+      if (p.accumulate) {   // uniform: all 16 reads in flight before the first add
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += old[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[r];
+      if (p.bs_partial) {   // uniform: reductions of the next backward stage (IgemmParams)
+        const BwdCoef cf = bwd_coef(p, n, li);
+        const float* yb = p.bs_y + pix0o * p.ldo + li;
+        const float2 mine = wave_bwd_stats<1>(
+            cf, p.slope, [&](int, int r) { return acc[r]; },
+            [&](int, int r) { return yb[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo]; });
+        if (lh == 0) red[(buf * 8 + wave) * 32 + li] = mine;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (more) store_patch(buf ^ 1);   // every wave left that buffer before the previous barrier
+    __syncthreads();
+    if (summaries && tid < 32) {   // red[buf] is rewritten two tiles (two barriers) from now
+      const float2* rr = red + buf * 8 * 32 + tid;
+      const size_t dst = ((size_t)n * (tiles_x * tiles_y) + (y0 / C32_TH) * tiles_x + (x0 >> 5)) * 32 + tid;
+      if (FUSED) {
+        float mean[4], m2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mean[k] = rr[(2 * k) * 32].x; m2[k] = rr[(2 * k) * 32].y;
+          wf_merge_eq(mean[k], m2[k], rr[(2 * k + 1) * 32].x, rr[(2 * k + 1) * 32].y, 32.f);
+        }
+        wf_merge_eq(mean[0], m2[0], mean[1], m2[1], 64.f);
+        wf_merge_eq(mean[2], m2[2], mean[3], m2[3], 64.f);
+        wf_merge_eq(mean[0], m2[0], mean[2], m2[2], 128.f);
+        p.stats[dst] = float2{mean[0], m2[0]};
+      } else {
+        float a = rr[0].x, b = rr[0].y;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += rr[k * 32].x; b += rr[k * 32].y; }
+        p.bs_partial[dst] = float2{a, b};
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// 3x3 stride-1, 32 input and 32 output channels, image tiles as 8 x 32 pixels
+bool c32_applicable(const IgemmParams& p) {
+  static const int off = getenv("UNET_NO_C32") ? 1 : 0;
+  return !off && p.ntaps == 9 && p.tap_cstride == 0 && p.src0_pitch == 0 && p.sout == 1 &&
+         p.Hl == p.Hin && p.Wl == p.Win && p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 8 == 0 &&
+         p.Win % 32 == 0 && p.C0 == 32 && p.C1 == 0 && p.Ncols == 32 &&
+         (long long)p.N * p.Hin * p.Win * 128 < (1LL << 31);
+}
+
+// fused != 0: the fused-layer forward (activation on load, statistics into p.stats when set);
+// else the data gradient (p.accumulate, BSTATS epilogue when p.bs_partial is set).  *tile_px
+// receives the pixels per statistics / reduction tile (256) or 0 when none was emitted.
+int launch_c32(const IgemmParams& p0, int fused, hipStream_t stream, int* tile_px) {
+  IgemmParams p = p0;
+  const int tiles256 = p.Hin * p.Win / 256;
+  if (tile_px) *tile_px = 0;
+  if (fused) {
+    p.bs_partial = nullptr;
+    if (p.stats && tile_px) { p.stats_tiles = tiles256; *tile_px = 256; }
+    else p.stats = nullptr;
+  } else {
+    p.stats = nullptr;
+    if (p.bs_partial && tile_px) { p.bs_tiles = tiles256; p.bs_tile0 = 0; *tile_px = 256; }
+    else p.bs_partial = nullptr;
+  }
+  const int ntiles = p.N * (p.Hin / C32_TH) * (p.Win / C32_TW);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  if (fused) {
+    auto kern = conv_c32_kernel<true>;
+    UNET_SET_DYN_LDS(kern, C32_LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C32_LDS, stream, p, ntiles);
+  } else {
+    auto kern = conv_c32_kernel<false>;
+    UNET_SET_DYN_LDS(kern, C32_LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C32_LDS, stream, p, ntiles);
+  }
+  UNET_CHECK_LAUNCH("conv_c32");
+  return UNET_OK;
+}
+
+}  // namespace unet_conv

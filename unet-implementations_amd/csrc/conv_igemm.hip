@@ -999,6 +999,10 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
     if (rc != 1) return rc;
   }
   if (stats_px) {
+    if (patch_s2_applicable(p)) {   // conv_patch.hip; 1 = too few tiles
+      const int rc = launch_patch_s2_auto(p, stream, stats_px);
+      if (rc != 1) return rc;
+    }
     if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
       return launch_igemm_fused<128, 128, 64, 64>(p, stream, stats_px);
     if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
@@ -1362,7 +1366,9 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     if (prec == 1) return dispatch_igemm_bf16(p, stream);
     if (prec == 3) return dispatch_igemm_split(p, stream);
     int rc;
-    if (rf_applicable(p) && (Cout == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
+    if (c32_applicable(p))   // conv_c32.hip: 32 -> 32 channels
+      rc = launch_c32(p, 0, stream, use_bs ? &bs_px : nullptr);
+    else if (rf_applicable(p) && (Cout == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
       rc = (Cout == 32) ? launch_igemm_rf<128, 32, 32, 32, true>(p, 1, stream, &bs_px)
                         : launch_igemm_rf<128, 32, 32, 32, false>(p, 1, stream, &bs_px);
     else
@@ -1653,7 +1659,9 @@ static int conv_in_fwd_impl(const unet_act_src* s0, const unet_act_src* s1, floa
       } else {
         fill_fwd_taps(p, stride);
         // K = 32: row-fused kernel with the weights resident in LDS; wider K: the patch kernel
-        if (stride == 1 && rf_applicable(p) &&
+        if (stride == 1 && c32_applicable(p))   // conv_c32.hip: 32 -> 32 channels
+          rc = launch_c32(p, 1, stream, &px);
+        else if (stride == 1 && rf_applicable(p) &&
             (Cin == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
           rc = (Cin == 32) ? launch_igemm_rf<128, 32, 32, 32, true, true>(p, 0, stream, &px)
                            : launch_igemm_rf<128, 32, 32, 32, false, true>(p, 0, stream, &px);

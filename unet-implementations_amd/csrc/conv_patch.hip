@@ -491,6 +491,226 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 }
 
 // ---------------------------------------------------------------------------
+// Stride-2 3x3 forward convolution (the first convolution of encoder stages 1..4,
+// Our_UNet/models/unet.py:106-115 with stride 2), patch-staged: the (2 TH + 1) x 65 input
+// pixels under a TH x 32 tile of OUTPUT pixels are staged once per 16-channel chunk and serve
+// all nine taps (the gather-GEMM re-loads and re-activates its A tile per tap).  An LDS patch
+// row holds the 33 even input columns first and the 32 odd ones behind them, so the fragment
+// of tap kx for output columns 0..31 is 32 CONSECUTIVE slots (kx = 0: even 0.., kx = 1: odd
+// 0.., kx = 2: even 1..) and reads as conflict-free as the stride-1 patch.  16-channel chunks
+// keep patch + weight panels at 67 KB (two workgroups per CU at BN = 128).  Always the fused
+// layer form: activation on load (plain sources pass null coefficients), statistics epilogue.
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN, int TH>
+__global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams p) {
+  constexpr int BK = 16, LDA = BK + 4, SEG = BK / 4;
+  constexpr int TW = 32, PWC = 2 * TW + 1, PH = 2 * TH + 1;
+  constexpr int ODD0 = TW + 1;               // first odd-column slot of a patch row
+  constexpr int PPIX = PH * PWC;
+  constexpr int P_SLOTS = PPIX * SEG;        // f32x4 slots: 16 channels per pixel
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = BN * SEG, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = BN * LDA;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                          // [patch row][even cols | odd cols][LDA]
+  float* Bs = smem + PPIX * LDA;             // [buf][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+
+  const int H = p.Hin, W = p.Win, Ho = p.Hl, Wo = p.Wl;
+  const int tiles_n = p.Ncols / BN, tiles_x = Wo / TW, tiles_y = Ho / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;   // output coordinates
+  const int Ktot = p.C0 + p.C1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  // patch slots (slots past P_SLOTS alias an earlier slot: same bytes to the same place)
+  int pp_lin[P_PASSES], pp_lds[P_PASSES];
+  unsigned pp_oob[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = (tid + 256 * i) % P_SLOTS;
+    const int pix = slot / SEG, seg = slot % SEG;
+    const int prow = pix / PWC, pcol = pix - prow * PWC;
+    const int iy = 2 * y0 - 1 + prow, ix = 2 * x0 - 1 + pcol;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    pp_lin[i] = ok ? ((n * H + iy) * W + ix) * 4 : 0;   // x channel count = byte offset
+    pp_oob[i] = (ok ? 0u : 0x80000000u) | (unsigned)(seg * 16);
+    pp_lds[i] = (prow * PWC + ((pcol & 1) ? ODD0 + (pcol >> 1) : (pcol >> 1))) * LDA + seg * 4;
+  }
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int row = slot / SEG, seg = slot % SEG;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
+    wslot_lds[j] = row * LDA + seg * 4;
+  }
+
+  f32x4 pr[P_PASSES], rb[B_PASSES];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+
+  // coefficients of this thread's four channels (slot % SEG is the same for every pass)
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
+  auto load_patch = [&](int chunk) {
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const unsigned cbytes = (unsigned)(first ? c : c - p.C0) * 4u;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const unsigned off = ((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i];
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
+    const float* al = first ? p.act0_alpha : p.act1_alpha;
+    const float* be = first ? p.act0_beta : p.act1_beta;
+    if (al) {   // uniform
+      const size_t o = (size_t)n * Cs + (first ? c : c - p.C0) + (tid % SEG) * 4;
+      ca = *reinterpret_cast<const f32x4*>(al + o);
+      cb = *reinterpret_cast<const f32x4*>(be + o);
+      cs = p.slope;
+    } else {    // plain source: z = v, slope 1 = identity
+      ca = f32x4{1.f, 1.f, 1.f, 1.f};
+      cb = f32x4{0.f, 0.f, 0.f, 0.f};
+      cs = 1.f;
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      pr[i] = act4(pr[i], ca, cb, cs, (pp_oob[i] >> 31) == 0u);
+      *reinterpret_cast<f32x4*>(Ps + pp_lds[i]) = pr[i];
+    }
+  };
+  auto load_b = [&](int t, int chunk) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const int wt = (int)(((tw >> ((t & 3) * 8)) & 0xffu) >> 4);
+    const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsw, wslot_off[j] + woff, 0, 0));
+  };
+  auto store_b = [&](int buf) {
+    float* Bb = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[j];
+  };
+
+  const int chunks = Ktot / BK;
+  const int steps = chunks * 9;
+  load_patch(0);
+  load_b(0, 0);
+  store_patch();
+  store_b(0);
+  __syncthreads();
+
+  // output pixel (wrow0 + m, li), tap (ky, kx) -> patch row 2 (wrow0 + m) + ky, column slot
+  // li + {0, ODD0, 1}[kx]; lane (li, lh) reads 4 consecutive k at k offset 4*lh
+  const int a_lane = (2 * wrow0 * PWC + li) * LDA + 4 * lh;
+  const int b_lane = (wn0 + li) * LDA + 4 * lh;
+  int t = 0, chunk = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    const int t1 = (t == 8) ? 0 : t + 1;
+    const int chunk1 = (t == 8) ? chunk + 1 : chunk;
+    const bool more = s + 1 < steps;
+    load_b(more ? t1 : t, more ? chunk1 : chunk);
+    if (t == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int ky = (int)(e & 3u), kx = (int)((e >> 2) & 3u);
+    const float* Ab = Ps + a_lane + (ky * PWC + (kx == 1 ? ODD0 : (kx >> 1))) * LDA;
+    const float* Bb = Bs + buf * B_TILE + b_lane;
+    f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * 2 * PWC * LDA);
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) b[0][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 8) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+          a[nxt][m] = *reinterpret_cast<const f32x4*>(Ab + m * 2 * PWC * LDA + (kk + 1) * 8);
+#pragma unroll
+        for (int nb = 0; nb < TN; ++nb)
+          b[nxt][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA + (kk + 1) * 8);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][nb][r],
+                                                              acc[m][nb], 0, 0, 0);
+    }
+    store_b(buf ^ 1);
+    if (t == 8) {            // every wave is done with this chunk's patch
+      __syncthreads();
+      store_patch();
+    }
+    __syncthreads();
+    t = t1;
+    chunk = chunk1;
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      float* o = p.out + (((size_t)n * Ho + (y0 + wrow0 + m)) * Wo + x0 + 4 * lh) * p.ldo + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r];
+    }
+  }
+  if (p.stats) {   // uniform; the K loop ended on a barrier: the patch area is free scratch
+    constexpr int WAVES_M = 4 / WAVES_N;
+    float2* red = reinterpret_cast<float2*>(Ps);
+    static_assert(WAVES_M * BN * 2 <= PPIX * LDA, "stats scratch fits in the patch area");
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r]; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
+      p.stats[((size_t)n * p.stats_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // First convolution of a decoder stage: y = conv3x3(cat(upsample2x(act(low)), act(skip))) with the
 // bilinear up-sampling done INSIDE the patch loader (Our_UNet/models/unet.py:215-231: the
 // reference materialises both the up-sampled tensor and the concatenation).  Source 0 is the
@@ -815,7 +1035,44 @@ int launch_patch_f32(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+template <int BN, int WM, int WN, int TH>
+int launch_patch_s2(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((2 * TH + 1) * 65) * 20 + 2 * (size_t)BN * 20) * sizeof(float);
+  auto kern = conv_patch_s2_kernel<BN, WM, WN, TH>;
+  UNET_SET_DYN_LDS(kern, lds);
+  const long long tiles = (long long)p.N * (p.Hl / TH) * (p.Wl / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_s2");
+  return UNET_OK;
+}
+
 }  // namespace
+
+// stride-2 3x3 forward whose OUTPUT tiles as 4 x 32 pixels, 16-channel chunks, standard taps
+bool patch_s2_applicable(const IgemmParams& p) {
+  static const int off = getenv("UNET_NO_PATCH_S2") ? 1 : 0;
+  IgemmParams std_taps{};
+  for (int t = 0; t < 9; ++t) set_tap(std_taps, t, t / 3 - 1, t % 3 - 1, t);
+  return !off && p.ntaps == 9 && p.tap_cstride == 0 && p.src0_pitch == 0 && p.sin == 2 &&
+         p.sout == 1 && p.Hin == 2 * p.Hl && p.Win == 2 * p.Wl && p.Hl == p.Hout &&
+         p.Wl == p.Wout && p.Hl % 4 == 0 && p.Wl % 32 == 0 && p.C0 % 16 == 0 && p.C1 % 16 == 0 &&
+         !p.accumulate && p.tapw[0] == std_taps.tapw[0] && p.tapw[1] == std_taps.tapw[1] &&
+         p.tapw[2] == std_taps.tapw[2];
+}
+
+// Fused-layer stride-2 forward on the patch-staged kernel; returns 1 when no tile shape fills
+// the chip (the caller falls back to the gather-GEMM).  *stats_px = pixels per statistics tile.
+int launch_patch_s2_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+  IgemmParams p = p0;
+  const long long mt = (long long)p.N * p.Hl * p.Wl / 128;
+  const int nc = p.Ncols;
+  *stats_px = p.stats ? 128 : 0;
+  p.stats_tiles = p.Hl * p.Wl / 128;
+  if (nc % 128 == 0 && mt * (nc / 128) >= 512) return launch_patch_s2<128, 64, 64, 4>(p, stream);
+  if (nc % 64 == 0 && mt * (nc / 64) >= 512) return launch_patch_s2<64, 64, 32, 4>(p, stream);
+  *stats_px = 0;
+  return 1;
+}
 
 // stride-1 3x3 over an image that tiles as 4 x 32 pixels, 16-channel chunks
 bool patch_split_applicable(const IgemmParams& p) {
