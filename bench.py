@@ -76,8 +76,8 @@ def roofline_of(summ, steps, matmul, args):
         # algorithmic count
         "executed": k["executed"] / sec * 1e-12, "executed_frac": k["executed"] / sec * 1e-12 / peak,
         "kernel": "convolution forward + data-gradient group ("
-                  + {"fp32": "conv_patch_f32_kernel, conv_igemm_kernel, conv_igemm_rf_kernel, "
-                             "conv_dgrad_s2_kernel",
+                  + {"fp32": "conv_patch_f32_kernel, conv_patch_up_kernel, conv_patch_s2_kernel, "
+                             "conv_c32_kernel, conv_igemm_kernel, conv_dgrad_s2_kernel",
                      "bf16": "conv_igemm_bf16_kernel on bf16 tensors",
                      "bf16x3": "conv_patch_split_kernel, conv_igemm_split_kernel + fp32 "
                                "fallbacks"}[matmul] + "): "
