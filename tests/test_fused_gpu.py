@@ -489,7 +489,10 @@ BS_DGRAD = [  # (N, H, W, Cout, Ccols, stride, accumulate): H, W = size of dx
     (2, 16, 16, 64, 64, 1, False),       # gather-GEMM 64x64, two K groups
     (2, 16, 16, 128, 128, 1, True),      # four K groups, accumulate
     (2, 32, 32, 128, 128, 2, False),     # stride-2 per-class launches with 4 / 2 / 2 / 1 K groups
-    (2, 256, 256, 32, 64, 2, True),      # stride-2 one-launch kernel, accumulate
+    (2, 256, 256, 32, 64, 2, True),      # stride-2 patch-staged kernel, 64 columns, accumulate
+    (2, 512, 512, 64, 32, 2, False),     # stride-2 patch-staged kernel, 32 columns x 8 rows
+    (1, 128, 256, 96, 64, 2, False),     # stride-2 patch-staged kernel, three K chunks, H != W
+    (1, 64, 64, 32, 64, 2, False),       # stride-2 one-launch gather kernel (too few patch tiles)
     (2, 32, 32, 64, 64, 2, False),       # stride-2 per-class launches
     (3, 4, 4, 32, 32, 1, False),         # tiles span images: no epilogue, tiles == 0
 ]

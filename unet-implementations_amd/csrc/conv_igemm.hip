@@ -1382,6 +1382,16 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
     // one launch for all four parity classes when there are enough tiles to fill the chip
     const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
+    if (prec == 0 && !b16 && !per_class) {   // conv_patch.hip: the dy patch staged once per chunk
+      IgemmParams q = p;
+      if (!use_bs) q.bs_partial = nullptr;
+      int bt = 0;
+      const int rc = launch_dgrad_s2_patch_auto(q, stream, &bt);
+      if (rc != 1) {
+        if (rc == UNET_OK && use_bs && bt > 0) bs->tiles_out = bt;
+        return rc;
+      }
+    }
     if (prec != 1 && !b16 && !per_class && tiles >= 512) {
       p.py = p.px = 0; p.ntaps = 9;
       if (use_bs && (p.Hl * p.Wl) % 128 == 0) p.bs_tiles = p.Hl * p.Wl / 128;

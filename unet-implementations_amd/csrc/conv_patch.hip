@@ -711,6 +711,226 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
 }
 
 // ---------------------------------------------------------------------------
+// Stride-2 data gradient, patch-staged (aten::convolution_backward(data) of the stride-2
+// convolutions, Our_UNet/models/unet.py:106-115).  Position (a, b) of the dy grid produces the
+// four dx pixels (2a+py, 2b+px), class = py*2+px; tap (ky, kx) feeds the class with
+// py = (ky+1)&1, px = (kx+1)&1 from dy[a + (py+1-ky)/2][b + (px+1-kx)/2], i.e. a dy shift in
+// {0,1}^2.  The (TH+1) x 33 dy pixels under a TH x 32 tile of positions are staged once per
+// 32-channel chunk and serve all nine taps; per tap only the [BN][32] weight panel is
+// re-staged (double buffered) and its 16 k-pairs x TM x TN MFMAs accumulate into the tap's
+// class (4 x TM x TN accumulator blocks = 128 VGPRs per wave).  The nine taps are unrolled:
+// the class of a step is a compile-time index.  Output tile = 2 TH x 64 dx pixels x BN channels.
+// ---------------------------------------------------------------------------
+struct S2PTap { int ky, kx, oy, ox, cls; };
+__device__ constexpr S2PTap kS2PTaps[9] = {{1, 1, 0, 0, 0}, {1, 2, 0, 0, 1}, {2, 1, 0, 0, 2},
+                                           {2, 2, 0, 0, 3}, {1, 0, 0, 1, 1}, {2, 0, 0, 1, 3},
+                                           {0, 1, 1, 0, 2}, {0, 2, 1, 0, 3}, {0, 0, 1, 1, 3}};
+
+template <int BN, int WM, int WN, int TH>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_kernel(const IgemmParams p) {
+  constexpr int BK = 32, LDA = BK + 4;
+  constexpr int TW = 32, PW = TW + 1, PH = TH + 1;
+  constexpr int PPIX = PH * PW;
+  constexpr int P_SLOTS = PPIX * 8;
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = BN * LDA;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN, WAVES_M = 4 / WAVES_N;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ps = smem;                          // [dy pixel][LDA]
+  float* Bs = smem + PPIX * LDA;             // [buf][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+
+  const int Hl = p.Hl, Wl = p.Wl;            // dy grid
+  const int tiles_n = p.Ncols / BN, tiles_x = Wl / TW, tiles_y = Hl / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int Ktot = p.C0;                     // Cout of the forward convolution
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  int pp_lin[P_PASSES], pp_lds[P_PASSES];
+  unsigned pp_oob[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = (tid + 256 * i) % P_SLOTS;
+    const int pix = slot >> 3, seg = slot & 7;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    const int iy = y0 + prow, ix = x0 + pcol;
+    const bool ok = iy < Hl && ix < Wl;
+    pp_lin[i] = ok ? ((n * Hl + iy) * Wl + ix) * 4 : 0;   // x channel count = byte offset
+    pp_oob[i] = (ok ? 0u : 0x80000000u) | (unsigned)(seg * 16);
+    pp_lds[i] = pix * LDA + seg * 4;
+  }
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int row = slot >> 3, seg = slot & 7;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
+    wslot_lds[j] = row * LDA + seg * 4;
+  }
+
+  f32x4 pr[P_PASSES], rb[B_PASSES];
+  f32x16 acc[4][TM][TN];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][m][nb][r] = 0.f;
+
+  auto load_patch = [&](int chunk) {
+    const unsigned cbytes = (unsigned)(chunk * BK) * 4u;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const unsigned off = ((unsigned)(pp_lin[i] * Ktot) + cbytes) + pp_oob[i];
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) *reinterpret_cast<f32x4*>(Ps + pp_lds[i]) = pr[i];
+  };
+  auto load_b = [&](int wt, int chunk) {
+    const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsw, wslot_off[j] + woff, 0, 0));
+  };
+  auto store_b = [&](int buf) {
+    float* Bb = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[j];
+  };
+
+  const int chunks = Ktot / BK;
+  load_patch(0);
+  load_b(kS2PTaps[0].ky * 3 + kS2PTaps[0].kx, 0);
+  store_patch();
+  store_b(0);
+  __syncthreads();
+
+  const int a_lane = (wrow0 * PW + li) * LDA + 4 * lh;
+  const int b_lane = (wn0 + li) * LDA + 4 * lh;
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const int chunk_n = chunk + 1 < chunks ? chunk + 1 : chunk;   // the last chunk re-stages itself
+    for_range_p<0, 9>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr S2PTap T = kS2PTaps[t];
+      constexpr S2PTap T1 = kS2PTaps[t == 8 ? 0 : t + 1];
+      const int buf = (chunk + t) & 1;   // step = 9 * chunk + t
+      load_b(T1.ky * 3 + T1.kx, t == 8 ? chunk_n : chunk);
+      if (t == 0) load_patch(chunk_n);
+
+      const float* Ab = Ps + a_lane + (T.oy * PW + T.ox) * LDA;
+      const float* Bb = Bs + buf * B_TILE + b_lane;
+      f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * PW * LDA);
+#pragma unroll
+      for (int nb = 0; nb < TN; ++nb) b[0][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA);
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 8) {
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+            a[nxt][m] = *reinterpret_cast<const f32x4*>(Ab + m * PW * LDA + (kk + 1) * 8);
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            b[nxt][nb] = *reinterpret_cast<const f32x4*>(Bb + nb * 32 * LDA + (kk + 1) * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int nb = 0; nb < TN; ++nb)
+              acc[T.cls][m][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                  a[cur][m][r], b[cur][nb][r], acc[T.cls][m][nb], 0, 0, 0);
+      }
+      store_b(buf ^ 1);
+      if (t == 8) {            // every wave is done with this chunk's patch
+        __syncthreads();
+        store_patch();
+      }
+      __syncthreads();
+    });
+  }
+
+  // ---- epilogue: position (y0 + wrow0 + m, x0 + row), row = (reg&3) + 8*(reg>>2) + 4*lh;
+  // class c -> dx pixel (2a + c/2, 2b + c%2), column li
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+    BwdCoef cf{};
+    if (p.bs_partial) cf = bwd_coef(p, n, col);   // uniform
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t pix = ((size_t)n * p.Hout + 2 * (y0 + wrow0 + m) + (c >> 1)) * p.Wout +
+                           2 * (x0 + 4 * lh) + (c & 1);
+        float* o = p.out + pix * p.ldo + col;
+        if (p.accumulate) {        // uniform: all 16 reads in flight before the first add
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = o[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][m][nb][r] += old[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo] = acc[c][m][nb][r];
+        if (p.bs_partial) {   // uniform: sums of the next backward stage over the final values
+          const float* yb = p.bs_y + pix * p.ldo + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float y = yb[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo];
+            const float z = fmaf(y, cf.A, cf.B0);
+            const float gz = acc[c][m][nb][r] * cf.mk * (z > 0.f ? 1.f : p.slope);
+            s1[nb] += gz;
+            s2[nb] = fmaf(gz, (y - cf.mu) * cf.rs, s2[nb]);
+          }
+        }
+      }
+  }
+  if (p.bs_partial) {   // uniform; the K loop ended on a barrier: the patch area is free scratch
+    float2* red = reinterpret_cast<float2*>(Ps);
+    static_assert(WAVES_M * BN * 2 <= PPIX * LDA, "reduction scratch fits in the patch area");
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const float a = s1[nb] + __shfl_xor(s1[nb], 32, 64);
+      const float b = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = float2{a, b};
+    }
+    float2 out;
+    if (block_col_sums<BN, WAVES_M>(red, out))
+      p.bs_partial[((size_t)n * p.bs_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // First convolution of a decoder stage: y = conv3x3(cat(upsample2x(act(low)), act(skip))) with the
 // bilinear up-sampling done INSIDE the patch loader (Our_UNet/models/unet.py:215-231: the
 // reference materialises both the up-sampled tensor and the concatenation).  Source 0 is the
@@ -1046,7 +1266,42 @@ int launch_patch_s2(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+template <int BN, int WM, int WN, int TH>
+int launch_dgrad_s2_patch(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((TH + 1) * 33) * 36 + 2 * (size_t)BN * 36) * sizeof(float);
+  auto kern = conv_dgrad_s2_patch_kernel<BN, WM, WN, TH>;
+  UNET_SET_DYN_LDS(kern, lds);
+  const long long tiles = (long long)p.N * (p.Hl / TH) * (p.Wl / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_dgrad_s2_patch");
+  return UNET_OK;
+}
+
 }  // namespace
+
+// Stride-2 data gradient on the patch-staged kernel: p describes the dy grid (Hl x Wl, K = C0,
+// fp32) and dx = (2 Hl) x (2 Wl) x Ncols.  Returns 1 when the shape does not tile or too few
+// tiles would run (the caller keeps its gather-GEMM forms).  With p.bs_partial set the BSTATS
+// epilogue runs and *bs_tiles_out receives the reduction tiles per image.
+int launch_dgrad_s2_patch_auto(const IgemmParams& p0, hipStream_t stream, int* bs_tiles_out) {
+  static const int off = getenv("UNET_NO_PATCH_S2") ? 1 : 0;
+  IgemmParams p = p0;
+  if (off || p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
+  const long long pos = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  p.bs_tile0 = 0;
+  if (nc % 64 == 0 && p.Hl % 4 == 0 && pos / 128 * (nc / 64) >= 256) {
+    p.bs_tiles = p.Hl * p.Wl / 128;
+    if (bs_tiles_out) *bs_tiles_out = p.bs_partial ? p.bs_tiles : 0;
+    return launch_dgrad_s2_patch<64, 32, 64, 4>(p, stream);
+  }
+  if (nc == 32 && p.Hl % 8 == 0 && pos / 256 >= 256) {
+    p.bs_tiles = p.Hl * p.Wl / 256;
+    if (bs_tiles_out) *bs_tiles_out = p.bs_partial ? p.bs_tiles : 0;
+    return launch_dgrad_s2_patch<32, 64, 32, 8>(p, stream);
+  }
+  return 1;
+}
 
 // stride-2 3x3 forward whose OUTPUT tiles as 4 x 32 pixels, 16-channel chunks, standard taps
 bool patch_s2_applicable(const IgemmParams& p) {
