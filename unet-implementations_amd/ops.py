@@ -22,15 +22,24 @@ class KernelTimer:
     issued (`executed`: lower where a gradient is reassociated onto the low-resolution grid) and
     the HBM rates of the streaming kernels (`nbytes` = algorithmic bytes)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        # only: set of call-site classes ("conv" = 3x3 forward / data gradient, "wgrad") to
+        # bracket; None = every entry point.  An event pair costs ~2.5 us of stream time (the
+        # marker packets serialise the command processor), 0.8 ms per step over all ~330
+        # calls - so bench.py brackets only the roofline group inside its timed region.
+        self.only = only
         self.records = []  # (tag, flops, launches, start_event, end_event, executed, nbytes)
 
-    def begin(self):
+    def begin(self, kind=None):
+        if self.only is not None and kind not in self.only:
+            return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
     def end(self, tag, flops, launches, start, executed=None, nbytes=0.0):
+        if start is None:
+            return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.append((tag, flops, launches, start, ev,
@@ -191,7 +200,7 @@ def conv3x3_fwd(x0, x1, wf, bias, stride, out=None, bf16=False, wf3=None):
     assert wf.shape[0] == 9 and wf.shape[2] == C0 + C1
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = out if out is not None else _f32((N, Ho, Wo, Cout), x0)
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("conv") if _timer is not None else None
     pr = _prec(bf16)
     if pr == 3 and C0 == 3:
         pr = 0                      # the RGB stem has no split form (K = 27, HBM-bound)
@@ -240,7 +249,7 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     if _is_b16(dy):     # mixed-precision pipeline: bf16 tensors, bf16 matrix cores
         dx = out if out is not None else _b16((N, H, W, ccols), dy)
         assert dx.shape == (N, H, W, ccols) and _is_b16(dx)
-        t0 = _timer.begin() if _timer is not None else None
+        t0 = _timer.begin("conv") if _timer is not None else None
         check(lib().unet_conv3x3_bwd_data_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx),
                                               N, H, W, Cout, ccols, stride,
                                               1 if accumulate else 0, _stream()))
@@ -253,7 +262,7 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     pr = _prec(bf16)
     if nxt is not None and pr == 0:
         bs = nxt.c_struct()
-        t0 = _timer.begin() if _timer is not None else None
+        t0 = _timer.begin("conv") if _timer is not None else None
         check(lib().unet_conv3x3_bwd_data_bs(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N,
                                              H, W, Cout, ccols, stride, 1 if accumulate else 0,
                                              ctypes.byref(bs), _stream()))
@@ -261,7 +270,7 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
         if t0 is not None:
             _timer.end("conv_igemm", 2.0 * N * Ho * Wo * 9 * ccols * Cout, 1, t0)
         return dx
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("conv") if _timer is not None else None
     fn = getattr(lib(), "unet_conv3x3_bwd_data" + _SUFFIX[pr])
     if pr == 3:
         if wd3 is None:
@@ -288,7 +297,7 @@ def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None, bf16=False):
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     nbytes = lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride)
     ws = _ws(nbytes, x)
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("wgrad") if _timer is not None else None
     pr = _prec(bf16)
     fn = getattr(lib(), "unet_conv3x3_bwd_weight" + _SUFFIX[pr])
     check(fn(_ptr(x), Cx, _ptr(dy), _ptr(dw_oihw), ci_offset, cin_total, _ptr(db), _ptr(ws),
@@ -470,7 +479,7 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
     fwd = lib().unet_conv_in_fwd_b16 if b16 else lib().unet_conv_in_fwd
     fin = lib().unet_conv_in_stats_finalize_b16 if b16 else lib().unet_conv_in_stats_finalize
     px = ctypes.c_int(0)
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("conv") if _timer is not None else None
     if u8 is not None:
         assert s1 is None and ksize == 3 and stride == 1
         m3, s3 = u8.c_mean_std()
@@ -506,7 +515,7 @@ def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask):
     st = _f32((4, N, Cout), skip.x)
     ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1), skip.x)
     px = ctypes.c_int(0)
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("conv") if _timer is not None else None
     check(lib().unet_conv_up_in_fwd(rl, rs, slope, _ptr(wf), _ptr(bias), _ptr(y), _ptr(ws),
                                     ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     if t0 is not None:
@@ -524,7 +533,7 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
         Cout = dy.shape[3]
         ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, 3, Cout, 1), dy)
         m3, s3 = x.c_mean_std()
-        t0 = _timer.begin() if _timer is not None else None
+        t0 = _timer.begin("wgrad") if _timer is not None else None
         check(lib().unet_stem_u8_bwd_weight(_ptr(x.x), m3, s3, _ptr(dy), _ptr(dw_oihw), _ptr(ws),
                                             ws.numel(), N, H, W, Cout, _stream()))
         if t0 is not None:
@@ -537,7 +546,7 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
     ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride), dy)
     b16 = _is_b16(dy)
     fn = lib().unet_conv_in_bwd_weight_b16 if b16 else lib().unet_conv_in_bwd_weight
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("wgrad") if _timer is not None else None
     check(fn(rx, slope, _ptr(dy), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], ksize, stride,
              _ptr(ws), ws.numel(), N, H, W, Cout, _stream()))
     if t0 is not None:
@@ -582,7 +591,7 @@ def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
     assert D.shape[:3] == x.shape[:3] and dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     ws = _ws(lib().unet_conv3x3_up_bwd_weight_workspace_bytes(N, h, w, Cx, Cout), D)
     fn = lib().unet_conv3x3_up_bwd_weight_b16 if _is_b16(D) else lib().unet_conv3x3_up_bwd_weight
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("wgrad") if _timer is not None else None
     check(fn(rx, slope, _ptr(D), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], _ptr(ws), ws.numel(),
              N, h, w, Cout, _stream()))
     if t0 is not None:   # algorithmic FLOPs: the 3x3 weight gradient on the up-sampled grid
@@ -602,7 +611,7 @@ def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False, nxt
     b16 = _is_b16(D)
     g = out if out is not None else (_b16 if b16 else _f32)((N, h, w, ccols), D)
     fn = lib().unet_conv3x3_up_bwd_data_b16 if b16 else lib().unet_conv3x3_up_bwd_data
-    t0 = _timer.begin() if _timer is not None else None
+    t0 = _timer.begin("conv") if _timer is not None else None
     if nxt is not None and not b16:
         bs = nxt.c_struct()
         check(lib().unet_conv3x3_up_bwd_data_bs(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N,
