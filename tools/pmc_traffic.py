@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-GROUP = re.compile(r"conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel")
+GROUP = re.compile(r"conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel")
 
 
 def per_launch(path, counter):
@@ -28,8 +28,7 @@ def per_launch(path, counter):
 
 fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 write, nw = per_launch(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "conv_patch_f32_kernel | conv_igemm_kernel | conv_igemm_rf_kernel | "
-                 "conv_dgrad_s2_kernel (3x3 forward + data gradient)",
+out = {"kernel": GROUP.pattern.replace("|", " | ") + " (3x3 forward + data gradient)",
        "launches_profiled": nf,
        "fetch_bytes_per_launch_corrected": 2.0 * fetch,
        "write_bytes_per_launch": write,

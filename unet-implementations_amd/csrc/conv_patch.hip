@@ -546,12 +546,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
   for (int i = 0; i < P_PASSES; ++i) {
     const int slot = (tid + 256 * i) % P_SLOTS;
     const int pix = slot / SEG, seg = slot % SEG;
-    const int prow = pix / PWC, pcol = pix - prow * PWC;
+    // slots walk the LDS order (linear, conflict-free writes); the 64-B global segments of
+    // neighbouring slots then lie two pixels apart, which costs nothing (a segment is the unit)
+    const int prow = pix / PWC, idx = pix - prow * PWC;
+    const int pcol = idx < ODD0 ? 2 * idx : 2 * (idx - ODD0) + 1;
     const int iy = 2 * y0 - 1 + prow, ix = 2 * x0 - 1 + pcol;
     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     pp_lin[i] = ok ? ((n * H + iy) * W + ix) * 4 : 0;   // x channel count = byte offset
     pp_oob[i] = (ok ? 0u : 0x80000000u) | (unsigned)(seg * 16);
-    pp_lds[i] = (prow * PWC + ((pcol & 1) ? ODD0 + (pcol >> 1) : (pcol >> 1))) * LDA + seg * 4;
+    pp_lds[i] = pix * LDA + seg * 4;
   }
   unsigned wslot_off[B_PASSES];
   int wslot_lds[B_PASSES];
