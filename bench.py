@@ -48,7 +48,8 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
     data-gradient launches), from the KernelTimer summary of the TIMED region (`summ`, which
     brackets only that group: an event pair per call costs stream time), and the per-group
     table from the summary of a separate pass with every entry point bracketed (`gsumm`)."""
-    k = next((summ[t] for t in CONV_GROUPS if t in summ), None)
+    pref = {"fp32": "conv_igemm", "bf16": "conv_igemm_bf16", "bf16x3": "conv_igemm_bf16x3"}[matmul]
+    k = summ.get(pref) or next((summ[t] for t in CONV_GROUPS if t in summ), None)
     if gsumm is None:
         gsumm, gsteps = summ, steps
     groups = {}
@@ -83,8 +84,8 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
                   + {"fp32": "conv_patch_f32_kernel, conv_patch_up_kernel, conv_patch_s2_kernel, "
                              "conv_c32_kernel, conv_igemm_kernel, conv_dgrad_s2_kernel",
                      "bf16": "conv_igemm_bf16_kernel on bf16 tensors",
-                     "bf16x3": "conv_patch_split_kernel, conv_igemm_split_kernel + fp32 "
-                               "fallbacks"}[matmul] + "): "
+                     "bf16x3": "conv_patch_split_kernel on the fused pipeline + the fp32 kernels "
+                               "for the shapes it does not tile (stride 2, 1/32 resolution)"}[matmul] + "): "
                   f"{k['flops'] / steps * 1e-12:.3f} of the step's "
                   f"{total / steps * 1e-12:.3f} algorithmic conv TFLOP",
         "launches_per_step": k["launches"] / steps,
@@ -280,43 +281,57 @@ def main():
         raise SystemExit("loss is NaN")
     gsumm, gsteps = groups_pass() if timer is not None else (None, None)
 
-    # Beside the fp32-matrix-core headline: the same K steps with the convolutions in the
-    # split-bf16 ("bf16x3") operand mode, which holds the same reference fixtures and tolerances
-    # (tests/test_net_gpu.py, profiles/r01_bf16x3_accuracy_vs_fp64.txt).  Reported, never `value`.
-    alt = None
-    if args.matmul == "fp32" and not args.no_alt:
-        model.matmul_precision = "bf16x3"
-        for _ in range(max(2, args.warmup // 2)):
-            step()
-        fence()
-        alt_timer = None if args.no_kernel_timer else ua.ops.KernelTimer(only={"conv"})
-        ua.ops.set_timer(alt_timer)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        fence()
-        dt_alt = time.perf_counter() - t1
-        ua.ops.set_timer(None)
-        if world > 1:
-            t = torch.tensor([dt_alt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_alt = t.item()
-        alt = {"bf16x3": {
-            "value": args.batch * world * args.steps / dt_alt, "unit": "images/s",
-            "ms_per_step": 1e3 * dt_alt / args.steps,
-            "dtype": "f32 tensors; conv operands split into 3 bf16 terms, 6 bf16 MFMA products "
+    # Beside the fp32-matrix-core headline, the same K steps in the two other operand modes
+    # (reported, never `value`): the split-bf16 ("bf16x3") mode, which holds the same reference
+    # fixtures and tolerances as fp32 (tests/test_net_gpu.py,
+    # profiles/r01_bf16x3_accuracy_vs_fp64.txt), and BASELINE config 4, bf16 mixed precision
+    # (bf16 layer tensors + bf16 MFMA, fp32 accumulate / statistics / master weights;
+    # tests/test_bf16_gpu.py holds it against the oracle on bf16-rounded operands).
+    ALT = {"bf16x3": dict(
+               dtype="f32 tensors; conv operands split into 3 bf16 terms, 6 bf16 MFMA products "
                      "per multiply, f32 accumulate",
-            "parity": "same fixtures and tolerances as fp32 (1e-4 logits, bit-exact argmax off "
-                      "ties); per-conv error vs fp64 <= the fp32 MFMA kernels'"}}
-        if alt_timer is not None:
-            asumm, asteps = groups_pass(2)
-        if alt_timer is not None and rank == 0:
-            roof, groups = roofline_of(alt_timer.summary(), args.steps, "bf16x3", args, asumm, asteps)
-            if roof:
-                roof["note"] = ("peak = dense bf16 MFMA peak / 6 products per multiply; the chip "
-                                "holds ~1.8 GHz under this load (DESIGN.md section 3b)")
-                alt["bf16x3"]["roofline"] = roof
-            alt["bf16x3"]["kernel_groups"] = groups
+               parity="same fixtures and tolerances as fp32 (1e-4 logits, bit-exact argmax off "
+                      "ties); per-conv error vs fp64 <= 2.5e-6",
+               note="peak = dense bf16 MFMA peak / 6 products per multiply; the chip holds "
+                    "~1.8 GHz under this load (DESIGN.md section 3d)"),
+           "bf16": dict(
+               dtype="bf16 layer tensors and MFMA operands; f32 accumulate, statistics, weights, "
+                     "optimizer (BASELINE config 4)",
+               parity="every entry point and the whole net against the oracle evaluated on "
+                      "bf16-rounded operands with bf16 stores (tests/test_bf16_gpu.py)",
+               note="peak = dense bf16 MFMA peak; this mode is bound by HBM / the gather-GEMM "
+                    "loaders, not by the matrix cores")}
+    alt = None
+    if args.matmul == "fp32" and not args.no_alt and not args.clip:
+        alt = {}
+        for mode in ("bf16x3", "bf16"):
+            model.matmul_precision = mode
+            for _ in range(max(2, args.warmup // 2)):
+                step()
+            fence()
+            alt_timer = None if args.no_kernel_timer else ua.ops.KernelTimer(only={"conv"})
+            ua.ops.set_timer(alt_timer)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            fence()
+            dt_alt = time.perf_counter() - t1
+            ua.ops.set_timer(None)
+            if world > 1:
+                t = torch.tensor([dt_alt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_alt = t.item()
+            alt[mode] = {"value": args.batch * world * args.steps / dt_alt, "unit": "images/s",
+                         "ms_per_step": 1e3 * dt_alt / args.steps, "dtype": ALT[mode]["dtype"],
+                         "parity": ALT[mode]["parity"]}
+            if alt_timer is not None:
+                asumm, asteps = groups_pass(2)
+            if alt_timer is not None and rank == 0:
+                roof, groups = roofline_of(alt_timer.summary(), args.steps, mode, args, asumm, asteps)
+                if roof:
+                    roof["note"] = ALT[mode]["note"]
+                    alt[mode]["roofline"] = roof
+                alt[mode]["kernel_groups"] = groups
         model.matmul_precision = args.matmul
 
     if rank == 0:

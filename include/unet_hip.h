@@ -329,6 +329,15 @@ int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, float slope
                      const float* bias, int ksize, int stride, float* y, void* workspace,
                      size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
                      unet_stream_t stream);
+/* The same in the split-bf16 ("bf16x3") operand mode: fp32 tensors, fp32-class accuracy on the
+ * bf16 matrix cores.  w3 = the pre-split planes of unet_pack_conv3x3_weights_bf16x3 (forward
+ * layout; may be NULL for ksize 1).  Stride-1 3x3 shapes that tile as 4 x 32 pixels run the
+ * split patch kernel with the activation applied before the split; other shapes run the fp32
+ * kernels (same results to fp32 rounding). */
+int unet_conv_in_fwd_bf16x3(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                            const float* w, const uint16_t* w3, const float* bias, int ksize,
+                            int stride, float* y, void* workspace, size_t workspace_bytes,
+                            int* stats_px_out, int N, int H, int W, int Cout, unet_stream_t stream);
 /* InstanceNorm statistics of y [N][HoWo][Cout] from the summaries unet_conv_in_fwd left in
  * `workspace` (stats_px > 0: a few-microsecond merge) or from y itself (stats_px == 0), and the
  * folded coefficients for y's consumers: mean, rstd, alpha_out, beta_out [N][Cout]
@@ -425,6 +434,12 @@ typedef struct unet_bwd_stats {
 int unet_conv3x3_bwd_data_bs(const float* dy, const float* wd, int Cin_total, int ci_offset,
                              float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
                              int accumulate, unet_bwd_stats* bs, unet_stream_t stream);
+/* unet_conv3x3_bwd_data_bs in the split-bf16 mode (wd3 = pre-split planes, data-gradient
+ * layout); bs may be NULL (no reductions wanted). */
+int unet_conv3x3_bwd_data_bs_bf16x3(const float* dy, const float* wd, const uint16_t* wd3,
+                                    int Cin_total, int ci_offset, float* dx, int N, int H, int W,
+                                    int Cout, int Ccols, int stride, int accumulate,
+                                    unet_bwd_stats* bs, unet_stream_t stream);
 int unet_conv3x3_up_bwd_data_bs(const float* D, const float* wd, int Cin_total, int ci_offset,
                                 float* g, int N, int h, int w, int Cout, int Ccols, int accumulate,
                                 unet_bwd_stats* bs, unet_stream_t stream);

@@ -139,6 +139,72 @@ def test_conv_in_fwd(ua, case, with_mask):
     assert (st[3].cpu().double() - beta_ref).abs().max() <= 5e-5 * scale
 
 
+X3_FUSED_CASES = [  # shapes the split patch kernel takes in the fused pipeline
+    (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # 128 columns, two sources
+    (2, 256, 256, 64, 0, 64, 1, 3, True, False),     # 64 columns, 8-row tiles
+    (1, 128, 256, 64, 0, 64, 1, 3, True, False),     # 64 columns, 4-row tiles
+    (2, 256, 256, 32, 32, 32, 1, 3, False, True),    # 32 columns x 8 rows; plain src0
+    (2, 16, 16, 64, 0, 64, 1, 3, True, False),       # too few tiles: fp32 kernel behind the same entry
+]
+
+
+@pytest.mark.parametrize("case", X3_FUSED_CASES)
+def test_conv_in_fwd_split_bf16(ua, case):
+    """The split-bf16 operand mode behind the fused entry point: fp32-class results (same
+    tolerance as the fp32 test) with the activation applied before the operand split."""
+    N, H, W, C0, C1, Cout, stride, ks, act0, act1 = case
+    x0 = rnd(N, C0, H, W, seed=1)
+    x1 = rnd(N, C1, H, W, seed=2) if C1 else None
+    c0 = coeffs(N, C0, 10) if act0 else None
+    c1 = coeffs(N, C1, 20) if (act1 and C1) else None
+    w = rnd(Cout, C0 + C1, ks, ks, seed=3, scale=(2.0 / (ks * ks * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma = rnd(Cout, seed=5) * 0.2 + 1.0
+    beta = rnd(Cout, seed=6) * 0.2
+    keep = torch.rand(N, Cout, generator=torch.Generator().manual_seed(7)) < 0.7
+    mask = keep.float() / 0.7
+    a0 = act_ref(x0, *c0) if c0 else x0.double()
+    parts = [a0]
+    if C1:
+        parts.append(act_ref(x1, *c1) if c1 else x1.double())
+    y_ref = F.conv2d(torch.cat(parts, 1), w.double(), b.double(), stride=stride, padding=1)
+    mean_ref = y_ref.mean(dim=(2, 3))
+    rstd_ref = 1.0 / torch.sqrt(y_ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+    wk, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    wf3, _ = ua.ops.pack_conv3x3_weights_bf16x3(w.to(DEV))
+    s0 = make_src(ua, x0, c0)
+    s1 = make_src(ua, x1, c1) if C1 else None
+    y, st = ua.ops.conv_in_fwd(s0, s1, SLOPE, wk, b.to(DEV), ks, stride, gamma.to(DEV),
+                               beta.to(DEV), 1e-5, mask.to(DEV), w3=wf3)
+    check(from_nhwc(y), y_ref, 2e-5, "y (bf16x3)")
+    assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), rstd_ref, 5e-5, "rstd (bf16x3)")
+    # against the fp32 kernel of the same entry point: both within fp32 rounding of fp64
+    y32, _ = ua.ops.conv_in_fwd(s0, s1, SLOPE, wk, b.to(DEV), ks, stride, gamma.to(DEV),
+                                beta.to(DEV), 1e-5, mask.to(DEV))
+    check(y, y32, 2e-5, "bf16x3 vs fp32 MFMA")
+
+
+@pytest.mark.parametrize("case", [(1, 256, 256, 32, 128, 1, False), (2, 256, 256, 64, 64, 1, True),
+                                  (2, 256, 256, 32, 32, 1, False)])
+def test_data_gradient_split_bf16_emits_reductions(ua, case):
+    N, H, W, Cout, Ccols, stride, acc = case
+    dy = to_nhwc(rnd(N, Cout, H, W, seed=1))
+    w = rnd(Cout, Ccols, 3, 3, seed=2, scale=0.1)
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    _, wd3 = ua.ops.pack_conv3x3_weights_bf16x3(w.to(DEV))
+    y, st, gamma, beta, mask = _next_norm(ua, N, Ccols, H, W, 10)
+    base = to_nhwc(rnd(N, Ccols, H, W, seed=3)) if acc else None
+    ref = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, stride,
+                                  out=base.clone() if acc else None, accumulate=acc)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, stride, out=base.clone() if acc else None,
+                                accumulate=acc, nxt=nn, bf16="bf16x3", wd3=wd3)
+    check(g, ref, 2e-5, "bf16x3 data gradient vs fp32 MFMA")
+    assert nn.tiles > 0
+    _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
+
+
 WGRAD_CASES = [  # (N, H, W, Cx, Cout, stride, ksize, act)
     (2, 12, 64, 32, 32, 1, 3, True),     # 32x32 tile
     (1, 16, 32, 64, 64, 1, 3, True),     # 64x64 tile

@@ -1305,7 +1305,10 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   // b16: dy and dx are bf16 tensors (mixed-precision pipeline; prec is then 1)
   const long long es = b16 ? 2 : 4;
   if (bs) bs->tiles_out = 0;
-  const bool use_bs = bs && prec == 0 && !b16 && bs->y && bs->mean && bs->rstd && bs->gamma &&
+  // split mode with reductions (fused pipeline): only the stride-1 patch shapes have a split
+  // kernel with that epilogue; everything else runs the fp32 kernels
+  if (prec == 3 && bs && stride == 2) prec = 0;
+  const bool use_bs = bs && (prec == 0 || prec == 3) && !b16 && bs->y && bs->mean && bs->rstd && bs->gamma &&
                       bs->beta && bs->partial &&
                       bs->partial_bytes >= (size_t)N * ceil_div(H * W, 64) * Ccols * sizeof(float2);
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
@@ -1364,8 +1367,12 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
     if (b16) return dispatch_igemm_b16(p, stream, nullptr);
     if (prec == 1) return dispatch_igemm_bf16(p, stream);
-    if (prec == 3) return dispatch_igemm_split(p, stream);
-    int rc;
+    if (prec == 3 && !bs) return dispatch_igemm_split(p, stream);
+    int rc = 1;
+    if (prec == 3 && patch_split_applicable(p))   // fused pipeline, split mode (else: fp32 below)
+      rc = launch_patch_split_fused_auto(p, stream, nullptr, use_bs ? &bs_px : nullptr);
+    if (rc != 1) {
+    } else
     if (c32_applicable(p))   // conv_c32.hip: 32 -> 32 channels
       rc = launch_c32(p, 0, stream, use_bs ? &bs_px : nullptr);
     else if (rf_applicable(p) && (Cout == 32 || !patch_f32_applicable(p) || p.Hin % 8 != 0))
@@ -1454,6 +1461,17 @@ extern "C" int unet_conv3x3_bwd_data_bs(const float* dy, const float* wd, int Ci
                                         unet_stream_t stream) {
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
                                accumulate, 0, (hipStream_t)stream, nullptr, 0, bs);
+}
+
+// Split-bf16 mode of the fused pipeline (wd3 = pre-split planes, data-gradient layout); bs may
+// be null (no reductions wanted: the plain split kernels run)
+extern "C" int unet_conv3x3_bwd_data_bs_bf16x3(const float* dy, const float* wd,
+                                               const uint16_t* wd3, int Cin_total, int ci_offset,
+                                               float* dx, int N, int H, int W, int Cout, int Ccols,
+                                               int stride, int accumulate, unet_bwd_stats* bs,
+                                               unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
+                               accumulate, 3, (hipStream_t)stream, wd3, 0, bs);
 }
 
 // dy and dx are bf16 tensors, bf16 matrix cores (mixed-precision pipeline)
@@ -1572,10 +1590,13 @@ extern "C" size_t unet_conv_in_fwd_workspace_bytes(int N, int H, int W, int Cout
 
 // b16: the layer tensors (sources other than the RGB image, and y) are bf16 in HBM and the
 // contraction runs on the bf16 matrix cores (mixed-precision pipeline); else fp32 / fp32 MFMA.
+// w3 != nullptr: the split-bf16 mode - shapes the split patch kernel tiles run there (fp32
+// tensors, three-term operands, fp32-class accuracy), everything else on the fp32 kernels.
 static int conv_in_fwd_impl(const unet_act_src* s0, const unet_act_src* s1, float slope,
                             const float* w, const float* bias, int ksize, int stride, float* y,
                             void* workspace, size_t workspace_bytes, int* stats_px_out, int N,
-                            int H, int W, int Cout, hipStream_t stream, int b16) {
+                            int H, int W, int Cout, hipStream_t stream, int b16,
+                            const uint16_t* w3 = nullptr) {
   const size_t es = b16 ? 2 : 4;   // bytes per activation element
   UNET_REQUIRE(s0 && s0->x && w && y && workspace && stats_px_out, "conv_in_fwd: null pointer");
   UNET_REQUIRE(ksize == 3 || ksize == 1, "conv_in_fwd: kernel size %d unsupported", ksize);
@@ -1668,6 +1689,15 @@ static int conv_in_fwd_impl(const unet_act_src* s0, const unet_act_src* s1, floa
         rc = dispatch_igemm_b16(p, stream, &px);
       } else {
         fill_fwd_taps(p, stride);
+        rc = 1;
+        if (w3 && stride == 1 && patch_split_applicable(p)) {   // split-bf16 patch kernel
+          p.w3 = reinterpret_cast<const __bf16*>(w3);
+          p.w3_plane = 9 * Cout * Cin;
+          p.w3_bytes = (unsigned)((long long)3 * p.w3_plane * 2);
+          rc = launch_patch_split_fused_auto(p, stream, &px, nullptr);
+        }
+        if (rc != 1) {
+        } else
         // K = 32: row-fused kernel with the weights resident in LDS; wider K: the patch kernel
         if (stride == 1 && c32_applicable(p))   // conv_c32.hip: 32 -> 32 channels
           rc = launch_c32(p, 1, stream, &px);
@@ -1692,6 +1722,18 @@ extern "C" int unet_conv_in_fwd(const unet_act_src* s0, const unet_act_src* s1, 
                                 int H, int W, int Cout, unet_stream_t stream) {
   return conv_in_fwd_impl(s0, s1, slope, w, bias, ksize, stride, y, workspace, workspace_bytes,
                           stats_px_out, N, H, W, Cout, (hipStream_t)stream, 0);
+}
+
+// Split-bf16 mode of the fused pipeline: fp32 tensors; w3 = the pre-split weight planes of
+// unet_pack_conv3x3_weights_bf16x3 (forward layout).  Same arguments otherwise.
+extern "C" int unet_conv_in_fwd_bf16x3(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                                       const float* w, const uint16_t* w3, const float* bias,
+                                       int ksize, int stride, float* y, void* workspace,
+                                       size_t workspace_bytes, int* stats_px_out, int N, int H,
+                                       int W, int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(w3 || ksize != 3, "conv_in_fwd_bf16x3: the pre-split weight planes are null");
+  return conv_in_fwd_impl(s0, s1, slope, w, bias, ksize, stride, y, workspace, workspace_bytes,
+                          stats_px_out, N, H, W, Cout, (hipStream_t)stream, 0, w3);
 }
 
 // Mixed-precision pipeline (BASELINE config 4): the sources (except the fp32 RGB image) and y

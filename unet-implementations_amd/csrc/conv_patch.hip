@@ -34,7 +34,10 @@ __device__ __forceinline__ void for_range_p(F&& f) {
 // double-buffered per tap.  LDS: patch 3 x 204 x 48 B + weights 2 x 3 x BN x 48 B (66 KB at
 // BN = 128: two workgroups per CU).
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH>
+// ACT / STATS / BSTATS: the fused layer pipeline on this kernel, exactly as in
+// conv_patch_f32_kernel below (activation on load BEFORE the split, statistics of the output,
+// reductions of the next backward stage) - the split mode of the fused pipeline.
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmParams p) {
   constexpr int LDA = 24;                    // bf16 per LDS row: 16 + 8 pad (48 B)
   constexpr int TW = 32, PW = TW + 2;
@@ -111,6 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
 
+  // ACT: coefficients of this thread's four channels (slot & 3 is the same for every pass)
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
   auto load_patch = [&](int chunk) {
     const int c = chunk * 16;
     const bool first = c < p.C0;
@@ -123,10 +129,25 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
       const unsigned off = ((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i];
       pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
+    if (ACT) {
+      const float* al = first ? p.act0_alpha : p.act1_alpha;
+      const float* be = first ? p.act0_beta : p.act1_beta;
+      if (al) {   // uniform
+        const size_t o = (size_t)n * Cs + (first ? c : c - p.C0) + (tid & 3) * 4;
+        ca = *reinterpret_cast<const f32x4*>(al + o);
+        cb = *reinterpret_cast<const f32x4*>(be + o);
+        cs = p.slope;
+      } else {    // plain source: z = v, slope 1 = identity
+        ca = f32x4{1.f, 1.f, 1.f, 1.f};
+        cb = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = 1.f;
+      }
+    }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i) {
+      if (ACT) pr[i] = act4(pr[i], ca, cb, cs, (pp_oob[i] >> 31) == 0u);
       bf16x4 h, m, l;
       split3(pr[i], h, m, l);
       __bf16* d = Ps + pp_lds[i];
@@ -227,14 +248,43 @@ __global__ __launch_bounds__(256, 2) void conv_patch_split_kernel(const IgemmPar
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv + old[r];
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv + old[r];
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r] + bv;
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[m][nb][r];
     }
+  }
+  constexpr int WAVES_M = 4 / WAVES_N;
+  static_assert(WAVES_M * BN * 8 <= 3 * P_PLANE * 2, "reduction scratch fits in the patch area");
+  if (BSTATS && p.bs_partial) {   // uniform: reductions of the NEXT backward stage (IgemmParams)
+    float2* red = reinterpret_cast<float2*>(Ps);   // the K loop ended on a barrier
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const int col = n0 + wn0 + nb * 32 + li;
+      const BwdCoef cf = bwd_coef(p, n, col);
+      const float* yb = p.bs_y + (((size_t)n * H + (y0 + wrow0)) * W + x0 + 4 * lh) * p.ldo + col;
+      const float2 mine = wave_bwd_stats<TM>(
+          cf, p.slope, [&](int m, int r) { return acc[m][nb][r]; },
+          [&](int m, int r) { return yb[((size_t)m * W + (r & 3) + 8 * (r >> 2)) * p.ldo]; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_sums<BN, WAVES_M>(red, out))
+      p.bs_partial[((size_t)n * p.bs_tiles + p.bs_tile0 + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
+  }
+  if (STATS && p.stats) {   // uniform; the patch area is free scratch
+    float2* red = reinterpret_cast<float2*>(Ps);
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r]; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
+      p.stats[((size_t)n * p.stats_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
   }
 }
 
@@ -1235,11 +1285,11 @@ int launch_patch_up(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-template <int BN, int WM, int WN, int TH>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false>
 int launch_patch_split(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds =
       (3 * (size_t)((TH + 2) * 34) * 24 + 2 * 3 * (size_t)BN * 24) * sizeof(__bf16);
-  auto kern = conv_patch_split_kernel<BN, WM, WN, TH>;
+  auto kern = conv_patch_split_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS>;
   UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
@@ -1417,6 +1467,45 @@ int launch_patch_up_auto(const IgemmParams& p0, hipStream_t stream, int* stats_p
     return launch_patch_up<32, 64, 32, 8>(p, stream);
   }
   return 1;
+}
+
+// The split mode of the fused layer pipeline: stats_px != nullptr = fused forward (activation
+// on load, statistics epilogue), bs_px != nullptr = data gradient with the BSTATS epilogue.
+// Returns 1 when no tile shape fills the chip (the caller runs the fp32 fused kernel instead).
+int launch_patch_split_fused_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px,
+                                  int* bs_px) {
+  IgemmParams p = p0;
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  const bool fwd = stats_px != nullptr;
+  const bool tall = p.Hin % 8 == 0;
+  int px = 0;
+  int cls = 0;   // 1: <128,64,64,4>  2: <64,128,32,8>  3: <64,64,32,4>  4: <32,64,32,8>
+  if (nc % 128 == 0 && (M / 128) * (nc / 128) >= 512) { cls = 1; px = 128; }
+  else if (nc % 64 == 0 && tall && (M / 256) * (nc / 64) >= 512) { cls = 2; px = 256; }
+  else if (nc % 64 == 0 && (M / 128) * (nc / 64) >= 256) { cls = 3; px = 128; }
+  else if (nc == 32 && tall && (M / 256) >= 512) { cls = 4; px = 256; }
+  if (!cls) return 1;
+  if (fwd) {
+    *stats_px = p.stats ? px : 0;
+    p.stats_tiles = p.Hin * p.Win / px;
+    p.bs_partial = nullptr;
+    switch (cls) {
+      case 1: return launch_patch_split<128, 64, 64, 4, true, true, false>(p, stream);
+      case 2: return launch_patch_split<64, 128, 32, 8, true, true, false>(p, stream);
+      case 3: return launch_patch_split<64, 64, 32, 4, true, true, false>(p, stream);
+      default: return launch_patch_split<32, 64, 32, 8, true, true, false>(p, stream);
+    }
+  }
+  p.stats = nullptr;
+  if (bs_px && p.bs_partial) { *bs_px = px; p.bs_tiles = p.Hin * p.Win / px; p.bs_tile0 = 0; }
+  else { if (bs_px) *bs_px = 0; p.bs_partial = nullptr; }
+  switch (cls) {
+    case 1: return launch_patch_split<128, 64, 64, 4, false, false, true>(p, stream);
+    case 2: return launch_patch_split<64, 128, 32, 8, false, false, true>(p, stream);
+    case 3: return launch_patch_split<64, 64, 32, 4, false, false, true>(p, stream);
+    default: return launch_patch_split<32, 64, 32, 8, false, false, true>(p, stream);
+  }
 }
 
 int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream) {

@@ -260,15 +260,21 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
     dx = out if out is not None else _f32((N, H, W, ccols), dy)
     assert dx.shape == (N, H, W, ccols)
     pr = _prec(bf16)
-    if nxt is not None and pr == 0:
+    if nxt is not None and pr in (0, 3):
         bs = nxt.c_struct()
         t0 = _timer.begin("conv") if _timer is not None else None
-        check(lib().unet_conv3x3_bwd_data_bs(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx), N,
-                                             H, W, Cout, ccols, stride, 1 if accumulate else 0,
-                                             ctypes.byref(bs), _stream()))
+        if pr == 3:
+            check(lib().unet_conv3x3_bwd_data_bs_bf16x3(
+                _ptr(dy), _ptr(wd), _ptr(wd3), cin_total, ci_offset, _ptr(dx), N, H, W, Cout,
+                ccols, stride, 1 if accumulate else 0, ctypes.byref(bs), _stream()))
+        else:
+            check(lib().unet_conv3x3_bwd_data_bs(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx),
+                                                 N, H, W, Cout, ccols, stride,
+                                                 1 if accumulate else 0, ctypes.byref(bs),
+                                                 _stream()))
         nxt.tiles = bs.tiles_out
         if t0 is not None:
-            _timer.end("conv_igemm", 2.0 * N * Ho * Wo * 9 * ccols * Cout, 1, t0)
+            _timer.end("conv_igemm" + _GROUP[pr], 2.0 * N * Ho * Wo * 9 * ccols * Cout, 1, t0)
         return dx
     t0 = _timer.begin("conv") if _timer is not None else None
     fn = getattr(lib(), "unet_conv3x3_bwd_data" + _SUFFIX[pr])
@@ -450,12 +456,14 @@ def _act(a):
     return a, ctypes.byref(st)
 
 
-def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b16=False):
+def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b16=False,
+                w3=None):
     """Fused layer forward: y = conv(cat(act(s0), act(s1))) + bias and the InstanceNorm
     statistics of y.  Returns (y, st) with st = [mean, rstd, alpha, beta] as [4, N, Cout];
     alpha / beta carry the dropout `mask` [N, Cout] (or None) folded in.
     b16: the mixed-precision pipeline - y (and the sources other than the fp32 RGB image) are
-    bf16 tensors, bf16 matrix cores, fp32 statistics."""
+    bf16 tensors, bf16 matrix cores, fp32 statistics.
+    w3 (pre-split weight planes): the split-bf16 operand mode on fp32 tensors."""
     u8 = s0 if isinstance(s0, U8Image) else None
     if u8 is None:
         s0, r0 = _act(s0)
@@ -485,11 +493,16 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
         m3, s3 = u8.c_mean_std()
         check(lib().unet_stem_u8_fwd(_ptr(u8.x), m3, s3, _ptr(w), _ptr(bias), _ptr(y), _ptr(ws),
                                      ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
+    elif w3 is not None and not b16 and C0 != 3:
+        check(lib().unet_conv_in_fwd_bf16x3(r0, r1, slope, _ptr(w), _ptr(w3), _ptr(bias), ksize,
+                                            stride, _ptr(y), _ptr(ws), ws.numel(),
+                                            ctypes.byref(px), N, H, W, Cout, _stream()))
     else:
         check(fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y), _ptr(ws),
                   ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     if t0 is not None:   # the convolution launch alone (its epilogue includes the statistics)
-        _timer.end("conv_stem_fwd" if C0 == 3 else ("conv_igemm_bf16" if b16 else "conv_igemm"),
+        _timer.end("conv_stem_fwd" if C0 == 3 else
+                   ("conv_igemm_bf16" if b16 else ("conv_igemm_bf16x3" if w3 is not None else "conv_igemm")),
                    2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout, 1, t0)
     check(fin(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma), _ptr(beta), eps, _ptr(mask),
               _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), N, Ho * Wo, Cout, _stream()))

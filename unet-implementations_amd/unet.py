@@ -477,10 +477,13 @@ class _UNetFunction(torch.autograd.Function):
         # layer tensors themselves are bf16 in HBM); 0 <= slope <= 1 (lrelu(z) = max(z, slope z)),
         # one slope for the whole net.  Anything else runs the stand-alone passes.
         slope = layers[0].slope
-        fused = bf16 in ("fp32", "bf16") and model.fused_pipeline and \
+        fused = model.fused_pipeline and \
             len({l.slope for l in layers}) == 1 and 0.0 <= slope <= 1.0 and \
             not (bf16 == "bf16" and fusion is not None)
         b16 = fused and bf16 == "bf16"
+        # split-bf16 mode on the fused pipeline: the stride-1 3x3 layers that tile as 4 x 32
+        # pixels run the split patch kernel (forward + data gradient), the rest the fp32 kernels
+        x3 = fused and bf16 == "bf16x3"
 
         def run_layer_fused(l, s0, s1):
             """s0 / s1: ops.Act operands; returns the Act of this layer's output."""
@@ -491,12 +494,14 @@ class _UNetFunction(torch.autograd.Function):
             else:
                 k = packed[id(w)]
                 wk, wd = table.wf[k], table.wd[k]
+            w3 = table.wf3[k] if (x3 and l.ksize == 3) else None
             m = mask_of[id(l)]
             y, st = ops.conv_in_fwd(s0, s1, slope, wk, l.conv.bias.detach(), l.ksize, l.stride,
                                     l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps, m,
-                                    b16=b16)
+                                    b16=b16, w3=w3)
             if need_grad:
-                saved.append(dict(layer=l, x0=s0, x1=s1, y=y, st=st, mask=m, wd=wd, wd3=None))
+                saved.append(dict(layer=l, x0=s0, x1=s1, y=y, st=st, mask=m, wd=wd,
+                                  wd3=table.wd3[k] if w3 is not None else None))
             return ops.Act(y, st[2], st[3])
 
         def run_up_layer_fused(l, low, skip):
@@ -504,7 +509,8 @@ class _UNetFunction(torch.autograd.Function):
             The up-sampled tensor only lives for this call: backward works on `low`
             (ops.conv3x3_up_bwd_weight / _data)."""
             w = l.conv.weight
-            if not b16 and l.ksize == 3 and ops.conv_up_in_fwd_supported(low, skip, w.shape[0]):
+            if not b16 and not x3 and l.ksize == 3 and \
+                    ops.conv_up_in_fwd_supported(low, skip, w.shape[0]):
                 # the bilinear gather runs inside the conv's patch loader: no up-sampled tensor
                 k = packed[id(w)]
                 m = mask_of[id(l)]
@@ -673,7 +679,8 @@ class _UNetFunction(torch.autograd.Function):
                 dx1 = None
                 if need_dx1:
                     dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], x1.shape[1],
-                                               x1.shape[2], 1)
+                                               x1.shape[2], 1, wd3=rec["wd3"],
+                                               bf16="bf16x3" if rec["wd3"] is not None else False)
                 return g_low, dx1
             if want_dw and fused:      # the weight gradient activates its operand on load
                 ops.conv_in_bwd_weight(x0, slope, dy, dw, 0, l.ksize, l.stride)
