@@ -541,6 +541,10 @@ int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
 int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
+  {   // stride-1 3x3 that tiles as 4 x 32 pixels: the patch-staged kernel (conv_patch.hip)
+    const int rc = launch_patch_b16_auto(p, stream, stats_px);
+    if (rc != 1) return rc;
+  }
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
     return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)

@@ -237,6 +237,7 @@ bool patch_s2_applicable(const IgemmParams& p);               // stride-2 forwar
 int launch_patch_s2_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
 int launch_dgrad_s2_patch_auto(const IgemmParams& p, hipStream_t stream, int* bs_tiles_out);
 int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream);
+int launch_patch_b16_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);   // bf16 tensors
 int launch_patch_split_fused_auto(const IgemmParams& p, hipStream_t stream, int* stats_px,
                                   int* bs_px);
 bool patch_split_applicable(const IgemmParams& p);

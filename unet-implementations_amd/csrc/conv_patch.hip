@@ -541,6 +541,244 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 }
 
 // ---------------------------------------------------------------------------
+// Patch-staged kernel of the mixed-precision pipeline (BASELINE config 4): bf16 layer tensors
+// in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulation; stride-1 3x3 forward (ACT: activation on
+// load in fp32 before the rounding to bf16; STATS: statistics of the fp32 accumulators) and data
+// gradient.  Geometry of conv_patch_f32_kernel: the (TH+2) x 34 patch of a 32-channel chunk is
+// staged once (bf16, rows of 40 elements = 80 B: conflict-free ds_read_b128 fragments) and
+// serves all nine taps.  At the bf16 matrix rate a tap is only 2 x TM x TN MFMAs of 32 cycles,
+// so a K step covers a whole kernel ROW (three taps, three weight panels staged together): 24
+// MFMAs per wave between barriers at 128 columns.  Weights stay fp32 in HBM (master copy) and
+// are rounded while staged.  LDS 16 KB patch + 61 KB weights at 128 columns (two per CU).
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false>
+__global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParams p) {
+  constexpr int BK = 32, LDA = BK + 8;       // bf16 elements per LDS row
+  constexpr int TW = 32, PW = TW + 2;
+  constexpr int PPIX = (TH + 2) * PW;
+  constexpr int P_SLOTS = PPIX * 8;          // 4-channel slots: 32 channels per pixel
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = 3 * BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = 3 * BN * LDA;       // three taps of one kernel row
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* Ps = smem_h;                       // [pixel][LDA]
+  __bf16* Bs = smem_h + PPIX * LDA;          // [buf][tap in row][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+
+  const int H = p.Hin, W = p.Win;
+  const int tiles_n = p.Ncols / BN, tiles_x = W / TW, tiles_y = H / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int Ktot = p.C0 + p.C1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  int pp_lin[P_PASSES], pp_lds[P_PASSES];
+  unsigned pp_oob[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = (tid + 256 * i) % P_SLOTS;
+    const int pix = slot >> 3, seg = slot & 7;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    pp_lin[i] = ok ? (n * H + iy) * W + ix : 0;            // pixel index
+    pp_oob[i] = ok ? 0u : 0x80000000u;
+    pp_lds[i] = pix * LDA + seg * 4;
+  }
+  const int seg4 = (tid & 7) * 4;            // this thread's four channels within a chunk
+  // weight slot j: (tap in row, column row, segment)
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES], wslot_tap[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int tr = slot / (BN * 8), rem = slot - tr * BN * 8;
+    const int row = rem >> 3, seg = rem & 7;
+    wslot_tap[j] = tr;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
+    wslot_lds[j] = (tr * BN + row) * LDA + seg * 4;
+  }
+
+  f32x4 pr[P_PASSES], rb[B_PASSES];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+
+  auto tap_of = [&](int t, int& oy, int& ox, int& wt) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    oy = (int)(e & 3u) - 1; ox = (int)((e >> 2) & 3u) - 1; wt = (int)(e >> 4);
+  };
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
+  auto load_patch = [&](int chunk) {
+    const int c = chunk * BK;
+    const bool first = c < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int cc = (first ? c : c - p.C0) + seg4;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i)
+      pr[i] = buf_ld4<__bf16>(rs, (unsigned)(pp_lin[i] * Cs + cc), pp_oob[i]);
+    if (ACT) {
+      const float* al = first ? p.act0_alpha : p.act1_alpha;
+      const float* be = first ? p.act0_beta : p.act1_beta;
+      if (al) {   // uniform
+        const size_t o = (size_t)n * Cs + cc;
+        ca = *reinterpret_cast<const f32x4*>(al + o);
+        cb = *reinterpret_cast<const f32x4*>(be + o);
+        cs = p.slope;
+      } else {    // plain source: z = v, slope 1 = identity
+        ca = f32x4{1.f, 1.f, 1.f, 1.f};
+        cb = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = 1.f;
+      }
+    }
+  };
+  auto to_bf16 = [](const f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    return h;
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      if (ACT) pr[i] = act4(pr[i], ca, cb, cs, pp_oob[i] == 0u);
+      *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(pr[i]);
+    }
+  };
+  auto load_b = [&](int row, int chunk) {   // the three taps 3*row .. 3*row+2
+    int oy, ox, wt0, wt1, wt2;
+    tap_of(3 * row, oy, ox, wt0);
+    tap_of(3 * row + 1, oy, ox, wt1);
+    tap_of(3 * row + 2, oy, ox, wt2);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const int wt = wslot_tap[j] == 0 ? wt0 : (wslot_tap[j] == 1 ? wt1 : wt2);
+      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsw, wslot_off[j] + woff, 0, 0));
+    }
+  };
+  auto store_b = [&](int buf) {
+    __bf16* Bb = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS)
+        *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[j]);
+  };
+
+  const int chunks = Ktot / BK;
+  const int steps = chunks * 3;
+  load_patch(0);
+  load_b(0, 0);
+  store_patch();
+  store_b(0);
+  __syncthreads();
+
+  // lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of its row
+  const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
+  const int b_lane = (wn0 + li) * LDA + 8 * lh;
+  int row = 0, chunk = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    const int row1 = (row == 2) ? 0 : row + 1;
+    const int chunk1 = (row == 2) ? chunk + 1 : chunk;
+    const bool more = s + 1 < steps;
+    load_b(more ? row1 : row, more ? chunk1 : chunk);
+    if (row == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int oy, ox, wt;
+      tap_of(3 * row + j, oy, ox, wt);
+      const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
+      const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+          a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
+#pragma unroll
+        for (int nb = 0; nb < TN; ++nb)
+          b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[m][nb], 0, 0, 0);
+      }
+    }
+    store_b(buf ^ 1);
+    if (row == 2) {            // every wave is done with this chunk's patch
+      __syncthreads();
+      store_patch();
+    }
+    __syncthreads();
+    row = row1;
+    chunk = chunk1;
+  }
+
+  __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      __bf16* o = outp + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
+      if (p.accumulate) {        // uniform: all 16 reads in flight before the first add
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = (float)o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv + old[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] += bv;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = (__bf16)acc[m][nb][r];
+    }
+  }
+  if (STATS && p.stats) {   // uniform; statistics of the fp32 accumulators (before the rounding)
+    constexpr int WAVES_M = 4 / WAVES_N;
+    float2* red = reinterpret_cast<float2*>(Ps);
+    static_assert(WAVES_M * BN * 8 <= PPIX * LDA * 2, "stats scratch fits in the patch area");
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][nb][r]; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
+      p.stats[((size_t)n * p.stats_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Stride-2 3x3 forward convolution (the first convolution of encoder stages 1..4,
 // Our_UNet/models/unet.py:106-115 with stride 2), patch-staged: the (2 TH + 1) x 65 input
 // pixels under a TH x 32 tile of OUTPUT pixels are staged once per 16-channel chunk and serve
@@ -1366,6 +1604,46 @@ bool patch_s2_applicable(const IgemmParams& p) {
          p.Wl == p.Wout && p.Hl % 4 == 0 && p.Wl % 32 == 0 && p.C0 % 16 == 0 && p.C1 % 16 == 0 &&
          !p.accumulate && p.tapw[0] == std_taps.tapw[0] && p.tapw[1] == std_taps.tapw[1] &&
          p.tapw[2] == std_taps.tapw[2];
+}
+
+template <int BN, int WM, int WN, int TH, bool ACT, bool STATS>
+int launch_patch_b16_t(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((TH + 2) * 34) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16);
+  auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS>;
+  UNET_SET_DYN_LDS(kern, lds);
+  const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_b16");
+  return UNET_OK;
+}
+
+// Mixed-precision pipeline (bf16 tensors): stride-1 3x3 whose image tiles as 4 x 32 pixels.
+// stats_px != nullptr = fused forward (activation on load + statistics), else data gradient.
+// Returns 1 when the shape does not qualify (the caller keeps the bf16 gather-GEMM).
+int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+  static const int off = getenv("UNET_NO_PATCH_B16") ? 1 : 0;
+  if (off || !patch_f32_applicable(p0) || p0.src0_pitch) return 1;
+  IgemmParams p = p0;
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  const long long mt = M / 128;
+  const bool fused = stats_px != nullptr;
+  if (nc % 128 == 0 && mt * (nc / 128) >= 256) {
+    if (!fused) return launch_patch_b16_t<128, 64, 64, 4, false, false>(p, stream);
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_b16_t<128, 64, 64, 4, true, true>(p, stream);
+  }
+  if (nc % 64 == 0 && mt * (nc / 64) >= 256) {
+    if (!fused) return launch_patch_b16_t<64, 64, 32, 4, false, false>(p, stream);
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_b16_t<64, 64, 32, 4, true, true>(p, stream);
+  }
+  if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 256) {
+    if (!fused) return launch_patch_b16_t<32, 64, 32, 8, false, false>(p, stream);
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_patch_b16_t<32, 64, 32, 8, true, true>(p, stream);
+  }
+  return 1;
 }
 
 // Fused-layer stride-2 forward on the patch-staged kernel; returns 1 when no tile shape fills
