@@ -165,3 +165,46 @@ def test_bench_two_ranks_through_torch_distributed_run():
     assert r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
     assert r["config"]["world"] == 2 and r["config"]["dist_backend"] == "gloo"
     assert abs(r["value"] - 4 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]
+
+
+def _worker_rccl(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from unet_implementations_amd import ddp
+    ua, model, img, tgt = _setup(0)
+    opt = ua.create_optimizer(model)
+    sync = ddp.GradBucketAllReduce(model, opt, bucket_bytes=8 << 20, always_reduce=True)
+    ddp.broadcast_parameters(model)
+    loss = ua.train_step(model, opt, ua.get_loss_function(), img, tgt, grad_sync=sync.finish)
+    torch.cuda.synchronize()
+    arena, garena = model.flat_parameters()
+    out["grad"] = garena.cpu()
+    out["param"] = arena.cpu()
+    out["loss"] = loss.item()
+    out["ranges"] = list(sync.sent_ranges)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_call_path_with_a_single_rank():
+    """Backend "nccl" (= RCCL) on the one GPU this box has: a one-rank group whose bucketed
+    all-reduces, broadcast and barrier are really issued (`always_reduce`).  The sums are
+    identities, so the step must equal the plain single-process step bit for bit - what this
+    covers is the RCCL initialisation with `device_id`, the async work handles on RCCL's stream
+    and the wait in finish(), which the gloo tests cannot."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_rccl, args=(1, _free_port(), out), nprocs=1, join=True)
+    ua, model, img, tgt = _setup(0)
+    opt = ua.create_optimizer(model)
+    loss = ua.train_step(model, opt, ua.get_loss_function(), img, tgt)
+    arena, garena = model.flat_parameters()
+    assert out["loss"] == loss.item()
+    assert torch.equal(out["grad"], garena.cpu())
+    assert torch.equal(out["param"], arena.cpu())
+    covered = sorted(out["ranges"])
+    assert covered[0][0] == 0 and covered[-1][1] == garena.numel()
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "buckets must tile the arena"

@@ -26,7 +26,7 @@ class GradBucketAllReduce:
     """Bucketed, overlapped all-reduce of a UNet's gradient arena."""
 
     def __init__(self, model, optimizer=None, process_group=None, bucket_bytes=16 << 20,
-                 average=True):
+                 average=True, always_reduce=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend nccl or gloo)")
         self.model = model
@@ -36,6 +36,9 @@ class GradBucketAllReduce:
         self._works = []
         self._hi = None
         self.sent_ranges = []    # (lo, hi) arena ranges handed to all_reduce, newest last
+        # always_reduce: issue the collectives even in a one-rank group (a rehearsal of the RCCL
+        # call path - streams, async work handles - on a single GPU; the sums are identities)
+        self.always_reduce = always_reduce
         model.grad_ready_hook = self._on_ready
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world if average else 1.0
@@ -53,7 +56,7 @@ class GradBucketAllReduce:
         if hi <= lo:
             return
         self.sent_ranges.append((lo, hi))
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return
         self._works.append(dist.all_reduce(garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                            async_op=True))
@@ -89,7 +92,7 @@ class GradBucketAllReduce:
         """Call between backward and optimizer.step(): flushes the tail bucket and makes the
         current stream wait for every outstanding all-reduce."""
         self.check_gradients_alias_arena()
-        if self._hi is not None and self._hi > 0 and self.world > 1:
+        if self._hi is not None and self._hi > 0 and (self.world > 1 or self.always_reduce):
             _, garena = self.model.flat_parameters()
             self._launch(garena, self._frozen_prefix(), self._hi)
         for w in self._works:
