@@ -41,7 +41,8 @@ constexpr int C32_PPIX = C32_PH * C32_PW;          // 340 patch pixels
 constexpr int C32_SLOTS = C32_PPIX * 8;            // f32x4 slots
 constexpr int C32_PASSES = (C32_SLOTS + 511) / 512;
 constexpr size_t C32_LDS = 2 * (size_t)C32_PPIX * C32_LDA * sizeof(float) +
-                           2 * 8 * 32 * sizeof(float2);   // + per-wave summaries of two tiles
+                           2 * 8 * 32 * sizeof(float2) +   // per-wave summaries of two tiles
+                           8 * 1024 * sizeof(float);       // BSTATS: the raw outputs under a tile
 
 template <bool FUSED>
 __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, int ntiles) {
@@ -147,6 +148,11 @@ __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, i
   // row summaries of the tile in patch buffer b: red[b][wave][column]
   float2* red = reinterpret_cast<float2*>(smem + 2 * C32_PPIX * LDA);
   const bool summaries = FUSED ? p.stats != nullptr : p.bs_partial != nullptr;   // uniform
+  // BSTATS: the 32 x 32 raw outputs y under this wave's row (4 KB, contiguous in HBM) go
+  // global -> LDS by DMA at the start of the tile (no registers: none are free), land under the
+  // tile's MFMAs and are read back in the epilogue
+  float* ylds = smem + 2 * C32_PPIX * LDA + 2 * 8 * 32 * 2 + wave * 1024;
+  const bool y_dma = !FUSED && p.bs_partial != nullptr && p.ldo == 32;   // uniform
 
   load_patch(t_first);
   store_patch(0);
@@ -158,6 +164,16 @@ __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, i
     const int nxt = tile + t_stride;
     const bool more = nxt < t_end;
     if (more) load_patch(nxt);   // uniform
+    if (y_dma) {
+      int n_, y0_, x0_;
+      tile_pos(tile, n_, y0_, x0_);
+      const float* ysrc = p.bs_y + (((size_t)n_ * H + y0_ + wave) * W + x0_) * 32 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)   // LDS destination = uniform base + lane * 16 B
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ysrc + i * 256),
+            (__attribute__((address_space(3))) void*)(ylds + i * 256), 16, 0, 0);
+    }
     int n, y0, x0;
     tile_pos(tile, n, y0, x0);
     const int y = y0 + wave;
@@ -205,10 +221,19 @@ __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, i
       for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = acc[r];
       if (p.bs_partial) {   // uniform: reductions of the next backward stage (IgemmParams)
         const BwdCoef cf = bwd_coef(p, n, li);
-        const float* yb = p.bs_y + pix0o * p.ldo + li;
-        const float2 mine = wave_bwd_stats<1>(
-            cf, p.slope, [&](int, int r) { return acc[r]; },
-            [&](int, int r) { return yb[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo]; });
+        float2 mine;
+        if (y_dma) {   // uniform
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA issued at the tile start
+          const float* yl = ylds + 4 * lh * 32 + li;
+          mine = wave_bwd_stats<1>(
+              cf, p.slope, [&](int, int r) { return acc[r]; },
+              [&](int, int r) { return yl[((r & 3) + 8 * (r >> 2)) * 32]; });
+        } else {
+          const float* yb = p.bs_y + pix0o * p.ldo + li;
+          mine = wave_bwd_stats<1>(
+              cf, p.slope, [&](int, int r) { return acc[r]; },
+              [&](int, int r) { return yb[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo]; });
+        }
         if (lh == 0) red[(buf * 8 + wave) * 32 + li] = mine;
       }
     }
