@@ -383,6 +383,13 @@ int unet_conv_in_bwd_weight(const unet_act_src* x, float slope, const float* dy,
                             int ci_offset, int Cin_total, int ksize, int stride, void* workspace,
                             size_t workspace_bytes, int N, int H, int W, int Cout,
                             unet_stream_t stream);
+/* The same in the split-bf16 operand mode (fp32 tensors; stride-1 3x3 layers on the bf16 matrix
+ * cores with the activation applied before the three-term split, other shapes on the fp32
+ * kernels).  Workspace as unet_conv3x3_bwd_weight_workspace_bytes. */
+int unet_conv_in_bwd_weight_bf16x3(const unet_act_src* x, float slope, const float* dy, float* dw_oihw,
+                            int ci_offset, int Cin_total, int ksize, int stride, void* workspace,
+                            size_t workspace_bytes, int N, int H, int W, int Cout,
+                            unet_stream_t stream);
 
 /* up[N][2h][2w][C] = bilinear2x(act(x)) (the activation is applied to each of the four taps;
  * UpBlock.forward, Our_UNet/models/unet.py:219-225). */

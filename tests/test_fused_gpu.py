@@ -218,8 +218,9 @@ WGRAD_CASES = [  # (N, H, W, Cx, Cout, stride, ksize, act)
 ]
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", WGRAD_CASES)
-def test_conv_in_bwd_weight(ua, case):
+def test_conv_in_bwd_weight(ua, case, x3):
     N, H, W, Cx, Cout, stride, ks, act = case
     x = rnd(N, Cx, H, W, seed=1)
     coef = coeffs(N, Cx, 30) if act else None
@@ -233,7 +234,7 @@ def test_conv_in_bwd_weight(ua, case):
     if Cx == 3:
         off, total = 0, 3
     dw = torch.full((Cout, total, ks, ks), 7.0, device=DEV)
-    ua.ops.conv_in_bwd_weight(make_src(ua, x, coef), SLOPE, to_nhwc(dy), dw, off, ks, stride)
+    ua.ops.conv_in_bwd_weight(make_src(ua, x, coef), SLOPE, to_nhwc(dy), dw, off, ks, stride, x3=x3)
     check(dw[:, off:off + Cx].cpu(), wz.grad, 3e-5, "dw")
     if total > Cx:
         assert torch.all(dw[:, :off] == 7.0) and torch.all(dw[:, off + Cx:] == 7.0)

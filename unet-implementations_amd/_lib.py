@@ -101,6 +101,8 @@ SIGNATURES = {
     "unet_stem_u8_bwd_weight": (_i, [_p, _c.POINTER(_f), _c.POINTER(_f), _p, _p, _p, _sz, _i, _i,
                                      _i, _i, _p]),
     "unet_conv_in_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_conv_in_bwd_weight_bf16x3": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i,
+                                            _p]),
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_data_bs": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv3x3_bwd_data_bs_bf16x3": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs,

@@ -984,6 +984,15 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
       return UNET_OK;
     }
   }
+  if constexpr (NPL == 3) {
+    if (p.alpha) {   // split mode of the fused pipeline: activation on load, then the split
+      auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, 3, SB, float, float, true>;
+      UNET_SET_DYN_LDS(kern, lds);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+      UNET_CHECK_LAUNCH("conv_wgrad_bf16x3(act)");
+      return UNET_OK;
+    }
+  }
   auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, NPL, SB>;
   UNET_SET_DYN_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
@@ -1206,8 +1215,8 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                        dw_oihw, nslab, Cout);
     UNET_CHECK_LAUNCH("stem_wgrad_reduce");
   } else {
-    UNET_REQUIRE(!act_alpha || (act_beta && (prec == 0 || b16)),
-                 "conv_bwd_weight: activation on load needs the fp32 or the bf16-storage path");
+    UNET_REQUIRE(!act_alpha || (act_beta && (prec == 0 || prec == 3 || b16)),
+                 "conv_bwd_weight: activation on load needs the fp32, split or bf16-storage path");
     const size_t E = (size_t)9 * Cx * Cout;
     const int nmax = wgrad_batch_chunk(N, H, W, Cx, Cout, stride);
     int nslab = 0;
@@ -1331,6 +1340,26 @@ extern "C" int unet_conv_in_bwd_weight(const unet_act_src* x, float slope, const
   return conv_bwd_weight_impl(x->x, x->C, dy, dw_oihw, ci_offset, Cin_total, nullptr, workspace,
                               workspace_bytes, N, H, W, Cout, stride, ksize == 1,
                               (hipStream_t)stream, 0, x->alpha, x->beta, slope);
+}
+
+// The same in the split-bf16 operand mode (fp32 tensors, fp32-class accuracy): stride-1 3x3
+// layers whose segments split into whole 16-pixel groups run the three-plane kernel with the
+// activation applied before the split, other shapes the fp32 kernels.
+extern "C" int unet_conv_in_bwd_weight_bf16x3(const unet_act_src* x, float slope, const float* dy,
+                                              float* dw_oihw, int ci_offset, int Cin_total,
+                                              int ksize, int stride, void* workspace,
+                                              size_t workspace_bytes, int N, int H, int W, int Cout,
+                                              unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x, "conv_in_bwd_weight_bf16x3: null source");
+  UNET_REQUIRE(ksize == 3 || (ksize == 1 && stride == 1),
+               "conv_in_bwd_weight_bf16x3: kernel %d / stride %d unsupported", ksize, stride);
+  UNET_REQUIRE(x->C == 3 ? !x->alpha : x->C % 32 == 0,
+               "conv_in_bwd_weight_bf16x3: Cx %d unsupported (the RGB image is a plain operand)",
+               x->C);
+  const int prec = (ksize == 3 && x->C != 3) ? 3 : 0;
+  return conv_bwd_weight_impl(x->x, x->C, dy, dw_oihw, ci_offset, Cin_total, nullptr, workspace,
+                              workspace_bytes, N, H, W, Cout, stride, ksize == 1,
+                              (hipStream_t)stream, prec, x->alpha, x->beta, slope);
 }
 
 // ---- conv3x3(upsample2x(a)): weight gradient w.r.t. the up-sampled operand at low resolution

@@ -539,8 +539,9 @@ def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask):
     return y, st
 
 
-def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
-    """Weight gradient of a fused layer: dw[:, ci_offset : ci_offset + Cx] = act(x) (x) dy."""
+def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride, x3=False):
+    """Weight gradient of a fused layer: dw[:, ci_offset : ci_offset + Cx] = act(x) (x) dy.
+    x3: the split-bf16 operand mode (fp32 tensors)."""
     if isinstance(x, U8Image):
         N, H, W, _ = x.shape
         Cout = dy.shape[3]
@@ -558,12 +559,14 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride):
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride), dy)
     b16 = _is_b16(dy)
-    fn = lib().unet_conv_in_bwd_weight_b16 if b16 else lib().unet_conv_in_bwd_weight
+    fn = lib().unet_conv_in_bwd_weight_b16 if b16 else \
+        (lib().unet_conv_in_bwd_weight_bf16x3 if x3 else lib().unet_conv_in_bwd_weight)
     t0 = _timer.begin("wgrad") if _timer is not None else None
     check(fn(rx, slope, _ptr(dy), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], ksize, stride,
              _ptr(ws), ws.numel(), N, H, W, Cout, _stream()))
     if t0 is not None:
-        _timer.end("conv_stem_wgrad" if Cx == 3 else ("conv_wgrad_bf16" if b16 else "conv_wgrad"),
+        _timer.end("conv_stem_wgrad" if Cx == 3 else
+                   ("conv_wgrad_bf16" if b16 else ("conv_wgrad_bf16x3" if x3 else "conv_wgrad")),
                    2.0 * N * dy.shape[1] * dy.shape[2] * ksize * ksize * Cx * Cout, 2, t0)
     return dw_oihw
 

@@ -600,6 +600,7 @@ class _UNetFunction(torch.autograd.Function):
         head = model.segmentation_output
         fused, slope = ctx.fused, ctx.slope
         b16_bwd = ctx.bf16 == "bf16"
+        x3_bwd = ctx.fused and ctx.bf16 == "bf16x3"
         hw = head.weight.detach().view(head.out_channels, -1)
         if fused:
             g = ops.head1x1_in_bwd(ctx.last, slope, dlogits, hw,
@@ -672,7 +673,7 @@ class _UNetFunction(torch.autograd.Function):
                 D = ops.upsample2x_bwd_taps(dy) if (want_dw or need_dx) else None
                 if want_dw:
                     ops.conv3x3_up_bwd_weight(low, slope, D, dw, 0)
-                    ops.conv_in_bwd_weight(x1, slope, dy, dw, C0, 3, 1)
+                    ops.conv_in_bwd_weight(x1, slope, dy, dw, C0, 3, 1, x3=x3_bwd)
                 g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0, nxt=nxt) if need_dx else None
                 if nxt is not None:
                     saved[i - 1]["nxt"] = nxt
@@ -683,9 +684,10 @@ class _UNetFunction(torch.autograd.Function):
                                                bf16="bf16x3" if rec["wd3"] is not None else False)
                 return g_low, dx1
             if want_dw and fused:      # the weight gradient activates its operand on load
-                ops.conv_in_bwd_weight(x0, slope, dy, dw, 0, l.ksize, l.stride)
+                ops.conv_in_bwd_weight(x0, slope, dy, dw, 0, l.ksize, l.stride, x3=x3_bwd)
                 if x1 is not None:
-                    ops.conv_in_bwd_weight(x1, slope, dy, dw, x0.shape[3], l.ksize, l.stride)
+                    ops.conv_in_bwd_weight(x1, slope, dy, dw, x0.shape[3], l.ksize, l.stride,
+                                           x3=x3_bwd)
                 want_dw = False
             if l.ksize == 1:
                 if want_dw:
