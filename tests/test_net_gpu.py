@@ -197,6 +197,51 @@ def test_tie_free_network_gradients_per_element(ua, golden, fused):
     assert not bad, "\n".join(bad)
 
 
+SWEEP = [(1, 64, 64), (3, 96, 160), (2, 128, 256), (1, 320, 192), (5, 256, 256), (2, 384, 384),
+         (1, 512, 512)]
+
+
+@pytest.mark.parametrize("shape", SWEEP, ids=[f"{n}x{h}x{w}" for n, h, w in SWEEP])
+def test_shape_sweep_fused_vs_standalone_pipeline(ua, shape):
+    """The fused pipeline picks its kernels by shape (patch / 32-channel / stride-2 patch /
+    K-group gather-GEMM / up-sampling loader, each with tiling conditions).  Over batch sizes and
+    image sizes that land on different combinations of them, the tie-free network
+    (negative_slope = 1: no LeakyReLU branch to flip) must agree with the stand-alone pipeline -
+    whose kernels are held to the oracle one by one - on the logits and on EVERY element of all
+    90 gradients to 1e-4 of each tensor's max magnitude."""
+    n, h, w = shape
+    sd0 = O.fill_state_dict(17)
+    img, tgt = O.synthetic_batch(3, n, h, w)
+    masks = O.draw_dropout_masks(9, n)
+    outs = []
+    for fused in (True, False):
+        model = ua.UNet(nonlin_kwargs={"negative_slope": 1.0, "inplace": True})
+        model.load_state_dict(sd0)
+        model = model.to(DEV).train()
+        model.fused_pipeline = fused
+        model.dropout_mask_override = masks
+        logits = model(img.to(DEV))
+        loss = ua.get_loss_function()(logits, tgt.to(DEV))
+        loss.backward()
+        outs.append((logits.detach().cpu(), loss.item(),
+                     {k: p.grad.detach().cpu() for k, p in model.named_parameters()}))
+        del model
+    (lf, lossf, gf), (ls, losss, gs) = outs
+    assert relerr(lf, ls) <= 1e-4
+    assert abs(lossf - losss) <= 2e-4 * abs(losss)
+    bad = []
+    for k in gs:
+        scale = gs[k].abs().max().item()
+        if scale < 1e-6:      # conv biases under InstanceNorm: exact 0 up to rounding
+            if gf[k].abs().max().item() > 1e-3:
+                bad.append(f"{k}: should be ~0")
+            continue
+        e = (gf[k] - gs[k]).abs().max().item() / scale
+        if e > 1e-4:
+            bad.append(f"{k}: {e:.2e}")
+    assert not bad, "\n".join(bad)
+
+
 def test_net_vs_oracle_random_init(ua):
     """Reference-style random init (Kaiming weights, zero biases, unit gamma), 96x64 input,
     train mode with oracle-drawn masks: logits, loss and every gradient against the oracle."""
