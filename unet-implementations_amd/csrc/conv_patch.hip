@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
   };
 
   const int chunks = Ktot / BK;
-  const int steps = chunks * 9;
   load_patch(0);
   load_b(0, 0);
   store_patch();
@@ -435,14 +434,18 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
   // MFMA r of a k-group of 8 multiplies k = 8*kk + 4*lh + r on both operands
   const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 4 * lh;
   const int b_lane = (wn0 + li) * LDA + 4 * lh;
-  int t = 0, chunk = 0;
-  for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
+  // Tap 0 of a chunk is PEELED from the rolled loop over taps 1..8: vmcnt is in-order, so with
+  // one rolled tap body the wait for a tap's four weight loads had to assume the worst path and
+  // also drained the next chunk's patch loads at tap 0, 0.85 us after their issue.  In the
+  // peeled copy the compiler counts exactly (tap 0 waits for its weights only; the patch loads
+  // land under taps 0..1).
+  auto tap_step = [&](auto first_tag, int t, int chunk, int chunk_n) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int buf = (chunk + t) & 1;   // step = 9 * chunk + t
     const int t1 = (t == 8) ? 0 : t + 1;
-    const int chunk1 = (t == 8) ? chunk + 1 : chunk;
-    const bool more = s + 1 < steps;
-    load_b(more ? t1 : t, more ? chunk1 : chunk);
-    if (t == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+    load_b(t1, t == 8 ? chunk_n : chunk);
+    if constexpr (FIRST) load_patch(chunk_n);
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay ahead of the tap's MFMAs
 
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
@@ -475,13 +478,20 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
                                                               acc[m][nb], 0, 0, 0);
     }
     store_b(buf ^ 1);
-    if (t == 8) {            // every wave is done with this chunk's patch
-      __syncthreads();
-      store_patch();
-    }
+  };
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const int chunk_n = chunk + 1 < chunks ? chunk + 1 : chunk;   // the last chunk re-stages itself
+    tap_step(std::true_type{}, 0, chunk, chunk_n);
     __syncthreads();
-    t = t1;
-    chunk = chunk1;
+#pragma nounroll
+    for (int t = 1; t < 9; ++t) {
+      tap_step(std::false_type{}, t, chunk, chunk_n);
+      if (t == 8) {            // every wave is done with this chunk's patch
+        __syncthreads();
+        store_patch();
+      }
+      __syncthreads();
+    }
   }
 
 #pragma unroll
