@@ -16,6 +16,9 @@ opt = ua.create_optimizer(model); lossf = ua.get_loss_function()
 model3 = ua.UNet(); model3.load_state_dict(sd0); model3 = model3.to("cuda").train()
 model3.matmul_precision = "bf16x3"
 opt3 = ua.create_optimizer(model3)
+modelb = ua.UNet(); modelb.load_state_dict(sd0); modelb = modelb.to("cuda").train()
+modelb.matmul_precision = "bf16"      # BASELINE config 4: bf16 layer tensors + bf16 matrix cores
+optb = ua.create_optimizer(modelb)
 o32 = O.leaf_state_dict(sd0); b32 = [None] * len(o32)
 o64 = {k: v.double().clone().requires_grad_(True) for k, v in sd0.items()}; b64 = [None] * len(o64)
 
@@ -37,8 +40,10 @@ for s in range(steps):
     lh = ua.train_step(model, opt, lossf, img.cuda(), tgt.cuda()).item()
     model3.dropout_mask_override = masks
     l3 = ua.train_step(model3, opt3, lossf, img.cuda(), tgt.cuda()).item()
+    modelb.dropout_mask_override = masks
+    lb = ua.train_step(modelb, optb, lossf, img.cuda(), tgt.cuda()).item()
     d3 = max(((p.detach().cpu().double() - o64[k].detach()).abs().max() / (o64[k].detach().abs().max() + 1e-30)).item() for k, p in model3.named_parameters())
     dh = max(((p.detach().cpu().double() - o64[k].detach()).abs().max() / (o64[k].detach().abs().max() + 1e-30)).item() for k, p in model.named_parameters())
     d32 = max(((o32[k].detach().double() - o64[k].detach()).abs().max() / (o64[k].detach().abs().max() + 1e-30)).item() for k in o32)
-    print(f"step {s}: loss fp64 {l64:.6f}  ref32 {l32.item():.6f}  hip {lh:.6f}  hip-bf16x3 {l3:.6f} | "
+    print(f"step {s}: loss fp64 {l64:.6f}  ref32 {l32.item():.6f}  hip {lh:.6f}  hip-bf16x3 {l3:.6f}  hip-bf16 {lb:.6f} | "
           f"max rel param diff vs fp64: hip {dh:.3e}  hip-bf16x3 {d3:.3e}  ref32 {d32:.3e}")
