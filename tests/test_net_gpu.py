@@ -413,6 +413,31 @@ def test_bf16_matmul_mode_tracks_fp32(ua):
     assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0]
 
 
+def test_clip_unet_in_split_bf16_mode(ua, golden):
+    """CLIP_UNet with matmul_precision = "bf16x3" on the fused pipeline (the 1x1 fusion layer
+    stays on the fp32 kernels, the 3x3 layers run the split kernels): the reference fixture's
+    logits and loss to the fp32 tolerances, gradient norms to 5e-3."""
+    g = golden("clip64")
+    n, hw, clip_dim = int(g["n"]), int(g["hw"]), int(g["clip_dim"])
+    sd0 = O.fill_state_dict(int(g["seed_w"]), clip_dim=clip_dim)
+    model = ua.CLIPUNet(with_clip_features=True, clip_dim=clip_dim)
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    model.matmul_precision = "bf16x3"
+    img, tgt = O.synthetic_batch(int(g["seed_x"]), n, hw, hw)
+    clip = torch.from_numpy(g["clip_features"]).to(DEV)
+    model.dropout_mask_override = O.draw_dropout_masks(int(g["seed_drop"]), n)
+    logits = model(img.to(DEV), clip)
+    loss = ua.SimpleLoss()(logits, tgt.to(DEV))
+    loss.backward()
+    assert relerr(logits, torch.from_numpy(g["train_logits"])) <= 1e-4
+    assert abs(loss.item() - float(g["loss_0"])) <= 2e-4 * abs(float(g["loss_0"]))
+    for i, (k, p) in enumerate(model.named_parameters()):
+        ref_norm = float(g[f"gnorm_{i}"])
+        if ref_norm >= 1e-4:
+            assert abs(p.grad.double().norm().item() - ref_norm) <= 5e-3 * ref_norm, k
+
+
 def test_clip_unet_golden(ua, golden):
     """CLIP_UNet variant (BASELINE config 5) against the fixture recorded from the reference's
     CLIP_UNet/models/unet.py with synthetic CLIP features: eval + train logits, loss, gradients."""
