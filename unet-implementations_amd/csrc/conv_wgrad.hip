@@ -439,10 +439,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
 // reproduces the fp32 product to one fp32 rounding (see conv_igemm_split_kernel).
 // SB = single LDS stage (two barriers per segment) where the double-buffered planes would leave
 // one workgroup per CU (32x32 tile, 64-pixel segments, three planes: 50 KB instead of 100 KB).
+// STRIDE = 2 (mixed-precision pipeline only): the patch holds (S-1)*2+3 input columns per row
+// and the A fragment rows are two patch pixels apart (the transposing read takes a row address
+// per lane, so the stride costs nothing).
 template <int CI_T, int CO_T, int S, int NPL, bool SB = false, typename TX = float,
-          typename TD = float, bool ACT = false>
+          typename TD = float, bool ACT = false, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradParams p) {
-  constexpr int STRIDE = 1;
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
   constexpr int NSB = TI * TJ, NPP = 4 / NSB;
   static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
@@ -595,9 +597,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
       for (int gq = 0; gq < NG; ++gq) {
         const int xx0 = 16 * (pp + NPP * gq);          // first pixel of this k-group
         const int r0 = xx0 + 8 * th + tq;              // this lane's row for half 0 (+4 for half 1)
-        auto frag = [&](const __bf16* q) {   // rows r0..r0+3 and r0+4..r0+7 of this lane's group
+        // rows r0..r0+3 and r0+4..r0+7 of this lane's group (`step` elements between rows + 4)
+        auto frag = [&](const __bf16* q, int step = 4 * 32) {
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + step));
           return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
         bf16x8 b[3];
@@ -607,11 +610,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
         for (int u = 0; u < 3; ++u)
 #pragma unroll
           for (int v = 0; v < 3; ++v) {
-            const __bf16* pa = P + (u * PW + r0 + v) * 32 + tcol;
+            const __bf16* pa = P + (u * PW + STRIDE * r0 + v) * 32 + tcol;
+            constexpr int AST = 4 * STRIDE * 32;
             if (NPL == 1) {
-              acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pa), b[0], acc[u][v], 0, 0, 0);
+              acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pa, AST), b[0], acc[u][v], 0, 0, 0);
             } else {
-              const bf16x8 a0 = frag(pa), a1 = frag(pa + PLANE), a2 = frag(pa + 2 * PLANE);
+              const bf16x8 a0 = frag(pa, AST), a1 = frag(pa + PLANE, AST),
+                           a2 = frag(pa + 2 * PLANE, AST);
               f32x16 c = acc[u][v];
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], c, 0, 0, 0);
@@ -1000,6 +1005,25 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+// mixed-precision pipeline, stride 2: bf16 tensors, bf16 matrix cores
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_b16_s2(const WgradParams& p, hipStream_t stream) {
+  constexpr int PW = (S - 1) * 2 + 3;
+  constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, 1, false, __bf16, __bf16, true, 2>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, 1, false, __bf16, __bf16, false, 2>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_bf16(b16, stride 2)");
+  return UNET_OK;
+}
+
 template <int CI_T, int CO_T, int S>
 int launch_wgrad_taps(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)S * (CI_T + 9 * CO_T) * sizeof(float);
@@ -1060,6 +1084,10 @@ int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int
     if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64, 3, true>(p, stream);
     if (pl.ci_t == 32) return launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
     return launch_wgrad_bf16<64, 64, 16, 3>(p, stream);
+  }
+  if (p.b16 && prec == 1 && stride == 2 && (pl.S / 16) % pl.npp == 0) {
+    if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_s2<64, 64, 16>(p, stream);
+    if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_s2<32, 64, 32>(p, stream);
   }
   if (use_bf16 && prec == 1) {
     if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64>(p, stream);
