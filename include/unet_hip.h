@@ -441,6 +441,11 @@ typedef struct unet_bwd_stats {
 int unet_conv3x3_bwd_data_bs(const float* dy, const float* wd, int Cin_total, int ci_offset,
                              float* dx, int N, int H, int W, int Cout, int Ccols, int stride,
                              int accumulate, unet_bwd_stats* bs, unet_stream_t stream);
+/* The same on the mixed-precision pipeline: dy, dx and bs->y are bf16 tensors (stride-1 shapes
+ * of the patch kernel emit the reductions; bs->tiles_out = 0 otherwise). */
+int unet_conv3x3_bwd_data_bs_b16(const uint16_t* dy, const float* wd, int Cin_total, int ci_offset,
+                                 uint16_t* dx, int N, int H, int W, int Cout, int Ccols, int stride,
+                                 int accumulate, unet_bwd_stats* bs, unet_stream_t stream);
 /* unet_conv3x3_bwd_data_bs in the split-bf16 mode (wd3 = pre-split planes, data-gradient
  * layout); bs may be NULL (no reductions wanted). */
 int unet_conv3x3_bwd_data_bs_bf16x3(const float* dy, const float* wd, const uint16_t* wd3,
@@ -459,6 +464,15 @@ int unet_instnorm_lrelu_drop_bwd_partials(const float* ga, const float* y, const
                                           const void* partial, int tiles, void* workspace,
                                           size_t workspace_bytes, int N, int HW, int C,
                                           unet_stream_t stream);
+/* bf16 storage (mixed-precision pipeline): ga, y, dy are bf16 tensors. */
+int unet_instnorm_lrelu_drop_bwd_partials_b16(const uint16_t* ga, const uint16_t* y,
+                                              const float* mean, const float* rstd,
+                                              const float* gamma, const float* beta,
+                                              const float* mask, float slope, uint16_t* dy,
+                                              float* dgamma, float* dbeta, float* dbias,
+                                              const void* partial, int tiles, void* workspace,
+                                              size_t workspace_bytes, int N, int HW, int C,
+                                              unet_stream_t stream);
 
 /* ---- mixed precision with bf16 activations in HBM (BASELINE config 4) ----------------------
  * The reference's AMP path is fp16 autocast + GradScaler (Our_UNet/src/train.py:638-652); the

@@ -318,3 +318,46 @@ def test_bf16_full_size_layers_and_batch_split(ua):
     torch.manual_seed(0)
     lossf(model(img.to(DEV)), tgt.to(DEV)).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("case", [(1, 256, 256, 32, 128, False), (2, 256, 256, 64, 64, True),
+                                  (2, 256, 256, 32, 32, False), (2, 16, 16, 64, 64, False)])
+def test_data_gradient_b16_emits_next_norm_reductions(ua, case):
+    """unet_conv3x3_bwd_data_bs_b16: the patch kernel's BSTATS epilogue on bf16 tensors (sums from
+    the fp32 accumulators and the bf16 raw outputs of the layer).  Same gradient bits as the plain
+    call; the InstanceNorm backward fed by the summaries agrees with the stand-alone reduction
+    (which reads the bf16-STORED gradient) to bf16 storage precision.  The last shape has no such
+    epilogue (gather-GEMM): tiles == 0."""
+    N, H, W, Cout, Ccols, acc = case
+    dy = to_nhwc_b16(r16(rnd(N, Cout, H, W, seed=1)))
+    w = rnd(Cout, Ccols, 3, 3, seed=2, scale=0.1)
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    y = to_nhwc_b16(r16(rnd(N, Ccols, H, W, seed=10) * 1.5 + 0.3))
+    gamma = (rnd(Ccols, seed=11) * 0.2 + 1.0).to(DEV)
+    beta = (rnd(Ccols, seed=12) * 0.2).to(DEV)
+    yf = y.float()
+    mean = yf.mean(dim=(1, 2))
+    rstd = 1.0 / torch.sqrt(yf.var(dim=(1, 2), unbiased=False) + 1e-5)
+    st = torch.stack([mean, rstd, torch.zeros_like(mean), torch.zeros_like(mean)]).contiguous()
+    mask = ((torch.rand(N, Ccols, generator=torch.Generator().manual_seed(13)) < 0.8).float()
+            / 0.8).to(DEV)
+    base = to_nhwc_b16(r16(rnd(N, Ccols, H, W, seed=3))) if acc else None
+    ref = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, 1, out=base.clone() if acc else None,
+                                  accumulate=acc)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, 1, out=base.clone() if acc else None,
+                                accumulate=acc, nxt=nn)
+    assert torch.equal(g, ref)
+    if H * W < 128 * 32:
+        assert nn.tiles == 0
+        return
+    assert nn.tiles > 0
+    outs = []
+    for partials in ((nn.partial, nn.tiles), None):
+        dg, db, dbias = (torch.empty(Ccols, device=DEV) for _ in range(3))
+        dz = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), y, st[0], st[1], gamma, beta, mask, SLOPE,
+                                            dg, db, dbias, partials=partials)
+        outs.append((dz.float(), dg, db))
+    check(outs[0][0], outs[1][0], 8e-3, "dy")
+    check(outs[0][1], outs[1][1], 3e-3, "dgamma")
+    check(outs[0][2], outs[1][2], 3e-3, "dbeta")

@@ -1308,7 +1308,9 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   // split mode with reductions (fused pipeline): only the stride-1 patch shapes have a split
   // kernel with that epilogue; everything else runs the fp32 kernels
   if (prec == 3 && bs && stride == 2) prec = 0;
-  const bool use_bs = bs && (prec == 0 || prec == 3) && !b16 && bs->y && bs->mean && bs->rstd && bs->gamma &&
+  // (b16: only the stride-1 patch kernel has the epilogue; other shapes report 0 tiles)
+  const bool use_bs = bs && (prec == 0 || prec == 3 || (b16 && stride == 1)) && bs->y && bs->mean &&
+                      bs->rstd && bs->gamma &&
                       bs->beta && bs->partial &&
                       bs->partial_bytes >= (size_t)N * ceil_div(H * W, 64) * Ccols * sizeof(float2);
   UNET_REQUIRE(dy && wd && dx, "conv3x3_bwd_data: null pointer");
@@ -1365,7 +1367,11 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
     p.ntaps = 9;
     p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
     for (int t = 0; t < 9; ++t) set_tap(p, t, 1 - t / 3, 1 - t % 3, t);
-    if (b16) return dispatch_igemm_b16(p, stream, nullptr);
+    if (b16) {
+      const int rc = dispatch_igemm_b16(p, stream, nullptr, use_bs ? &bs_px : nullptr);
+      if (rc == UNET_OK && use_bs && bs_px > 0) bs->tiles_out = H * W / bs_px;
+      return rc;
+    }
     if (prec == 1) return dispatch_igemm_bf16(p, stream);
     if (prec == 3 && !bs) return dispatch_igemm_split(p, stream);
     int rc = 1;
@@ -1461,6 +1467,16 @@ extern "C" int unet_conv3x3_bwd_data_bs(const float* dy, const float* wd, int Ci
                                         unet_stream_t stream) {
   return conv3x3_bwd_data_impl(dy, wd, Cin_total, ci_offset, dx, N, H, W, Cout, Ccols, stride,
                                accumulate, 0, (hipStream_t)stream, nullptr, 0, bs);
+}
+
+// Mixed-precision pipeline with the BSTATS epilogue: dy, dx and bs->y are bf16 tensors
+extern "C" int unet_conv3x3_bwd_data_bs_b16(const uint16_t* dy, const float* wd, int Cin_total,
+                                            int ci_offset, uint16_t* dx, int N, int H, int W,
+                                            int Cout, int Ccols, int stride, int accumulate,
+                                            unet_bwd_stats* bs, unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(reinterpret_cast<const float*>(dy), wd, Cin_total, ci_offset,
+                               reinterpret_cast<float*>(dx), N, H, W, Cout, Ccols, stride,
+                               accumulate, 1, (hipStream_t)stream, nullptr, 1, bs);
 }
 
 // Split-bf16 mode of the fused pipeline (wd3 = pre-split planes, data-gradient layout); bs may

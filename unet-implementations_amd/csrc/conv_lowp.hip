@@ -538,12 +538,14 @@ int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
 
 // bf16-storage gather-GEMM (sources / output bf16 in HBM); stats_px != nullptr: the fused-layer
 // forward (activation on load, statistics epilogue where every tile lies in one image)
-int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px) {
+int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px, int* bs_px) {
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
-  {   // stride-1 3x3 that tiles as 4 x 32 pixels: the patch-staged kernel (conv_patch.hip)
-    const int rc = launch_patch_b16_auto(p, stream, stats_px);
+  {   // stride-1 3x3 that tiles as 4 x 32 pixels: the patch-staged kernel (conv_patch.hip);
+      // only it has the BSTATS epilogue (bs_px), the gather-GEMM forms report 0 tiles
+    const int rc = launch_patch_b16_auto(p, stream, stats_px, bs_px);
     if (rc != 1) return rc;
+    if (bs_px) *bs_px = 0;
   }
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
     return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px);

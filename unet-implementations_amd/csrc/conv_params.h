@@ -237,14 +237,16 @@ bool patch_s2_applicable(const IgemmParams& p);               // stride-2 forwar
 int launch_patch_s2_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
 int launch_dgrad_s2_patch_auto(const IgemmParams& p, hipStream_t stream, int* bs_tiles_out);
 int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream);
-int launch_patch_b16_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);   // bf16 tensors
+int launch_patch_b16_auto(const IgemmParams& p, hipStream_t stream, int* stats_px,   // bf16 tensors
+                          int* bs_px = nullptr);
 int launch_patch_split_fused_auto(const IgemmParams& p, hipStream_t stream, int* stats_px,
                                   int* bs_px);
 bool patch_split_applicable(const IgemmParams& p);
 int dispatch_igemm(const IgemmParams& p, hipStream_t stream,           // conv_igemm.hip
                    int* stats_px = nullptr, int* bs_px = nullptr);
 int dispatch_igemm_bf16(const IgemmParams& p, hipStream_t stream);     // conv_lowp.hip
-int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px);  // bf16 storage
+int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px,   // bf16 storage
+                       int* bs_px = nullptr);
 int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream);    // conv_lowp.hip
 
 }  // namespace unet_conv

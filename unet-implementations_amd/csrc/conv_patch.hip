@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 // MFMAs per wave between barriers at 128 columns.  Weights stay fp32 in HBM (master copy) and
 // are rounded while staged.  LDS 16 KB patch + 61 KB weights at 128 columns (two per CU).
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParams p) {
   constexpr int BK = 32, LDA = BK + 8;       // bf16 elements per LDS row
   constexpr int TW = 32, PW = TW + 2;
@@ -772,6 +772,24 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
       for (int r = 0; r < 16; ++r)
         o[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldo] = (__bf16)acc[m][nb][r];
     }
+  }
+  if (BSTATS && p.bs_partial) {   // uniform: reductions of the NEXT backward stage, from the fp32
+    constexpr int WAVES_M = 4 / WAVES_N;   // accumulators and the bf16 raw outputs of that layer
+    float2* red = reinterpret_cast<float2*>(Ps);
+    const __bf16* ybase = reinterpret_cast<const __bf16*>(p.bs_y);
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const int col = n0 + wn0 + nb * 32 + li;
+      const BwdCoef cf = bwd_coef(p, n, col);
+      const __bf16* yb = ybase + (((size_t)n * H + (y0 + wrow0)) * W + x0 + 4 * lh) * p.ldo + col;
+      const float2 mine = wave_bwd_stats<TM>(
+          cf, p.slope, [&](int m, int r) { return acc[m][nb][r]; },
+          [&](int m, int r) { return (float)yb[((size_t)m * W + (r & 3) + 8 * (r >> 2)) * p.ldo]; });
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = mine;
+    }
+    float2 out;
+    if (block_col_sums<BN, WAVES_M>(red, out))
+      p.bs_partial[((size_t)n * p.bs_tiles + p.bs_tile0 + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
   }
   if (STATS && p.stats) {   // uniform; statistics of the fp32 accumulators (before the rounding)
     constexpr int WAVES_M = 4 / WAVES_N;
@@ -1616,10 +1634,10 @@ bool patch_s2_applicable(const IgemmParams& p) {
          p.tapw[2] == std_taps.tapw[2];
 }
 
-template <int BN, int WM, int WN, int TH, bool ACT, bool STATS>
+template <int BN, int WM, int WN, int TH, bool ACT, bool STATS, bool BSTATS = false>
 int launch_patch_b16_t(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = ((size_t)((TH + 2) * 34) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16);
-  auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS>;
+  auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS>;
   UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
@@ -1630,14 +1648,32 @@ int launch_patch_b16_t(const IgemmParams& p, hipStream_t stream) {
 // Mixed-precision pipeline (bf16 tensors): stride-1 3x3 whose image tiles as 4 x 32 pixels.
 // stats_px != nullptr = fused forward (activation on load + statistics), else data gradient.
 // Returns 1 when the shape does not qualify (the caller keeps the bf16 gather-GEMM).
-int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px, int* bs_px) {
   static const int off = getenv("UNET_NO_PATCH_B16") ? 1 : 0;
+  if (bs_px) *bs_px = 0;
   if (off || !patch_f32_applicable(p0) || p0.src0_pitch) return 1;
   IgemmParams p = p0;
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   const long long mt = M / 128;
   const bool fused = stats_px != nullptr;
+  if (!fused && bs_px && p.bs_partial) {   // data gradient with the BSTATS epilogue
+    p.bs_tile0 = 0;
+    if (nc % 128 == 0 && mt * (nc / 128) >= 256) {
+      *bs_px = 128; p.bs_tiles = p.Hin * p.Win / 128;
+      return launch_patch_b16_t<128, 64, 64, 4, false, false, true>(p, stream);
+    }
+    if (nc % 64 == 0 && mt * (nc / 64) >= 256) {
+      *bs_px = 128; p.bs_tiles = p.Hin * p.Win / 128;
+      return launch_patch_b16_t<64, 64, 32, 4, false, false, true>(p, stream);
+    }
+    if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 256) {
+      *bs_px = 256; p.bs_tiles = p.Hin * p.Win / 256;
+      return launch_patch_b16_t<32, 64, 32, 8, false, false, true>(p, stream);
+    }
+    return 1;
+  }
+  p.bs_partial = nullptr;
   if (nc % 128 == 0 && mt * (nc / 128) >= 256) {
     if (!fused) return launch_patch_b16_t<128, 64, 64, 4, false, false>(p, stream);
     *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;

@@ -604,6 +604,19 @@ extern "C" int unet_instnorm_lrelu_drop_bwd_b16(const uint16_t* ga, const uint16
                                    workspace, workspace_bytes, N, HW, C, (hipStream_t)stream_);
 }
 
+extern "C" int unet_instnorm_lrelu_drop_bwd_partials_b16(
+    const uint16_t* ga, const uint16_t* y, const float* mean, const float* rstd,
+    const float* gamma, const float* beta, const float* mask, float slope, uint16_t* dy,
+    float* dgamma, float* dbeta, float* dbias, const void* partial, int tiles, void* workspace,
+    size_t workspace_bytes, int N, int HW, int C, unet_stream_t stream) {
+  UNET_REQUIRE(partial && tiles > 0, "instnorm_lrelu_drop_bwd_partials_b16: no summaries");
+  return instnorm_bwd_impl<__bf16>(reinterpret_cast<const __bf16*>(ga),
+                                   reinterpret_cast<const __bf16*>(y), mean, rstd, gamma, beta,
+                                   mask, slope, reinterpret_cast<__bf16*>(dy), dgamma, dbeta, dbias,
+                                   workspace, workspace_bytes, N, HW, C, (hipStream_t)stream,
+                                   reinterpret_cast<const float2*>(partial), tiles);
+}
+
 template <typename TS>
 static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, const float* mask, float slope,

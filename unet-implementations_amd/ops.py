@@ -250,9 +250,17 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
         dx = out if out is not None else _b16((N, H, W, ccols), dy)
         assert dx.shape == (N, H, W, ccols) and _is_b16(dx)
         t0 = _timer.begin("conv") if _timer is not None else None
-        check(lib().unet_conv3x3_bwd_data_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx),
-                                              N, H, W, Cout, ccols, stride,
-                                              1 if accumulate else 0, _stream()))
+        if nxt is not None:
+            bs = nxt.c_struct()
+            check(lib().unet_conv3x3_bwd_data_bs_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset,
+                                                     _ptr(dx), N, H, W, Cout, ccols, stride,
+                                                     1 if accumulate else 0, ctypes.byref(bs),
+                                                     _stream()))
+            nxt.tiles = bs.tiles_out
+        else:
+            check(lib().unet_conv3x3_bwd_data_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx),
+                                                  N, H, W, Cout, ccols, stride,
+                                                  1 if accumulate else 0, _stream()))
         if t0 is not None:
             _timer.end("conv_igemm_bf16", 2.0 * N * Ho * Wo * 9 * ccols * Cout,
                        1 if stride == 1 else 4, t0)
@@ -382,14 +390,16 @@ def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma,
     N, H, W, C = y.shape
     dy = ga if out is None else out
     ws = _ws(lib().unet_instnorm_workspace_bytes(N, H * W, C), y)
-    if partials is not None and not _is_b16(y):
+    if partials is not None:
+        fnp = lib().unet_instnorm_lrelu_drop_bwd_partials_b16 if _is_b16(y) else \
+            lib().unet_instnorm_lrelu_drop_bwd_partials
         t0 = _timer.begin() if _timer is not None else None
-        check(lib().unet_instnorm_lrelu_drop_bwd_partials(
+        check(fnp(
             _ptr(ga), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(mask), slope,
             _ptr(dy), _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(partials[0]), partials[1],
             _ptr(ws), ws.numel(), N, H * W, C, _stream()))
         if t0 is not None:   # apply pass only: ga + y in, dy out
-            _timer.end("instnorm_bwd", 0.0, 2, t0, nbytes=4.0 * 3 * y.numel())
+            _timer.end("instnorm_bwd", 0.0, 2, t0, nbytes=y.element_size() * 3.0 * y.numel())
         return dy
     fn = lib().unet_instnorm_lrelu_drop_bwd_b16 if _is_b16(y) else lib().unet_instnorm_lrelu_drop_bwd
     if _is_b16(y) != _is_b16(ga):

@@ -655,7 +655,7 @@ class _UNetFunction(torch.autograd.Function):
             # halves dx1 are accumulated into later, by the encoder): its producer also emits
             # that layer's InstanceNorm-backward reductions
             nxt = None
-            if fused and not b16_bwd and need_dx and i > 0:
+            if fused and need_dx and i > 0:
                 pr_ = saved[i - 1]
                 pl_ = pr_["layer"]
                 nxt = ops.NextNorm(pr_["y"], pr_["st"], pl_.norm.weight.detach(),
