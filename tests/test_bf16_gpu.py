@@ -138,7 +138,10 @@ def test_conv_in_bwd_weight_b16(ua, case):
 
 
 @pytest.mark.parametrize("case", [(2, 12, 20, 32, 64, 1), (1, 16, 32, 64, 64, 2),
-                                  (2, 32, 32, 128, 32, 1)])
+                                  (2, 32, 32, 128, 32, 1),
+                                  (2, 256, 256, 64, 32, 2),    # stride-2 patch kernel, 64 columns
+                                  (2, 512, 512, 32, 64, 2),    # stride-2 patch kernel, 32 columns x 8 rows
+                                  (1, 128, 256, 64, 96, 2)])   # three K chunks, H != W
 def test_conv3x3_bwd_data_b16(ua, case):
     N, H, W, Cin, Cout, stride = case
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1

@@ -1405,6 +1405,10 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
         return rc;
       }
     }
+    if (b16 && !per_class) {   // mixed-precision pipeline: one launch instead of four per class
+      const int rc = launch_dgrad_s2_patch_b16_auto(p, stream);
+      if (rc != 1) return rc;
+    }
     if (prec != 1 && !b16 && !per_class && tiles >= 512) {
       p.py = p.px = 0; p.ntaps = 9;
       if (use_bs && (p.Hl * p.Wl) % 128 == 0) p.bs_tiles = p.Hl * p.Wl / 128;

@@ -1250,6 +1250,199 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_kernel(const Igemm
 }
 
 // ---------------------------------------------------------------------------
+// The stride-2 data gradient of the mixed-precision pipeline (bf16 dy / dx, bf16 matrix cores):
+// geometry of conv_dgrad_s2_patch_kernel (dy patch of TH+1 rows x 33 columns staged once per
+// 32-channel chunk, nine taps into four parity-class accumulators), LDS rows of 40 bf16, and -
+// as a tap is only 2 x TM x TN MFMAs at the bf16 rate - three taps (three weight panels staged
+// together) per barrier.  Replaces sixteen per-class gather-GEMM launches per step.
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN, int TH>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const IgemmParams p) {
+  constexpr int BK = 32, LDA = BK + 8;
+  constexpr int TW = 32, PW = TW + 1, PH = TH + 1;
+  constexpr int PPIX = PH * PW;
+  constexpr int P_SLOTS = PPIX * 8;          // 4-channel slots
+  constexpr int P_PASSES = (P_SLOTS + 255) / 256;
+  constexpr int B_SLOTS = 3 * BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  constexpr int B_TILE = 3 * BN * LDA;       // three taps per step
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((TH * 32 / WM) * (BN / WN) == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* Ps = smem_h;                       // [dy pixel][LDA]
+  __bf16* Bs = smem_h + PPIX * LDA;          // [buf][tap in step][BN][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
+
+  const int Hl = p.Hl, Wl = p.Wl;            // dy grid
+  const int tiles_n = p.Ncols / BN, tiles_x = Wl / TW, tiles_y = Hl / TH;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n; bid /= tiles_n;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int Ktot = p.C0;                     // Cout of the forward convolution
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  int pp_lin[P_PASSES], pp_lds[P_PASSES];
+  unsigned pp_oob[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = (tid + 256 * i) % P_SLOTS;
+    const int pix = slot >> 3, seg = slot & 7;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    const int iy = y0 + prow, ix = x0 + pcol;
+    const bool ok = iy < Hl && ix < Wl;
+    pp_lin[i] = ok ? (n * Hl + iy) * Wl + ix : 0;
+    pp_oob[i] = ok ? 0u : 0x80000000u;
+    pp_lds[i] = pix * LDA + seg * 4;
+  }
+  const int seg4 = (tid & 7) * 4;
+  unsigned wslot_off[B_PASSES];
+  int wslot_lds[B_PASSES], wslot_tap[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    const int slot = (tid + 256 * j) % B_SLOTS;
+    const int tr = slot / (BN * 8), rem = slot - tr * BN * 8;
+    const int row = rem >> 3, seg = rem & 7;
+    wslot_tap[j] = tr;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
+    wslot_lds[j] = (tr * BN + row) * LDA + seg * 4;
+  }
+
+  f32x4 pr[P_PASSES], rb[B_PASSES];
+  f32x16 acc[4][TM][TN];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int nb = 0; nb < TN; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][m][nb][r] = 0.f;
+
+  auto to_bf16 = [](const f32x4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+    return h;
+  };
+  auto load_patch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i)
+      pr[i] = buf_ld4<__bf16>(rs0, (unsigned)(pp_lin[i] * Ktot + chunk * BK + seg4), pp_oob[i]);
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(pr[i]);
+  };
+  auto load_b = [&](auto step_tag, int chunk) {   // the three taps 3*step .. 3*step+2
+    constexpr int st = decltype(step_tag)::value;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const int wt = wslot_tap[j] == 0 ? kS2PTaps[3 * st].ky * 3 + kS2PTaps[3 * st].kx
+                   : wslot_tap[j] == 1 ? kS2PTaps[3 * st + 1].ky * 3 + kS2PTaps[3 * st + 1].kx
+                                       : kS2PTaps[3 * st + 2].ky * 3 + kS2PTaps[3 * st + 2].kx;
+      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsw, wslot_off[j] + woff, 0, 0));
+    }
+  };
+  auto store_b = [&](int buf) {
+    __bf16* Bb = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS)
+        *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[j]);
+  };
+
+  const int chunks = Ktot / BK;
+  load_patch(0);
+  load_b(std::integral_constant<int, 0>{}, 0);
+  store_patch();
+  store_b(0);
+  __syncthreads();
+
+  const int a_lane = (wrow0 * PW + li) * LDA + 8 * lh;
+  const int b_lane = (wn0 + li) * LDA + 8 * lh;
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const int chunk_n = chunk + 1 < chunks ? chunk + 1 : chunk;   // the last chunk re-stages itself
+    for_range_p<0, 3>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      constexpr int st1 = st == 2 ? 0 : st + 1;
+      const int buf = (chunk + st) & 1;   // step = 3 * chunk + st
+      load_b(std::integral_constant<int, st1>{}, st == 2 ? chunk_n : chunk);
+      if (st == 0) load_patch(chunk_n);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        constexpr S2PTap T0 = kS2PTaps[3 * st], T1 = kS2PTaps[3 * st + 1], T2 = kS2PTaps[3 * st + 2];
+        const S2PTap T = j == 0 ? T0 : (j == 1 ? T1 : T2);
+        const __bf16* Ab = Ps + a_lane + (T.oy * PW + T.ox) * LDA;
+        const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 a[TM], b[TN];
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+            a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int nb = 0; nb < TN; ++nb) {
+              // T.cls is a compile-time value once j is unrolled
+              if (T.cls == 0) acc[0][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[0][m][nb], 0, 0, 0);
+              else if (T.cls == 1) acc[1][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[1][m][nb], 0, 0, 0);
+              else if (T.cls == 2) acc[2][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[2][m][nb], 0, 0, 0);
+              else acc[3][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[3][m][nb], 0, 0, 0);
+            }
+        }
+      }
+      store_b(buf ^ 1);
+      if (st == 2) {            // every wave is done with this chunk's patch
+        __syncthreads();
+        store_patch();
+      }
+      __syncthreads();
+    });
+  }
+
+  // ---- epilogue: class c -> dx pixel (2a + c/2, 2b + c%2), column li ----
+  __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const int col = n0 + wn0 + nb * 32 + li;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t pix = ((size_t)n * p.Hout + 2 * (y0 + wrow0 + m) + (c >> 1)) * p.Wout +
+                           2 * (x0 + 4 * lh) + (c & 1);
+        __bf16* o = outp + pix * p.ldo + col;
+        if (p.accumulate) {        // uniform
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            old[r] = (float)o[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][m][nb][r] += old[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo] = (__bf16)acc[c][m][nb][r];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // First convolution of a decoder stage: y = conv3x3(cat(upsample2x(act(low)), act(skip))) with the
 // bilinear up-sampling done INSIDE the patch loader (Our_UNet/models/unet.py:215-231: the
 // reference materialises both the up-sampled tensor and the concatenation).  Source 0 is the
@@ -1597,6 +1790,30 @@ int launch_dgrad_s2_patch(const IgemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+template <int BN, int WM, int WN, int TH>
+int launch_dgrad_s2_patch_b16(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((TH + 1) * 33) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16);
+  auto kern = conv_dgrad_s2_patch_b16_kernel<BN, WM, WN, TH>;
+  UNET_SET_DYN_LDS(kern, lds);
+  const long long tiles = (long long)p.N * (p.Hl / TH) * (p.Wl / 32) * (p.Ncols / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_dgrad_s2_patch_b16");
+  return UNET_OK;
+}
+
+// The same for the mixed-precision pipeline (bf16 dy / dx); no BSTATS epilogue.
+int launch_dgrad_s2_patch_b16_auto(const IgemmParams& p, hipStream_t stream) {
+  static const int off = getenv("UNET_NO_PATCH_S2") ? 1 : 0;
+  if (off || p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
+  const long long pos = (long long)p.N * p.Hl * p.Wl;
+  const int nc = p.Ncols;
+  if (nc % 64 == 0 && p.Hl % 4 == 0 && pos / 128 * (nc / 64) >= 256)
+    return launch_dgrad_s2_patch_b16<64, 32, 64, 4>(p, stream);
+  if (nc == 32 && p.Hl % 8 == 0 && pos / 256 >= 256)
+    return launch_dgrad_s2_patch_b16<32, 64, 32, 8>(p, stream);
+  return 1;
+}
 
 // Stride-2 data gradient on the patch-staged kernel: p describes the dy grid (Hl x Wl, K = C0,
 // fp32) and dx = (2 Hl) x (2 Wl) x Ncols.  Returns 1 when the shape does not tile or too few
