@@ -197,6 +197,38 @@ def test_tie_free_network_gradients_per_element(ua, golden, fused):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
+def test_train_step_is_run_to_run_deterministic(ua, mode):
+    """No float atomics anywhere: every partial sum (split-K slabs, K groups, statistics and
+    backward-reduction tiles, loss reductions) is combined in a fixed order, so two train steps
+    from the same state give bit-identical logits, loss, gradients and updated parameters - in
+    all three operand modes, at a size where every kernel family is in play."""
+    sd0 = O.fill_state_dict(21)
+    img, tgt = O.synthetic_batch(4, 2, 256, 256)
+    masks = O.draw_dropout_masks(8, 2)
+    outs = []
+    for _ in range(2):
+        model = ua.UNet()
+        model.load_state_dict(sd0)
+        model = model.to(DEV).train()
+        model.matmul_precision = mode
+        model.dropout_mask_override = masks
+        opt = ua.create_optimizer(model)
+        logits = model(img.to(DEV))
+        loss = ua.get_loss_function()(logits, tgt.to(DEV))
+        opt.zero_grad()
+        loss.backward()
+        arena, garena = model.flat_parameters()
+        g = garena.clone()
+        opt.step()
+        outs.append((logits.detach().clone(), loss.item(), g, arena.clone()))
+        del model, opt
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    assert torch.equal(a[2], b[2]), "gradients differ between two identical runs"
+    assert torch.equal(a[3], b[3])
+
+
 SWEEP = [(1, 64, 64), (3, 96, 160), (2, 128, 256), (1, 320, 192), (5, 256, 256), (2, 384, 384),
          (1, 512, 512)]
 
