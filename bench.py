@@ -73,25 +73,29 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
     peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
             "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[matmul]
     traffic, src = hbm_traffic(args) if matmul == "fp32" else (None, None)
+    exe = k["executed"] / sec * 1e-12
     roof = {
-        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        # `achieved` / `frac`: the MFMA FLOPs the kernels actually ISSUE over their measured time
+        # (matrix-pipe utilisation against the dense peak).  The data gradient of the up-sampled
+        # operand runs on the low-resolution grid and issues 1/4 of the reference layer's 3x3
+        # FLOPs; crediting the reference's (algorithmic) count gives `algorithmic` /
+        # `algorithmic_frac`, which is the figure to compare with a direct convolution.
+        "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s", "frac": exe / peak,
+        "algorithmic": ach, "algorithmic_frac": ach / peak,
         "traffic": traffic, "traffic_source": src,
-        # MFMA FLOPs actually issued: the data gradient of the up-sampled operand runs on the
-        # low-resolution grid (1/4 of the algorithmic 3x3 work), everything else executes its
-        # algorithmic count
-        "executed": k["executed"] / sec * 1e-12, "executed_frac": k["executed"] / sec * 1e-12 / peak,
         "kernel": "convolution forward + data-gradient group ("
                   + {"fp32": "conv_patch_f32_kernel, conv_patch_up_kernel, conv_patch_s2_kernel, "
-                             "conv_c32_kernel, conv_igemm_kernel, conv_dgrad_s2_kernel",
-                     "bf16": "conv_igemm_bf16_kernel on bf16 tensors",
+                             "conv_c32_kernel, conv_igemm_kernel, conv_dgrad_s2_patch_kernel",
+                     "bf16": "conv_patch_b16_kernel, conv_igemm_bf16_kernel on bf16 tensors",
                      "bf16x3": "conv_patch_split_kernel on the fused pipeline + the fp32 kernels "
                                "for the shapes it does not tile (stride 2, 1/32 resolution)"}[matmul] + "): "
                   f"{k['flops'] / steps * 1e-12:.3f} of the step's "
                   f"{total / steps * 1e-12:.3f} algorithmic conv TFLOP",
         "launches_per_step": k["launches"] / steps,
         "avg_launch_us": 1e3 * k["ms"] / k["launches"],
-        "flop_per_step": k["flops"] / steps,
-        "flop_per_launch": k["flops"] / k["launches"],
+        "flop_per_step": k["executed"] / steps,
+        "flop_per_launch": k["executed"] / k["launches"],
+        "algorithmic_flop_per_launch": k["flops"] / k["launches"],
     }
     return roof, groups
 
@@ -160,6 +164,24 @@ def cpu_baseline(steps=8, hw=512, n=2):
                       f"after 1 warm-up step"}
 
 
+def self_launch(n):
+    """Run this command line under `python -m torch.distributed.run --nproc-per-node n` as a
+    child process (never exec: the parent stays a plain launcher that has not touched the GPU)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,10 +190,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--hw", type=int, default=512)
     ap.add_argument("--matmul", choices=["fp32", "bf16", "bf16x3"], default="fp32",
-                    help="fp32 = fp32 matrix cores; bf16 = BASELINE config 4 (bf16 MFMA operands, "
-                         "fp32 accumulate/storage); bf16x3 = fp32 operands split into three bf16 "
-                         "terms, six products per multiply on the bf16 matrix cores (fp32-class "
-                         "accuracy, see DESIGN.md)")
+                    help="fp32 = fp32 matrix cores; bf16 = BASELINE config 4 (bf16 layer tensors in "
+                         "HBM and bf16 MFMA operands; fp32 accumulate, statistics, master weights "
+                         "and optimizer); bf16x3 = fp32 operands split into three bf16 terms, six "
+                         "products per multiply on the bf16 matrix cores (fp32-class accuracy, see "
+                         "DESIGN.md)")
     ap.add_argument("--clip", action="store_true",
                     help="BASELINE config 5: CLIP_UNet variant with synthetic CLIP features")
     ap.add_argument("--loss-sync", choices=["local", "global"], default="local",
@@ -184,13 +207,19 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process
+        # per GPU through torch.distributed.run) BEFORE this process touches the GPU, relay rank
+        # 0's JSON line and exit with the launcher's code
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("UNET_SHARE_GPU"):   # rehearsal: every rank on device 0
         local_rank = 0
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's "
+                         "--nproc-per-node must equal --gpus")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -199,15 +228,29 @@ def main():
     from unet_implementations_amd import ddp
 
     backend_used = None
-    if world > 1:
+    # UNET_BENCH_RCCL=1 at N=1: a one-rank RCCL group, so the fence's barrier, the MAX all-reduce
+    # of the step time and the bucketed gradient all-reduces (always_reduce) really go through
+    # RCCL in the bench itself (a rehearsal of the N>1 call path on the one GPU of a test box)
+    solo_rccl = world == 1 and bool(os.environ.get("UNET_BENCH_RCCL"))
+    use_dist = world > 1 or solo_rccl
+    if use_dist:
         # backend "nccl" is RCCL on ROCm; UNET_DIST_BACKEND=gloo lets the N>1 path be rehearsed
         # with several ranks sharing one GPU (RCCL refuses duplicate devices)
         backend = os.environ.get("UNET_DIST_BACKEND", "nccl")
         backend_used = backend if backend != "nccl" else "nccl (RCCL)"
+        if solo_rccl:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                sock = socket.socket()
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+                sock.close()
+        kw = dict(rank=rank, world_size=world) if solo_rccl else {}
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, **kw)
 
     torch.manual_seed(1234)          # same initial replica on every rank
     if args.clip:
@@ -219,9 +262,10 @@ def main():
     lossf = ua.get_loss_function()
     lossf.batch_sync = args.loss_sync
     sync = None
-    if world > 1:
+    if use_dist:
         ddp.broadcast_parameters(model)
-        sync = ddp.GradBucketAllReduce(model, opt, average=args.loss_sync != "global")
+        sync = ddp.GradBucketAllReduce(model, opt, average=args.loss_sync != "global",
+                                       always_reduce=solo_rccl)
     img, tgt = synthetic_batch(1234 + rank, args.batch, args.hw, args.hw)
     img, tgt = img.to(dev), tgt.to(dev)
     torch.manual_seed(99 + rank)     # dropout stream differs per rank
@@ -260,7 +304,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -272,7 +316,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ua.ops.set_timer(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -280,6 +324,20 @@ def main():
     if not (final_loss == final_loss):
         raise SystemExit("loss is NaN")
     gsumm, gsteps = groups_pass() if timer is not None else (None, None)
+
+    def enqueue_ms(reps=5):
+        """Host time to ENQUEUE one step onto an idle stream (median of `reps`): the Python /
+        ctypes walk over the ~330 entry points, no HIP events, no waiting on the device."""
+        ts = []
+        for _ in range(reps):
+            fence()
+            t = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t)
+        fence()
+        return 1e3 * sorted(ts)[len(ts) // 2]
+
+    enqueue = enqueue_ms()
 
     # Beside the fp32-matrix-core headline, the same K steps in the two other operand modes
     # (reported, never `value`): the split-bf16 ("bf16x3") mode, which holds the same reference
@@ -317,12 +375,13 @@ def main():
             fence()
             dt_alt = time.perf_counter() - t1
             ua.ops.set_timer(None)
-            if world > 1:
+            if use_dist:
                 t = torch.tensor([dt_alt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_alt = t.item()
             alt[mode] = {"value": args.batch * world * args.steps / dt_alt, "unit": "images/s",
-                         "ms_per_step": 1e3 * dt_alt / args.steps, "dtype": ALT[mode]["dtype"],
+                         "ms_per_step": 1e3 * dt_alt / args.steps,
+                         "enqueue_ms_per_step": enqueue_ms(), "dtype": ALT[mode]["dtype"],
                          "parity": ALT[mode]["parity"]}
             if alt_timer is not None:
                 asumm, asteps = groups_pass(2)
@@ -355,6 +414,9 @@ def main():
                        "parallelism": f"dp{world}", "world": world,
                        "dist_backend": backend_used},
             "final_loss": final_loss,
+            # host time to enqueue one step (Python + ctypes, idle stream); the step is
+            # launch-bound when this approaches ms_per_step
+            "enqueue_ms_per_step": enqueue,
             "step_tflops": value / world * GFLOP_PER_IMAGE * 1e-3,
             "step_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * 1e-3 / PEAK_F32_MFMA_TFLOPS,
         }
@@ -371,7 +433,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -183,3 +183,57 @@ def test_finish_refuses_gradients_outside_the_arena():
             sync.finish()
     finally:
         dist.destroy_process_group()
+
+
+def test_sent_ranges_keep_one_step_only():
+    """`sent_ranges` serves the tests; it must not grow with the number of steps."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from unet_implementations_amd import ddp
+        m = _M(frozen=(False, False, False))
+        sync = ddp.GradBucketAllReduce(m, None, bucket_bytes=4 * 20)
+        for _ in range(5):
+            for lo in (90, 70, 40, 0):
+                m.grad_ready_hook(lo)
+            sync.finish()
+            covered = sorted(sync.sent_ranges)
+            assert covered[0][0] == 0 and covered[-1][1] == 100
+            assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            assert len(sync.sent_ranges) <= 4
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE starts its own N ranks through
+    torch.distributed.run as a CHILD process (the parent never touches the GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    class _R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -167,6 +167,43 @@ def test_bench_two_ranks_through_torch_distributed_run():
     assert abs(r["value"] - 4 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]
 
 
+def _run_bench(args, extra_env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_without_a_launcher():
+    """`python bench.py --gpus 2` exactly as a driver might type it (no torch.distributed.run):
+    bench.py starts its own two ranks as child processes and relays rank 0's JSON line."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--hw", "64",
+                    "--no-alt", "--no-cpu-baseline"],
+                   dict(UNET_SHARE_GPU="1", UNET_DIST_BACKEND="gloo"))
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["config"]["world"] == 2 and r["config"]["dist_backend"] == "gloo"
+    assert r["config"]["global_batch"] == 4 and r["value"] > 0
+
+
+def test_bench_single_gpu_through_a_one_rank_rccl_group():
+    """UNET_BENCH_RCCL=1: the N=1 bench runs its fence barrier, the MAX all-reduce of the step
+    time and the bucketed gradient all-reduces through RCCL (backend nccl, one rank)."""
+    r = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--hw", "64",
+                    "--no-alt", "--no-cpu-baseline"], dict(UNET_BENCH_RCCL="1"))
+    assert r["n_gpus"] == 1 and r["config"]["world"] == 1
+    assert r["config"]["dist_backend"] == "nccl (RCCL)" and r["value"] > 0
+    assert r["roofline"]["frac"] > 0 and "enqueue_ms_per_step" in r
+
+
 def _worker_rccl(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -35,7 +35,10 @@ class GradBucketAllReduce:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._works = []
         self._hi = None
-        self.sent_ranges = []    # (lo, hi) arena ranges handed to all_reduce, newest last
+        self._prefix = 0         # frozen prefix of the arena, looked up once per backward
+        # (lo, hi) arena ranges handed to all_reduce during the CURRENT / most recent step,
+        # newest last (reset when a new backward starts, so a long run keeps one step's worth)
+        self.sent_ranges = []
         # always_reduce: issue the collectives even in a one-rank group (a rehearsal of the RCCL
         # call path - streams, async work handles - on a single GPU; the sums are identities)
         self.always_reduce = always_reduce
@@ -45,10 +48,14 @@ class GradBucketAllReduce:
 
     # called from UNet backward: every gradient at arena offsets >= lo is final
     def _on_ready(self, lo):
-        _, garena = self.model.flat_parameters()
-        if self._hi is None:
+        garena = getattr(self.model, "_grad_arena", None)   # built by forward before any hook call
+        if garena is None:
+            _, garena = self.model.flat_parameters()
+        if self._hi is None:                 # first hook call of this backward
             self._hi = garena.numel()
-        if self._hi - lo >= self.bucket_elems or lo <= self._frozen_prefix():
+            self._prefix = self._frozen_prefix()
+            self.sent_ranges = []
+        if self._hi - lo >= self.bucket_elems or lo <= self._prefix:
             self._launch(garena, lo, self._hi)
             self._hi = lo
 
@@ -63,8 +70,10 @@ class GradBucketAllReduce:
 
     def _frozen_prefix(self):
         """Arena offset of the first trainable parameter: a frozen encoder prefix (AE transfer,
-        Our_UNet/src/train.py:800-859) produces no gradient and is left out of the exchange."""
-        self.model.flat_parameters()
+        Our_UNet/src/train.py:800-859) produces no gradient and is left out of the exchange.
+        A 90-parameter walk: called once per backward (`_on_ready` caches it in `_prefix`)."""
+        if getattr(self.model, "_offsets", None) is None:
+            self.model.flat_parameters()
         offsets = getattr(self.model, "_offsets", None)
         if offsets is None or not hasattr(self.model, "parameters"):
             return 0
@@ -94,7 +103,7 @@ class GradBucketAllReduce:
         self.check_gradients_alias_arena()
         if self._hi is not None and self._hi > 0 and (self.world > 1 or self.always_reduce):
             _, garena = self.model.flat_parameters()
-            self._launch(garena, self._frozen_prefix(), self._hi)
+            self._launch(garena, self._prefix, self._hi)
         for w in self._works:
             w.wait()
         self._works = []
