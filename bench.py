@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the second timed loop that reports the bf16x3 operand mode beside "
                          "the fp32 headline (same model, same K steps)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="skip the extra leg that replays the step from a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -339,6 +341,31 @@ def main():
 
     enqueue = enqueue_ms()
 
+    def graph_leg():
+        """The same K steps replayed from ONE HIP graph (ua.GraphedTrainStep): what the step
+        costs once the host walk is out of the way.  Single process, plain UNet only (the
+        bucketed all-reduce hook is not captured)."""
+        if use_dist or args.clip or args.no_graph:
+            return None
+        gstep = ua.GraphedTrainStep(model, opt, lossf, img, tgt)
+        for _ in range(2):
+            gstep(img, tgt)
+        fence()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            gstep(img, tgt)
+        t_enq = time.perf_counter() - t
+        fence()
+        dt_g = time.perf_counter() - t
+        opt.use_device_hyper(False)
+        return {"value": args.batch * args.steps / dt_g, "unit": "images/s",
+                "ms_per_step": 1e3 * dt_g / args.steps,
+                "enqueue_ms_per_step": 1e3 * t_enq / args.steps,
+                "note": "train step captured once in a HIP graph and replayed (same kernels, "
+                        "same order; dropout masks drawn inside the graph)"}
+
+    graph = graph_leg()
+
     # Beside the fp32-matrix-core headline, the same K steps in the two other operand modes
     # (reported, never `value`): the split-bf16 ("bf16x3") mode, which holds the same reference
     # fixtures and tolerances as fp32 (tests/test_net_gpu.py,
@@ -383,6 +410,9 @@ def main():
                          "ms_per_step": 1e3 * dt_alt / args.steps,
                          "enqueue_ms_per_step": enqueue_ms(), "dtype": ALT[mode]["dtype"],
                          "parity": ALT[mode]["parity"]}
+            g_alt = graph_leg()
+            if g_alt is not None:
+                alt[mode]["graph_replay"] = g_alt
             if alt_timer is not None:
                 asumm, asteps = groups_pass(2)
             if alt_timer is not None and rank == 0:
@@ -428,6 +458,8 @@ def main():
             result["kernel_groups_pass"] = (f"{gsteps} extra steps after the timed region with every "
                                             "entry point bracketed by HIP events (the timed region "
                                             "brackets only the roofline group)")
+        if graph is not None:
+            result["graph_replay"] = graph
         if alt is not None:
             result["alt_modes"] = alt
         if world == 1 and not args.no_cpu_baseline:

@@ -290,6 +290,12 @@ int unet_sgd_nesterov_step(float* params, const float* grads, float* momentum, i
                            float lr, float mu, float weight_decay, int first_step,
                            float grad_scale, unet_stream_t stream);
 
+/* The same with the hyper-parameters read from DEVICE memory, hyper = {lr, mu, weight_decay,
+ * grad_scale}: a train step captured in a HIP graph keeps following the learning-rate schedule
+ * (the reference steps it per epoch, Our_UNet/src/train.py:940) without being re-captured. */
+int unet_sgd_nesterov_step_dev(float* params, const float* grads, float* momentum, int64_t n,
+                               const float* hyper, int first_step, unet_stream_t stream);
+
 /* out[i] = a[i] + b[i] (gradient accumulation of skip tensors, test helper) */
 int unet_add_inplace(float* a, const float* b, int64_t n, unet_stream_t stream);
 

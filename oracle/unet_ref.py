@@ -147,7 +147,8 @@ def _operand_bf16(w):
     return w + (w.bfloat16().float() - w).detach()
 
 
-def conv_in_lrelu_drop_bf16(x, w, b, gamma, beta, stride, mask=None, slope=NEG_SLOPE):
+def conv_in_lrelu_drop_bf16(x, w, b, gamma, beta, stride, mask=None, slope=NEG_SLOPE,
+                            record=None):
     """The conv -> InstanceNorm -> LeakyReLU -> dropout unit with the rounding points of the
     MI355X mixed-precision pipeline (BASELINE config 4; the reference's own AMP path is fp16
     autocast, Our_UNet/src/train.py:638-652): operands of the convolution rounded to bf16, fp32
@@ -163,20 +164,43 @@ def conv_in_lrelu_drop_bf16(x, w, b, gamma, beta, stride, mask=None, slope=NEG_S
     a = F.leaky_relu(z, slope)
     if mask is not None:
         a = a * mask.view(mask.shape[0], mask.shape[1], 1, 1)
+    if record is not None:      # debug: (raw output, activation) with their gradients retained
+        if y.requires_grad:
+            y.retain_grad()
+            a.retain_grad()
+        record.append((y, a))
     return a
 
 
-def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None, slope=NEG_SLOPE):
+def conv_in_lrelu_drop(x, w, b, gamma, beta, stride, mask=None, record=None, slope=NEG_SLOPE,
+                       branch=None, tie_eps=0.0, tie_diag=None):
     """Conv2d(3x3, pad 1) -> InstanceNorm2d(eps, affine) -> LeakyReLU(0.01) -> channel mask
     (models/unet.py:101-134; SpatialDropout2d.forward :22-35).  `record` (debug): list that
-    receives the raw conv output with retain_grad set."""
+    receives the raw conv output with retain_grad set.
+    `branch` (test hook, tie-aware comparison): a bool tensor "z > 0" decided by ANOTHER fp32
+    implementation of the same layer.  Where this run's own pre-activation is within `tie_eps`
+    of zero - where two fp32 implementations may legitimately land on different sides - the
+    LeakyReLU takes that decision instead of its own, so both runs differentiate the same
+    piecewise-linear function; elsewhere the two must agree (counted in `tie_diag`)."""
     y = F.conv2d(x, w, b, stride=stride, padding=1)
     if record is not None:
         if y.requires_grad:
             y.retain_grad()
         record.append(y)
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=EPS)
-    y = F.leaky_relu(y, slope)   # `slope` = nonlin_kwargs["negative_slope"] of the reference ctor
+    if branch is not None:
+        own = y.detach() > 0
+        risky = y.detach().abs() < tie_eps
+        if tie_diag is not None:
+            tie_diag["risky"] = tie_diag.get("risky", 0) + int(risky.sum())
+            tie_diag["taken_from_other"] = tie_diag.get("taken_from_other", 0) + \
+                int((risky & (own != branch)).sum())
+            tie_diag["disagree_away_from_ties"] = tie_diag.get("disagree_away_from_ties", 0) + \
+                int((~risky & (own != branch)).sum())
+        pos = torch.where(risky, branch, own)
+        y = torch.where(pos, y, y * slope)
+    else:
+        y = F.leaky_relu(y, slope)   # `slope` = nonlin_kwargs["negative_slope"] of the reference ctor
     if mask is not None:
         y = y * mask.view(mask.shape[0], mask.shape[1], 1, 1)
     return y
@@ -191,7 +215,7 @@ def upsample_concat(x, skip):
 
 # --------------------------------------------------------------------------- network
 def unet_forward(sd, x, masks=None, record=None, clip_features=None, slope=NEG_SLOPE,
-                 bf16_storage=False):
+                 bf16_storage=False, branches=None, tie_eps=0.0, tie_diag=None):
     """UNet.forward (models/unet.py:399-432).  `masks`: list from draw_dropout_masks (train
     mode) or None (eval / rates 0).  `record` (debug): collects each conv's raw output.
     `clip_features` [N,clip_dim,h/32,w/32]: the CLIP_UNet bottleneck fusion
@@ -214,13 +238,14 @@ def unet_forward(sd, x, masks=None, record=None, clip_features=None, slope=NEG_S
         if bf16_storage:     # emulation of the MI355X mixed-precision pipeline's rounding points
             cur = conv_in_lrelu_drop_bf16(cur, sd[f"{prefix}.{ci}.weight"],
                                           sd[f"{prefix}.{ci}.bias"], sd[f"{prefix}.{ni}.weight"],
-                                          sd[f"{prefix}.{ni}.bias"], stride, m, slope)
+                                          sd[f"{prefix}.{ni}.bias"], stride, m, slope, record)
             if kind == "enc" and li % 2 == 1 and li < n_enc - 1:
                 skips.append(cur)
             continue
         cur = conv_in_lrelu_drop(cur, sd[f"{prefix}.{ci}.weight"], sd[f"{prefix}.{ci}.bias"],
                                  sd[f"{prefix}.{ni}.weight"], sd[f"{prefix}.{ni}.bias"], stride, m,
-                                 record, slope)
+                                 record, slope, None if branches is None else branches[li],
+                                 tie_eps, tie_diag)
         if kind == "enc" and li % 2 == 1 and li < n_enc - 1:
             skips.append(cur)
     return F.conv2d(cur, sd["segmentation_output.weight"], sd["segmentation_output.bias"])

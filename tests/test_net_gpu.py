@@ -106,10 +106,14 @@ def run_golden(ua, g, full, precision="fp32", fused=True):
                 # the reference's own fp32 run deviates from fp64 by 1e-3..1.5e-2 of max|g| at
                 # 512x512 (profiles/r01_grad_accuracy_vs_fp64_512.txt): LeakyReLU tie flips
                 tol = 1e-2 * max(ref_s.abs().max().item(), ref_norm / gk.numel() ** 0.5)
-                # at most 10 % of the samples beyond tol (tie flips), none beyond 5 tol; the
-                # element-by-element check is test_tie_free_network_gradients_per_element
-                if (err > tol).sum().item() > 0.1 * err.numel() or err.max().item() > 5 * tol:
-                    bad.append(f"{k}: sampled grad err {err.max().item():.3e} (tol {tol:.3e})")
+                # an absolute cap on the outliers a few tie flips can cause: at most 3 + 1 % of
+                # the samples beyond tol, none beyond 5 tol; the element-by-element checks are
+                # test_tie_free_network_gradients_per_element (slope 1) and
+                # test_default_slope_gradients_per_element_with_the_hip_branch_pattern
+                n_out = int((err > tol).sum().item())
+                if n_out > 3 + 0.01 * err.numel() or err.max().item() > 5 * tol:
+                    bad.append(f"{k}: {n_out} of {err.numel()} sampled grads beyond tol, max err "
+                               f"{err.max().item():.3e} (tol {tol:.3e})")
             assert not bad, "\n".join(bad)
             opt.step()
         else:
@@ -197,6 +201,71 @@ def test_tie_free_network_gradients_per_element(ua, golden, fused):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("hw", [64, 128])
+def test_default_slope_gradients_per_element_with_the_hip_branch_pattern(ua, hw):
+    """Whole-network gradients at the REFERENCE slope 0.01, element by element, away from ties.
+
+    Two fp32 implementations of the network land on different sides of z = 0 for the few
+    pre-activations that are at rounding level (|z| ~ 1e-6), and one such flip changes
+    lrelu'(z) from 1 to 0.01 at that pixel - which is why the default-slope goldens can only be
+    held norm-wise.  Here the oracle is evaluated with the HIP run's branch decisions on exactly
+    those risky elements (|z_oracle| < 1e-4; the decision is sign(fma(y, gamma*rstd,
+    beta - mean*gamma*rstd)) of the captured raw outputs, the expression of the backward
+    kernels), so both differentiate the same piecewise-linear function: away from the risky
+    elements the two must agree on every branch, and ALL 90 gradients are then held per element
+    to 1e-4 of each tensor's max magnitude - the check that `z > 0 ? 1 : slope` in the
+    InstanceNorm-backward kernels, the data-gradient epilogues and the activation-on-load of the
+    weight gradients is right at the reference slope."""
+    n = 2
+    sd0 = O.fill_state_dict(29)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).train()
+    img, tgt = O.synthetic_batch(13, n, hw, hw)
+    masks = O.draw_dropout_masks(17, n)
+    model.dropout_mask_override = masks
+    model._debug_forward = []
+    logits = model(img.to(DEV))
+    loss = ua.get_loss_function()(logits, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    branches = []
+    params = dict(model.named_parameters())
+    for (name, y, st), row in zip(model._debug_forward, O.layer_table()):
+        prefix, ci, ni = row[0], row[1], row[2]
+        gamma = params[f"{prefix}.{ni}.weight"].detach().cpu()
+        beta = params[f"{prefix}.{ni}.bias"].detach().cpu()
+        mean, rstd = st[0].cpu(), st[1].cpu()                       # [N, C]
+        al = gamma[None, :] * rstd                                   # fp32, one rounding
+        b0 = (beta[None, :].double() - mean.double() * al.double()).float()
+        z = y.detach().cpu().double() * al.double()[:, None, None, :] + b0.double()[:, None, None, :]
+        branches.append((z > 0).permute(0, 3, 1, 2).contiguous())   # NCHW like the oracle
+    assert len(branches) == len(O.layer_table())
+    model._debug_forward = None
+
+    osd = O.leaf_state_dict(sd0)
+    diag = {}
+    ologits = O.unet_forward(osd, img, masks, branches=branches, tie_eps=1e-4, tie_diag=diag)
+    oloss = O.simple_loss(ologits, tgt)
+    oloss.backward()
+    assert diag["disagree_away_from_ties"] == 0, diag
+    assert diag["risky"] > 0      # the hook did see elements near zero ...
+    assert relerr(logits, ologits.detach()) <= 1e-4
+    bad = []
+    for k, p in model.named_parameters():
+        og = osd[k].grad
+        gk = p.grad.detach().cpu()
+        scale = og.abs().max().item()
+        if scale < 1e-4:         # conv biases under InstanceNorm: exact 0 up to rounding
+            if gk.double().norm().item() >= 1e-3:
+                bad.append(f"{k}: should be ~0")
+            continue
+        e = (gk - og).abs().max().item() / scale
+        if e > 1e-4:
+            bad.append(f"{k}: every-element err {e:.2e}")
+    assert not bad, f"{diag}\n" + "\n".join(bad)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_train_step_is_run_to_run_deterministic(ua, mode):
     """No float atomics anywhere: every partial sum (split-K slabs, K groups, statistics and
@@ -227,6 +296,66 @@ def test_train_step_is_run_to_run_deterministic(ua, mode):
     assert torch.equal(a[0], b[0]) and a[1] == b[1]
     assert torch.equal(a[2], b[2]), "gradients differ between two identical runs"
     assert torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_graph_captured_train_step_equals_the_eager_walk(ua, mode):
+    """`GraphedTrainStep` replays the train step from one HIP graph.  With the dropout masks
+    injected (static tensors) four replayed steps - the third and fourth after a learning-rate
+    change, which the graph must follow through the device-side hyper-parameters without being
+    re-captured - leave parameters, momentum and losses bit-identical to four eager steps, and
+    the throw-away capture steps leave no trace in the model."""
+    sd0 = O.fill_state_dict(23)
+    img, tgt = O.synthetic_batch(6, 2, 128, 128)
+    img2, tgt2 = O.synthetic_batch(7, 2, 128, 128)
+    masks = [m.to(DEV) if m is not None else None for m in O.draw_dropout_masks(5, 2)]
+    outs = []
+    for graphed in (False, True):
+        model = ua.UNet()
+        model.load_state_dict(sd0)
+        model = model.to(DEV).train()
+        model.matmul_precision = mode
+        model.dropout_mask_override = masks
+        opt = ua.create_optimizer(model)
+        lossf = ua.get_loss_function()
+        a, b = (img.to(DEV), tgt.to(DEV)), (img2.to(DEV), tgt2.to(DEV))
+        if graphed:
+            step = ua.GraphedTrainStep(model, opt, lossf, *a)
+            arena, _ = model.flat_parameters()
+            assert torch.equal(arena.cpu(), outs[0][0]), "capture changed the parameters"
+        else:
+            arena, _ = model.flat_parameters()
+            outs.append((arena.detach().cpu().clone(),))
+
+            def step(x, y, model=model, opt=opt, lossf=lossf):
+                return ua.train_step(model, opt, lossf, x, y)
+        losses = []
+        for k, batch in enumerate((a, b, a, b)):
+            if k == 2:
+                opt.param_groups[0]["lr"] *= 0.5
+            losses.append(step(*batch).item())
+        torch.cuda.synchronize()
+        arena, _ = model.flat_parameters()
+        outs.append((losses, arena.detach().cpu().clone(), opt._flat_buf.detach().cpu().clone()))
+        del model, opt
+    _, eager, graph = outs
+    assert eager[0] == graph[0], f"losses differ: {eager[0]} vs {graph[0]}"
+    assert torch.equal(eager[1], graph[1]), "parameters differ after four steps"
+    assert torch.equal(eager[2], graph[2]), "momentum differs after four steps"
+
+
+def test_graph_captured_step_draws_fresh_dropout_masks(ua):
+    """Without injected masks the Bernoulli draw is part of the graph: consecutive replays must
+    use different masks (torch's graph-safe generator advances the Philox offset per replay)."""
+    torch.manual_seed(3)
+    model = ua.create_model(DEV).train()
+    opt = ua.create_optimizer(model)
+    opt.param_groups[0]["lr"] = 0.0          # frozen weights: only the masks differ
+    opt.param_groups[0]["weight_decay"] = 0.0
+    img, tgt = O.synthetic_batch(6, 2, 64, 64)
+    step = ua.GraphedTrainStep(model, opt, ua.get_loss_function(), img.to(DEV), tgt.to(DEV))
+    losses = {round(step(step.images, step.masks).item(), 7) for _ in range(4)}
+    assert len(losses) >= 3, f"replays reused the dropout masks: {losses}"
 
 
 SWEEP = [(1, 64, 64), (3, 96, 160), (2, 128, 256), (1, 320, 192), (5, 256, 256), (2, 384, 384),
@@ -511,8 +640,10 @@ def test_clip_unet_golden(ua, golden):
         ref_s = torch.from_numpy(g[f"gsamp_{i}"])
         err = (gk[idx].cpu() - ref_s).abs()
         tol = 1e-2 * max(ref_s.abs().max().item(), ref_norm / gk.numel() ** 0.5)
-        if (err > tol).sum().item() > 0.1 * err.numel() or err.max().item() > 5 * tol:
-            bad.append(f"{k}: sampled grad err {err.max().item():.3e} (tol {tol:.3e})")
+        n_out = int((err > tol).sum().item())
+        if n_out > 3 + 0.01 * err.numel() or err.max().item() > 5 * tol:
+            bad.append(f"{k}: {n_out} of {err.numel()} sampled grads beyond tol, max err "
+                       f"{err.max().item():.3e} (tol {tol:.3e})")
     assert not bad, "\n".join(bad)
     # one optimizer step through the flat arena (94 tensors)
     opt = ua.create_optimizer(model)

@@ -11,10 +11,10 @@ from .losses import SimpleLoss  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .train import (create_lr_scheduler, create_model, create_optimizer,  # noqa: F401
                     get_loss_function, load_checkpoint, save_checkpoint, train_one_epoch,
-                    train_step, validate, predict_masks)
+                    train_step, validate, predict_masks, GraphedTrainStep)
 from .clip_unet import CLIPUNet  # noqa: F401
 from .unet import ConvBlock, SpatialDropout2d, UNet, UpBlock  # noqa: F401
 
 __all__ = ["UNet", "CLIPUNet", "ConvBlock", "UpBlock", "SpatialDropout2d", "SimpleLoss", "FusedSGD",
            "create_model", "create_optimizer", "create_lr_scheduler", "get_loss_function",
-           "train_step", "train_one_epoch", "save_checkpoint", "load_checkpoint", "validate", "predict_masks", "ops", "build", "lib", "UNetHipError", "LIB_PATH"]
+           "train_step", "GraphedTrainStep", "train_one_epoch", "save_checkpoint", "load_checkpoint", "validate", "predict_masks", "ops", "build", "lib", "UNetHipError", "LIB_PATH"]

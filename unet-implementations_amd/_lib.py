@@ -85,6 +85,7 @@ SIGNATURES = {
     "unet_argmax_dice_counts": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _p]),
     "unet_sgd_nesterov_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
+    "unet_sgd_nesterov_step_dev": (_i, [_p, _p, _p, _i64, _p, _i, _p]),
     "unet_add_inplace": (_i, [_p, _p, _i64, _p]),
     "unet_conv_in_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "unet_conv_in_fwd": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,

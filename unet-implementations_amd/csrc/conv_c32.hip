@@ -271,8 +271,7 @@ __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, i
 
 // 3x3 stride-1, 32 input and 32 output channels, image tiles as 8 x 32 pixels
 bool c32_applicable(const IgemmParams& p) {
-  static const int off = getenv("UNET_NO_C32") ? 1 : 0;
-  return !off && p.ntaps == 9 && p.tap_cstride == 0 && p.src0_pitch == 0 && p.sout == 1 &&
+  return p.ntaps == 9 && p.tap_cstride == 0 && p.src0_pitch == 0 && p.sout == 1 &&
          p.Hl == p.Hin && p.Wl == p.Win && p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 8 == 0 &&
          p.Win % 32 == 0 && p.C0 == 32 && p.C1 == 0 && p.Ncols == 32 &&
          (long long)p.N * p.Hin * p.Win * 128 < (1LL << 31);

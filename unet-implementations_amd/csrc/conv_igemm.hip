@@ -58,14 +58,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_kernel(c
 
   const int tiles_n = p.Ncols / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  if (KG > 1 && p.n_group) {   // column groups outermost (tiles_n % n_group == 0)
-    const int tiles_m = gridDim.x / tiles_n;
-    const int per_group = tiles_m * p.n_group;
-    const int ng = bid / per_group, r = bid - ng * per_group;
-    tm = r / p.n_group;
-    tn = ng * p.n_group + (r - tm * p.n_group);
-  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int HlWl = p.Hl * p.Wl;
   const int M = p.N * HlWl;
@@ -210,9 +203,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_kernel(c
     advance(ks + 2 < KS);
     const float* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
     const float* Bb = Bs + buf * B_TILE + wn0 * LDA + frag_off;
-#ifdef UNET_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
     f32x4 a[2][TM], b[2][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDA);
@@ -238,9 +228,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_kernel(c
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][r], b[cur][n][r], acc[m][n],
                                                              0, 0, 0);
     }
-#ifdef UNET_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     // FUSED: the activation arithmetic on the staged rows must not drift above the MFMAs (it
     // would wait for this step's buffer loads before the matrix work that is meant to hide them)
     if (!FUSED) store_tiles(buf ^ 1);
@@ -297,74 +284,80 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_kernel(c
   }
 
   // ---- epilogue: D row = (reg&3) + 8*(reg>>2) + 4*lh, column = li ----
+  // BSTATS (uniform `bs`): the output is FINAL for the layer behind it, so each stored block is
+  // followed by the read of the matching raw outputs y (same element offsets) and the lane's
+  // share of that layer's InstanceNorm-backward sums (IgemmParams); needs every tile inside one
+  // image and all rows valid (dispatcher check)
   const bool direct = (p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout);
+  const bool bs = !FUSED && p.bs_partial;
+  constexpr int WAVES_M_ = BM / WM;
+  float2* bred = reinterpret_cast<float2*>(scratch);
+  const int bimg = m0 / HlWl;
 #pragma unroll
   for (int n = 0; n < TN; ++n) {
     const int col = n0 + wn0 + n * 32 + li;
     const float bv = p.bias ? p.bias[col] : 0.f;
+    BwdCoef cf{};
+    if (bs) cf = bwd_coef(p, bimg, col);
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-      float* o[16];
+      unsigned o[16];   // element offsets into p.out (the tensor stays below 2^29 elements)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int mg = lead ? m0 + row : M;   // the other K groups store nothing
-        size_t opix = (size_t)mg;
+        unsigned opix = (unsigned)mg;
         if (!direct) {
           const int nn = mg / HlWl;
           const int rr = mg - nn * HlWl;
           const int a = rr / p.Wl;
           const int b = rr - a * p.Wl;
-          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
+          opix = (unsigned)((nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px));
         }
-        o[r] = mg < M ? p.out + opix * p.ldo + col : nullptr;
+        o[r] = mg < M ? opix * (unsigned)p.ldo + (unsigned)col : kNoOut;
       }
-      if (!FUSED && p.bs_partial) {   // uniform: keep the FINAL values for the reductions below
+      if (bs) {
         if (p.accumulate) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][n][r] += bv + (o[r] ? *o[r] : 0.f);
+          for (int r = 0; r < 16; ++r) acc[m][n][r] += bv + (o[r] != kNoOut ? p.out[o[r]] : 0.f);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][n][r] += bv;
         }
+        float yv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (o[r]) *o[r] = acc[m][n][r];
+        for (int r = 0; r < 16; ++r) {
+          yv[r] = 0.f;
+          if (o[r] != kNoOut) {
+            p.out[o[r]] = acc[m][n][r];
+            yv[r] = p.bs_y[o[r]];
+          }
+        }
+        if (lead) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {   // the order of wave_bwd_stats (conv_params.h)
+            const float z = fmaf(yv[r], cf.A, cf.B0);
+            const float gz = acc[m][n][r] * cf.mk * (z > 0.f ? 1.f : p.slope);
+            s1 += gz;
+            s2 = fmaf(gz, (yv[r] - cf.mu) * cf.rs, s2);
+          }
+        }
       } else {
-        store_block16(o, acc[m][n], bv, p.accumulate);
+        store_block16_off(p.out, o, acc[m][n], bv, p.accumulate);
       }
     }
-  }
-  if (!FUSED && p.bs_partial) {   // uniform: reductions of the next backward stage (IgemmParams);
-    // needs every tile inside one image and all rows valid (dispatcher check)
-    constexpr int WAVES_M = BM / WM;
-    float2* red = reinterpret_cast<float2*>(scratch);
-    const int img = m0 / HlWl;
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const int col = n0 + wn0 + n * 32 + li;
-      const BwdCoef cf = bwd_coef(p, img, col);
-      float2 mine = float2{0.f, 0.f};
-      if (lead) mine = wave_bwd_stats<TM>(
-          cf, p.slope, [&](int m, int r) { return acc[m][n][r]; },
-          [&](int m, int r) {
-            const int mg = m0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            size_t opix = (size_t)mg;
-            if (!direct) {
-              const int nn = mg / HlWl;
-              const int rr = mg - nn * HlWl;
-              const int a = rr / p.Wl;
-              const int b = rr - a * p.Wl;
-              opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
-            }
-            return p.bs_y[opix * p.ldo + col];
-          });
-      if (lh == 0 && lead) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+    if (bs) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0 && lead) bred[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = float2{s1, s2};
     }
+  }
+  if (bs) {
     float2 out;
-    if (block_col_sums<BN, WAVES_M>(red, out))
-      p.bs_partial[((size_t)img * p.bs_tiles + p.bs_tile0 + (m0 - img * HlWl) / BM) * p.Ncols + n0 +
-                   tid] = out;
+    if (block_col_sums<BN, WAVES_M_>(bred, out))
+      p.bs_partial[((size_t)bimg * p.bs_tiles + p.bs_tile0 + (m0 - bimg * HlWl) / BM) * p.Ncols +
+                   n0 + tid] = out;
   }
   if (FUSED && p.stats) {   // uniform; the K loop ended on a barrier: the A tiles are free scratch
     constexpr int WAVES_M = BM / WM;
@@ -715,8 +708,7 @@ int launch_igemm_rf(const IgemmParams& p, int flip, hipStream_t stream, int* sta
 
 // stride-1 3x3 with rows that tile exactly: use the row-fused kernel for narrow outputs
 bool rf_applicable(const IgemmParams& p) {
-  static const int off = getenv("UNET_NO_ROWFUSE") ? 1 : 0;
-  return !off && p.ntaps == 9 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
+  return p.ntaps == 9 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
          p.Hl == p.Hout && p.Wl == p.Wout && p.Wl % 128 == 0 && p.Ncols == 32;
 }
 
@@ -952,11 +944,10 @@ static int launch_igemm_fused(IgemmParams p, hipStream_t stream, int* stats_px) 
 
 // Deep layers (at most one 64x64 tile per CU): number of K groups per block (1 = no split).
 static int deep_k_groups(const IgemmParams& p) {
-  static const int forced = getenv("UNET_IGEMM_KG") ? atoi(getenv("UNET_IGEMM_KG")) : 0;
   const long long M = (long long)p.N * p.Hl * p.Wl;
   if (p.Ncols % 64 != 0 || ceil_div64(M, 64) * (p.Ncols / 64) > 256) return 1;
   const int ks = p.ntaps * ((p.C0 + p.C1) / 32);
-  int kg = forced ? forced : 4;
+  int kg = 4;
   while (kg > 1 && (ks % kg != 0 || ks / kg < 4)) kg >>= 1;
   return kg;
 }
@@ -975,17 +966,8 @@ static int launch_igemm_bs(IgemmParams p, hipStream_t stream, int* bs_px) {
   return launch_igemm<BM, BN, WM, WN, 32, false, KG>(p, stream);
 }
 
-static int deep_n_group(const IgemmParams& p) {
-  static const int forced = getenv("UNET_IGEMM_NGROUP") ? atoi(getenv("UNET_IGEMM_NGROUP")) : -1;
-  const int tiles_n = p.Ncols / 64;
-  int g = forced >= 0 ? forced : 0;
-  if (g <= 0 || tiles_n % g != 0) return 0;
-  return g;
-}
-
 static int launch_igemm_deep(IgemmParams p, hipStream_t stream, int* bs_px) {
   const int kg = deep_k_groups(p);
-  p.n_group = deep_n_group(p);
   return kg == 4   ? launch_igemm_bs<64, 64, 32, 32, 4>(p, stream, bs_px)
          : kg == 2 ? launch_igemm_bs<64, 64, 32, 32, 2>(p, stream, bs_px)
                    : launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
@@ -1009,11 +991,9 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
       return launch_igemm_fused<128, 64, 64, 32>(p, stream, stats_px);
     if (nc % 64 == 0 && M <= 128 * 256) {
       const int kg = deep_k_groups(p);
-      IgemmParams q = p;
-      q.n_group = deep_n_group(p);
-      return kg == 4   ? launch_igemm_fused<64, 64, 32, 32, 4>(q, stream, stats_px)
-             : kg == 2 ? launch_igemm_fused<64, 64, 32, 32, 2>(q, stream, stats_px)
-                       : launch_igemm_fused<64, 64, 32, 32>(q, stream, stats_px);
+      return kg == 4   ? launch_igemm_fused<64, 64, 32, 32, 4>(p, stream, stats_px)
+             : kg == 2 ? launch_igemm_fused<64, 64, 32, 32, 2>(p, stream, stats_px)
+                       : launch_igemm_fused<64, 64, 32, 32>(p, stream, stats_px);
     }
     return launch_igemm_fused<128, 32, 32, 32>(p, stream, stats_px);
   }
@@ -1027,10 +1007,8 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
   }
   // Largest tile that still yields >= 256 workgroups (one per CU); otherwise the
   // small 64x64 tile.
-  static const int bk16 = getenv("UNET_IGEMM_BK16") ? 1 : 0;
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
-    return bk16 ? launch_igemm<128, 128, 64, 64, 16>(p, stream)
-                : launch_igemm<128, 128, 64, 64>(p, stream);
+    return launch_igemm<128, 128, 64, 64>(p, stream);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
     return launch_igemm<128, 64, 64, 32>(p, stream);
   if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_deep(p, stream, nullptr);
@@ -1392,10 +1370,9 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   // stride 2: dx[2a+py][2b+px] = sum over ky with (py+1-ky) even of dy[a + (py+1-ky)/2][..]
   p.Hl = H / 2; p.Wl = W / 2; p.sout = 2;
   {
-    static const int per_class = getenv("UNET_S2_PER_CLASS") ? 1 : 0;
     // one launch for all four parity classes when there are enough tiles to fill the chip
     const long long tiles = ceil_div64((long long)N * p.Hl * p.Wl, 128) * (Ccols / 32);
-    if (prec == 0 && !b16 && !per_class) {   // conv_patch.hip: the dy patch staged once per chunk
+    if (prec == 0 && !b16) {   // conv_patch.hip: the dy patch staged once per chunk
       IgemmParams q = p;
       if (!use_bs) q.bs_partial = nullptr;
       int bt = 0;
@@ -1405,11 +1382,11 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
         return rc;
       }
     }
-    if (b16 && !per_class) {   // mixed-precision pipeline: one launch instead of four per class
+    if (b16) {   // mixed-precision pipeline: one launch instead of four per class
       const int rc = launch_dgrad_s2_patch_b16_auto(p, stream);
       if (rc != 1) return rc;
     }
-    if (prec != 1 && !b16 && !per_class && tiles >= 512) {
+    if (prec != 1 && !b16 && tiles >= 512) {
       p.py = p.px = 0; p.ntaps = 9;
       if (use_bs && (p.Hl * p.Wl) % 128 == 0) p.bs_tiles = p.Hl * p.Wl / 128;
       else p.bs_partial = nullptr;

@@ -65,10 +65,6 @@ struct IgemmParams {
   float2* bs_partial;
   int bs_tiles;            // tiles per image
   int bs_tile0;            // first tile index of this launch (per-class stride-2 launches)
-  // gather-GEMM tile order: consecutive block ids (one XCD's share after the remap) walk all row
-  // tiles of n_group column tiles before the next column group; 0 = every column tile of a row
-  // tile first.  Deep layers (weights >> activations) keep an XCD on few weight panels this way.
-  int n_group;
 };
 
 // The kernels address their operands through buffer descriptors (free zero padding), whose
@@ -104,6 +100,25 @@ __device__ __forceinline__ void store_block16(TO* const (&o)[16], const f32x16& 
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (o[r]) st1(o[r], acc[r] + bv);
+  }
+}
+// The same with 32-bit element offsets from `base` (kNoOut = out of range): half the address
+// registers of the pointer form (a tensor stays below 2^29 elements: batch_chunk above).
+constexpr unsigned kNoOut = 0xffffffffu;
+template <typename TO>
+__device__ __forceinline__ void store_block16_off(TO* base, const unsigned (&o)[16],
+                                                  const f32x16& acc, float bv, int accumulate) {
+  if (accumulate) {
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = o[r] != kNoOut ? ld1(base + o[r]) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (o[r] != kNoOut) st1(base + o[r], acc[r] + bv + old[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (o[r] != kNoOut) st1(base + o[r], acc[r] + bv);
   }
 }
 #endif  // __HIPCC__

@@ -1291,20 +1291,21 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
-  int pp_lin[P_PASSES], pp_lds[P_PASSES];
-  unsigned pp_oob[P_PASSES];
+  // per slot ONE register: the linear dy pixel, or -1 for a slot outside the grid / past the
+  // patch (its buffer load returns 0 and nothing is written); the LDS slot of pass i is
+  // pass 0's + 32 pixels * i (256 threads = 32 pixels x 8 segments)
+  int pp_lin[P_PASSES];
 #pragma unroll
   for (int i = 0; i < P_PASSES; ++i) {
-    const int slot = (tid + 256 * i) % P_SLOTS;
-    const int pix = slot >> 3, seg = slot & 7;
+    const int slot = tid + 256 * i;
+    const int pix = slot >> 3;
     const int prow = pix / PW, pcol = pix - prow * PW;
     const int iy = y0 + prow, ix = x0 + pcol;
-    const bool ok = iy < Hl && ix < Wl;
-    pp_lin[i] = ok ? (n * Hl + iy) * Wl + ix : 0;
-    pp_oob[i] = ok ? 0u : 0x80000000u;
-    pp_lds[i] = pix * LDA + seg * 4;
+    const bool ok = slot < P_SLOTS && iy < Hl && ix < Wl;
+    pp_lin[i] = ok ? (n * Hl + iy) * Wl + ix : -1;
   }
   const int seg4 = (tid & 7) * 4;
+  const int pp_lds0 = (tid >> 3) * LDA + seg4;
   unsigned wslot_off[B_PASSES];
   int wslot_lds[B_PASSES], wslot_tap[B_PASSES];
 #pragma unroll
@@ -1336,11 +1337,14 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
   auto load_patch = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i)
-      pr[i] = buf_ld4<__bf16>(rs0, (unsigned)(pp_lin[i] * Ktot + chunk * BK + seg4), pp_oob[i]);
+      pr[i] = buf_ld4<__bf16>(rs0, (unsigned)(pp_lin[i] * Ktot + chunk * BK + seg4),
+                              pp_lin[i] < 0 ? 0x80000000u : 0u);
   };
   auto store_patch = [&]() {
 #pragma unroll
-    for (int i = 0; i < P_PASSES; ++i) *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(pr[i]);
+    for (int i = 0; i < P_PASSES; ++i)
+      if (256 * (i + 1) <= P_SLOTS || tid + 256 * i < P_SLOTS)
+        *reinterpret_cast<bf16x4*>(Ps + pp_lds0 + i * 32 * LDA) = to_bf16(pr[i]);
   };
   auto load_b = [&](auto step_tag, int chunk) {   // the three taps 3*step .. 3*step+2
     constexpr int st = decltype(step_tag)::value;
@@ -1804,8 +1808,7 @@ int launch_dgrad_s2_patch_b16(const IgemmParams& p, hipStream_t stream) {
 
 // The same for the mixed-precision pipeline (bf16 dy / dx); no BSTATS epilogue.
 int launch_dgrad_s2_patch_b16_auto(const IgemmParams& p, hipStream_t stream) {
-  static const int off = getenv("UNET_NO_PATCH_S2") ? 1 : 0;
-  if (off || p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
+  if (p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
   const long long pos = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   if (nc % 64 == 0 && p.Hl % 4 == 0 && pos / 128 * (nc / 64) >= 256)
@@ -1820,9 +1823,8 @@ int launch_dgrad_s2_patch_b16_auto(const IgemmParams& p, hipStream_t stream) {
 // tiles would run (the caller keeps its gather-GEMM forms).  With p.bs_partial set the BSTATS
 // epilogue runs and *bs_tiles_out receives the reduction tiles per image.
 int launch_dgrad_s2_patch_auto(const IgemmParams& p0, hipStream_t stream, int* bs_tiles_out) {
-  static const int off = getenv("UNET_NO_PATCH_S2") ? 1 : 0;
   IgemmParams p = p0;
-  if (off || p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
+  if (p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
   const long long pos = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
   p.bs_tile0 = 0;
@@ -1841,10 +1843,9 @@ int launch_dgrad_s2_patch_auto(const IgemmParams& p0, hipStream_t stream, int* b
 
 // stride-2 3x3 forward whose OUTPUT tiles as 4 x 32 pixels, 16-channel chunks, standard taps
 bool patch_s2_applicable(const IgemmParams& p) {
-  static const int off = getenv("UNET_NO_PATCH_S2") ? 1 : 0;
   IgemmParams std_taps{};
   for (int t = 0; t < 9; ++t) set_tap(std_taps, t, t / 3 - 1, t % 3 - 1, t);
-  return !off && p.ntaps == 9 && p.tap_cstride == 0 && p.src0_pitch == 0 && p.sin == 2 &&
+  return p.ntaps == 9 && p.tap_cstride == 0 && p.src0_pitch == 0 && p.sin == 2 &&
          p.sout == 1 && p.Hin == 2 * p.Hl && p.Win == 2 * p.Wl && p.Hl == p.Hout &&
          p.Wl == p.Wout && p.Hl % 4 == 0 && p.Wl % 32 == 0 && p.C0 % 16 == 0 && p.C1 % 16 == 0 &&
          !p.accumulate && p.tapw[0] == std_taps.tapw[0] && p.tapw[1] == std_taps.tapw[1] &&
@@ -1866,9 +1867,8 @@ int launch_patch_b16_t(const IgemmParams& p, hipStream_t stream) {
 // stats_px != nullptr = fused forward (activation on load + statistics), else data gradient.
 // Returns 1 when the shape does not qualify (the caller keeps the bf16 gather-GEMM).
 int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px, int* bs_px) {
-  static const int off = getenv("UNET_NO_PATCH_B16") ? 1 : 0;
   if (bs_px) *bs_px = 0;
-  if (off || !patch_f32_applicable(p0) || p0.src0_pitch) return 1;
+  if (!patch_f32_applicable(p0) || p0.src0_pitch) return 1;
   IgemmParams p = p0;
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
@@ -1925,16 +1925,14 @@ int launch_patch_s2_auto(const IgemmParams& p0, hipStream_t stream, int* stats_p
 
 // stride-1 3x3 over an image that tiles as 4 x 32 pixels, 16-channel chunks
 bool patch_split_applicable(const IgemmParams& p) {
-  static const int off = getenv("UNET_NO_PATCH") ? 1 : 0;
-  return !off && p.ntaps == 9 && p.sin == 1 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
+  return p.ntaps == 9 && p.sin == 1 && p.sout == 1 && p.Hl == p.Hin && p.Wl == p.Win &&
          p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 && p.Win % 32 == 0 &&
          p.C0 % 16 == 0 && p.C1 % 16 == 0;
 }
 
 // the same with 32-channel chunks (fp32 form)
 bool patch_f32_applicable(const IgemmParams& p) {
-  static const int off = getenv("UNET_NO_PATCH") ? 1 : 0;
-  return !off && p.ntaps == 9 && p.tap_cstride == 0 && p.sin == 1 && p.sout == 1 &&
+  return p.ntaps == 9 && p.tap_cstride == 0 && p.sin == 1 && p.sout == 1 &&
          p.Hl == p.Hin && p.Wl == p.Win && p.Hl == p.Hout && p.Wl == p.Wout && p.Hin % 4 == 0 &&
          p.Win % 32 == 0 && p.C0 % 32 == 0 && p.C1 % 32 == 0;
 }

@@ -49,18 +49,66 @@ struct WgradParams {
   int b16;             // x and dy are bf16 tensors (mixed-precision pipeline)
 };
 
-// Workgroup = 4 waves (one per SIMD, so co-resident workgroups load every SIMD alike).
-// The (CI_T x CO_T) tile has NSB = (CI_T/32)*(CO_T/32) 32x32 sub-blocks; wave w owns
-// sub-block w % NSB for ALL nine taps (9 accumulator blocks = 144 VGPRs) and, when NSB < 4,
-// the pixel pairs q = w / NSB (mod NPP) of each segment - its sums then go to a slab of
-// their own (slab index sp*NPP + pp), folded by the ordinary slab reduction.
+// Epilogue shared by the weight-gradient kernels.  A wave holds nine 32x32 accumulator blocks
+// (taps t = 0..8) of sub-block sb for its pixel part pp.  The NPP parts of a sub-block are
+// MERGED THROUGH LDS (three taps per round, parts added in part order: deterministic) and the
+// sums leave the CU as 16-byte stores - ONE slab per workgroup: partial[sp][9][Cx][Cout]
+// (NPP == 1: the round trip through LDS only widens the stores).  `smem` must hold
+// 3 * NW * 4 KB and be free (the main loops end on a barrier).
+// acc_of(integral_constant<t>) returns the block of tap t.
+template <int NSB, int NPP, int TJ, int NT, typename ACC>
+__device__ __forceinline__ void wgrad_epilogue(float* smem, const WgradParams& p, int sp, int ci0,
+                                               int co0, int sb, int pp, ACC&& acc_of) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  {
+    constexpr int TPR = 3;
+    const f32x4* M4 = reinterpret_cast<const f32x4*>(smem);
+    for_range<0, 3>([&](auto uc) {          // round u = taps 3u .. 3u+2
+      constexpr int u = decltype(uc)::value;
+      for_range<0, TPR>([&](auto vc) {
+        constexpr int v = decltype(vc)::value;
+        const f32x16& a = acc_of(template_ic<u * 3 + v>{});
+        float* dst = smem + ((v * NPP + pp) * NSB + sb) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * 64] = a[r];
+      });
+      __syncthreads();
+      for (int i = tid; i < TPR * NSB * 256; i += NT) {
+        const int v = i / (NSB * 256), rem = i - v * (NSB * 256);
+        const int s = rem >> 8, e4 = rem & 255;
+        f32x4 sum = M4[((v * NPP) * NSB + s) * 256 + e4];
+#pragma unroll
+        for (int q = 1; q < NPP; ++q) sum += M4[((v * NPP + q) * NSB + s) * 256 + e4];
+        // element e = 4*e4 of a 32x32 block: register r = e >> 6, lane = e & 63
+        const int r = e4 >> 4, l0 = (e4 & 15) * 4;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l0 >> 5);
+        const int swi = s / TJ, swj = s - swi * TJ;
+        float* out = p.partial +
+            ((size_t)(sp * 9 + u * 3 + v) * p.Cx + ci0 + swi * 32 + row) * p.Cout +
+            co0 + swj * 32 + (l0 & 31);
+        *reinterpret_cast<f32x4*>(out) = sum;
+      }
+      __syncthreads();
+    });
+  }
+}
+constexpr size_t kWgradMergeLds4 = (size_t)3 * 4 * 1024 * sizeof(float);   // 4-wave workgroup
+constexpr size_t kWgradMergeLds8 = (size_t)3 * 8 * 1024 * sizeof(float);   // 8-wave workgroup
+
+// Workgroup = NW waves: 4 (one per SIMD, two workgroups per CU) or 8 (two per SIMD, ONE
+// workgroup per CU).  The (CI_T x CO_T) tile has NSB = (CI_T/32)*(CO_T/32) 32x32 sub-blocks;
+// wave w owns sub-block w % NSB for ALL nine taps (9 accumulator blocks = 144 VGPRs) and the
+// pixel pairs q = w / NSB (mod NPP = NW / NSB) of each segment.
+// The NPP parts of a sub-block are merged through LDS before they leave the CU
+// (wgrad_epilogue): one slab per workgroup.
 template <int CI_T, int CO_T, int S, int STRIDE, bool ACT = false, typename TX = float,
-          typename TD = float>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
+          typename TD = float, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
-  constexpr int NSB = TI * TJ, NPP = 4 / NSB;
+  constexpr int NSB = TI * TJ, NPP = NW / NSB;
   static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
-  constexpr int NT = 256;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int NT = 64 * NW;
   constexpr int PW = (S - 1) * STRIDE + 3;
   constexpr int NP4 = 3 * PW * CI_T / 4;   // float4 slots of the patch
   constexpr int ND4 = S * CO_T / 4;        // float4 slots of the dy segment
@@ -159,22 +207,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                           ok ? 0u : 0x80000000u);
     }
   };
-  auto act_slot = [&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    if (ACT) rp[k] = act4(rp[k], ca, cb, p.slope, (okm >> k) & 1u);
-  };
-  auto store_stage = [&](int buf) {
-    float* base = smem + buf * STAGE;
-#pragma unroll
-    for (int k = 0; k < NLP; ++k)
-      if (NT * (k + 1) <= NP4 || tid + NT * k < NP4)
-        *reinterpret_cast<f32x4*>(base + 4 * (tid + NT * k)) = rp[k];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k)
-      if (NT * (k + 1) <= ND4 || tid + NT * k < ND4)
-        *reinterpret_cast<f32x4*>(base + PATCH + 4 * (tid + NT * k)) = rd[k];
-  };
-
   f32x16 acc[3][3];
 #pragma unroll
   for (int u = 0; u < 3; ++u)
@@ -187,20 +219,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   // that is not an MFMA is placed by hand behind a step's MFMAs and fenced there, so it issues
   // in the shadow of the matrix pipe instead of at the loop top / bottom:
   //   steps [0, LQ):        the next segment's buffer loads (address arithmetic + issue)
-  //   steps [NQ-HALF, NQ):  the activation of the loaded patch slots (ACT)
-  //   after the last step:  LDS writes of the next stage, barrier.
+  //   steps [NQ-HALF, NQ):  per loaded slot the activation (ACT) and its LDS write into the idle
+  //                         stage - the writes drain at ~80 B/clk/CU, so bunched at the end of
+  //                         the segment they would hold every wave at the barrier
+  //   after the last step:  the barrier.
   constexpr int NLS = NLP + NLD;
   constexpr int LQ = NQ >= 4 ? NQ / 4 : 1;
   constexpr int LPER = (NLS + LQ - 1) / LQ;
   constexpr int HALF = NQ >= 2 ? NQ / 2 : 1;
-  constexpr int APER = (NLP + HALF - 1) / HALF;
+  constexpr int APER = (NLS + HALF - 1) / HALF;
+  auto put_slot = [&](auto kc, float* base) {   // activate (patch slots) and write one slot
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < NLP) {
+      if (ACT) rp[k] = act4(rp[k], ca, cb, p.slope, (okm >> k) & 1u);
+      if (NT * (k + 1) <= NP4 || tid + NT * k < NP4)
+        *reinterpret_cast<f32x4*>(base + 4 * (tid + NT * k)) = rp[k];
+    } else {
+      constexpr int j = k - NLP;
+      if (NT * (j + 1) <= ND4 || tid + NT * j < ND4)
+        *reinterpret_cast<f32x4*>(base + PATCH + 4 * (tid + NT * j)) = rd[j];
+    }
+  };
 
   if (g_begin < g_end) {
     set_cursor(g_begin);
     load_coef();
     for_range<0, NLS>(issue_slot);
-    for_range<0, NLP>(act_slot);
-    store_stage(0);
+    for_range<0, NLS>([&](auto kc) { put_slot(kc, smem); });
     __syncthreads();
     for (int g = g_begin; g < g_end; ++g) {
       const int buf = (g - g_begin) & 1;
@@ -210,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
       load_coef();
       const float* P = smem + buf * STAGE + wi * 32 + li;
       const float* D = smem + buf * STAGE + PATCH + wj * 32 + li;
+      float* nxt_stage = smem + (buf ^ 1) * STAGE;
       float a[2][3][3], b[2];
       {
         const int xx = 2 * pp + lh;
@@ -237,28 +283,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][u][v], b[cur], acc[u][v], 0, 0, 0);
         if constexpr (q < LQ)
           for_range<q * LPER, ((q + 1) * LPER < NLS ? (q + 1) * LPER : NLS)>(issue_slot);
-        if constexpr (ACT && q >= NQ - HALF) {
+        if constexpr (q >= NQ - HALF) {
           constexpr int s0 = (q - (NQ - HALF)) * APER;
-          for_range<s0, (s0 + APER < NLP ? s0 + APER : NLP)>(act_slot);
+          for_range<s0, (s0 + APER < NLS ? s0 + APER : NLS)>(
+              [&](auto kc) { put_slot(kc, nxt_stage); });
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      store_stage(buf ^ 1);
       __syncthreads();
     }
   }
 
-#pragma unroll
-  for (int u = 0; u < 3; ++u)
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      float* out = p.partial + ((size_t)((sp * NPP + pp) * 9 + u * 3 + v) * p.Cx) * p.Cout;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[u][v][r];
-      }
-    }
+  wgrad_epilogue<NSB, NPP, TJ, NT>(smem, p, sp, ci0, co0, sb, pp, [&](auto tc) -> const f32x16& {
+    constexpr int t = decltype(tc)::value;
+    return acc[t / 3][t % 3];
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -271,12 +310,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // the flattened [N*h*w] pixel list.  Same slabs / reductions as conv_wgrad_kernel.
 // WgradParams: x = the low-resolution operand [Q][Cx], dy = D [Q][9*Cout], N*H*W = Q.
 // ---------------------------------------------------------------------------
-template <int CI_T, int CO_T, int S, bool ACT, typename TX = float, typename TD = float>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradParams p) {
+// NW = 8: one 8-wave workgroup per CU, pixel parts merged through LDS (see conv_wgrad_kernel).
+template <int CI_T, int CO_T, int S, bool ACT, typename TX = float, typename TD = float,
+          int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void conv_wgrad_taps_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
-  constexpr int NSB = TI * TJ, NPP = 4 / NSB;
+  constexpr int NSB = TI * TJ, NPP = NW / NSB;
   static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
-  constexpr int NT = 256;
+  constexpr int NT = 64 * NW;
   constexpr int BW = 9 * CO_T;             // floats per pixel of the staged D tile
   constexpr int NA4 = S * CI_T / 4;        // float4 slots of the A segment
   constexpr int NB4 = S * BW / 4;          // float4 slots of the D segment
@@ -310,17 +351,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
       const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 
   // A slot: pixel a_px[k] of the segment, channels a_ch..+3; D slot: pixel, float offset in BW
-  int a_px[NLA], b_px[NLB], b_col[NLB];
+  // D slots carry ONE register: the element offset from the segment's first pixel.  A pixel past
+  // the end of the tensor lands beyond the buffer descriptor's range and reads 0 by itself.
+  int a_px[NLA];
+  unsigned b_off[NLB];
   const int a_ch = ci0 + (tid % (CI_T / 4)) * 4;
 #pragma unroll
   for (int k = 0; k < NLA; ++k) a_px[k] = (tid + NT * k) / (CI_T / 4);
 #pragma unroll
   for (int k = 0; k < NLB; ++k) {
     const int idx = tid + NT * k;
-    b_px[k] = idx / (BW / 4);
-    const int f = (idx - b_px[k] * (BW / 4)) * 4;      // float offset within the 9*CO_T row
+    const int px = idx / (BW / 4);
+    const int f = (idx - px * (BW / 4)) * 4;           // float offset within the 9*CO_T row
     const int t = f / CO_T;
-    b_col[k] = t * p.Cout + co0 + (f - t * CO_T);      // channel of D's 9*Cout axis
+    b_off[k] = (unsigned)(px * (9 * p.Cout) + t * p.Cout + co0 + (f - t * CO_T));
   }
 
   f32x4 ra[NLA], rb[NLB];
@@ -341,9 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
       }
     } else {
       constexpr int j = k - NLA;
-      const int q = lq0 + b_px[j];
-      const bool ok = q < Q;
-      rb[j] = buf_ld4<TD>(rsd, (unsigned)(q * (9 * p.Cout) + b_col[j]), ok ? 0u : 0x80000000u);
+      rb[j] = buf_ld4<TD>(rsd, (unsigned)(lq0 * (9 * p.Cout)) + b_off[j], 0u);
     }
   };
   auto act_slot = [&](auto kc) {
@@ -413,15 +455,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(const WgradPara
     }
   }
 
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    float* out = p.partial + ((size_t)((sp * NPP + pp) * 9 + t) * p.Cx) * p.Cout;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[t][r];
-    }
-  }
+  wgrad_epilogue<NSB, NPP, TJ, NT>(smem, p, sp, ci0, co0, sb, pp, [&](auto tc) -> const f32x16& {
+    return acc[decltype(tc)::value];
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -465,7 +501,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
   constexpr int PSUB = 3 * PW * 32, DSUB = S * 32;   // elements per 32-channel sub-tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
   const int sb = wave % NSB, pp = wave / NSB;
   const int wi = sb / TJ, wj = sb - wi * TJ;
 
@@ -634,17 +669,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
     }
   }
 
-#pragma unroll
-  for (int u = 0; u < 3; ++u)
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      float* out = p.partial + ((size_t)((sp * NPP + pp) * 9 + u * 3 + v) * p.Cx) * p.Cout;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        out[(size_t)row * p.Cout + co0 + wj * 32 + li] = acc[u][v][r];
-      }
-    }
+  wgrad_epilogue<NSB, NPP, TJ, NT>(reinterpret_cast<float*>(smem_h), p, sp, ci0, co0, sb, pp,
+                                   [&](auto tc) -> const f32x16& {
+    constexpr int t = decltype(tc)::value;
+    return acc[t / 3][t % 3];
+  });
 }
 
 
@@ -714,6 +743,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int ci = rem / 9, t = rem - ci * 9;
     dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[t][ci][co];
   }
+}
+
+// The same with one tap per block (grid.z = 9): 9x the workgroups for the layers whose
+// gradient is small (32 / 64 channels: 4 / 16 blocks of the kernel above, each thread walking
+// split x 9 dependent slab rows, would run for tens of microseconds on a near-idle chip).
+__global__ __launch_bounds__(256) void wgrad_reduce_tap_kernel(const float* __restrict__ partial,
+                                                               float* __restrict__ dw, int split,
+                                                               int Cx, int Cout, int ci_off,
+                                                               int Cin_total) {
+  __shared__ float tile[8][33];
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 8, t = blockIdx.z;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;  // r in 0..7
+  const size_t slab = (size_t)9 * Cx * Cout;
+  const float* src = partial + ((size_t)t * Cx + ci0 + r) * Cout + co0 + c;
+  float s = 0.f;
+  for (int k = 0; k < split; ++k) s += src[(size_t)k * slab];
+  tile[r][c] = s;
+  __syncthreads();
+  // thread (co = tid >> 3, ci = tid & 7)
+  const int co = threadIdx.x >> 3, ci = threadIdx.x & 7;
+  dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[ci][co];
 }
 
 // ---------------------------------------------------------------------------
@@ -892,7 +942,9 @@ __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, floa
 }
 
 struct WgradPlan {
-  int npp;
+  int npp;   // pixel-pair parts per segment (waves that share a sub-block)
+  int sps;   // slabs per pixel split: 1 (the parts of a sub-block are merged in LDS)
+  int nw;    // waves per workgroup: 4, or 8 (fp32 tensors, one workgroup per CU, LDS merge)
   int ci_t, co_t, S, split, segs_per_row, total_segs, segs_per_block;
   size_t ws_floats;
   bool stem;
@@ -902,8 +954,18 @@ struct WgradPlan {
 
 int stem_grid(long long stages) { return (int)(stages < 1024 ? stages : 1024); }
 
-WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec = 0) {
+int wgrad_tiles(int Cx, int Cout) {
+  int ci_t = (Cx % 64 == 0) ? 64 : 32;
+  const int co_t = (Cout % 64 == 0) ? 64 : 32;
+  if (ci_t == 64 && co_t == 32) ci_t = 32;
+  return (Cx / ci_t) * (Cout / co_t);
+}
+
+// wide: the 8-wave kernel (fp32 tensors on the fp32 matrix cores)
+WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec = 0,
+                    bool wide = false) {
   WgradPlan pl{};
+  pl.nw = 4;
   if (Cx == 3) {
     pl.stem = true;
     const long long M = (long long)N * H * W;
@@ -920,17 +982,31 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   pl.co_t = (Cout % 64 == 0) ? 64 : 32;
   if (pl.ci_t == 64 && pl.co_t == 32) pl.ci_t = 32;  // instantiated: 32x32, 32x64, 64x64
   const int nsb = (pl.ci_t / 32) * (pl.co_t / 32);
-  pl.npp = 4 / nsb;  // pixel-pair parts per segment, each with a slab of its own
-  // segment length: enough pixel pairs per wave per stage, within the LDS budget
-  if (Wo <= 16) pl.S = 16;
-  else if (pl.ci_t == 64) pl.S = (stride == 2 || prec == 3) ? 16 : 32;  // bf16x3: 3 planes in LDS
-  else if (pl.co_t == 64) pl.S = 32;                       // 32x64 tile
-  else pl.S = (stride == 1 && Wo >= 64) ? 64 : 32;         // 32x32 tile
+  if (wide && prec == 0) {
+    // one 8-wave workgroup per CU; a segment as long as the image row and 133 KB of stages
+    // allow (16 pixel pairs per wave per barrier on 64x64 tiles at S = 64)
+    pl.nw = 8;
+    pl.npp = 8 / nsb;
+    pl.sps = 1;
+    const int smax = nsb == 1 ? (stride == 1 ? 128 : 32)
+                   : nsb == 2 ? 64
+                              : (stride == 1 ? 64 : 32);
+    pl.S = 16;
+    while (pl.S < smax && pl.S < Wo) pl.S *= 2;
+  } else {
+    pl.npp = 4 / nsb;  // pixel-pair parts per segment, each with a slab of its own
+    pl.sps = 1;
+    // segment length: enough pixel pairs per wave per stage, within the LDS budget
+    if (Wo <= 16) pl.S = 16;
+    else if (pl.ci_t == 64) pl.S = (stride == 2 || prec == 3) ? 16 : 32;  // bf16x3: 3 planes in LDS
+    else if (pl.co_t == 64) pl.S = 32;                       // 32x64 tile
+    else pl.S = (stride == 1 && Wo >= 64) ? 64 : 32;         // 32x32 tile
+  }
   pl.segs_per_row = ceil_div(Wo, pl.S);
   pl.total_segs = N * Ho * pl.segs_per_row;
   const int tiles = (Cx / pl.ci_t) * (Cout / pl.co_t);
-  // aim for ~512 workgroups (2 per CU), at least 4 segments per block
-  int split = ceil_div(512, tiles);
+  // aim for two 4-wave workgroups / one 8-wave workgroup per CU, at least 4 segments per block
+  int split = ceil_div(pl.nw == 8 ? 256 : 512, tiles);
   const int max_split = ceil_div(pl.total_segs, 4);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -938,9 +1014,42 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
   // slabs + ping-pong room for the staged reduction (each stage shrinks 16x)
   const size_t E = (size_t)9 * Cx * Cout;
-  const int slabs = pl.split * pl.npp;
+  const int slabs = pl.split * pl.sps;
   pl.ws_floats = (size_t)slabs * E + 2 * (size_t)ceil_div(slabs, kSlabChunk) * E;
   return pl;
+}
+
+// 8-wave form: LDS = the two stages, at least the 96 KB the merge epilogue uses
+template <int CI_T, int CO_T, int S, int STRIDE>
+int launch_wgrad8(const WgradParams& p, hipStream_t stream) {
+  constexpr int PW = (S - 1) * STRIDE + 3;
+  constexpr size_t stages = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
+  constexpr size_t lds = stages > kWgradMergeLds8 ? stages : kWgradMergeLds8;
+  static_assert(lds <= 160 * 1024, "stages exceed the CU's LDS");
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE, true, float, float, 8>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+  } else {
+    auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE, false, float, float, 8>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad(8 waves)");
+  return UNET_OK;
+}
+
+template <int CI_T, int CO_T, int STRIDE>
+int launch_wgrad8_s(const WgradParams& p, int S, hipStream_t stream) {
+  constexpr int NSB = (CI_T / 32) * (CO_T / 32);
+  constexpr int SMAX = NSB == 1 ? (STRIDE == 1 ? 128 : 32) : NSB == 2 ? 64 : (STRIDE == 1 ? 64 : 32);
+  if constexpr (SMAX >= 128) if (S == 128) return launch_wgrad8<CI_T, CO_T, 128, STRIDE>(p, stream);
+  if constexpr (SMAX >= 64) if (S == 64) return launch_wgrad8<CI_T, CO_T, 64, STRIDE>(p, stream);
+  if (S == 32) return launch_wgrad8<CI_T, CO_T, 32, STRIDE>(p, stream);
+  if (S == 16) return launch_wgrad8<CI_T, CO_T, 16, STRIDE>(p, stream);
+  unet_set_error("conv_wgrad(8 waves): no instantiation for S=%d", S);
+  return UNET_E_INVALID;
 }
 
 template <int CI_T, int CO_T, int S, int STRIDE, bool ACT, typename TS>
@@ -959,7 +1068,9 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
 template <int CI_T, int CO_T, int S, int STRIDE, bool ACT, typename TS>
 int launch_wgrad_t(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = (S - 1) * STRIDE + 3;
-  constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
+  constexpr size_t stages = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(float);
+  constexpr bool merge = true;
+  constexpr size_t lds = (merge && stages < kWgradMergeLds4) ? kWgradMergeLds4 : stages;
   constexpr int NT = 256;
   auto kern = conv_wgrad_kernel<CI_T, CO_T, S, STRIDE, ACT, TS, TS>;
   UNET_SET_DYN_LDS(kern, lds);
@@ -972,7 +1083,9 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t stream) {
 template <int CI_T, int CO_T, int S, int NPL = 1, bool SB = false>
 int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = S + 2;
-  constexpr size_t lds = (SB ? 1 : 2) * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  constexpr size_t stages = (SB ? 1 : 2) * NPL * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  constexpr bool merge = true;
+  constexpr size_t lds = (merge && stages < kWgradMergeLds4) ? kWgradMergeLds4 : stages;
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   if constexpr (NPL == 1 && !SB) {
     if (p.b16) {   // bf16 tensors in HBM, operand activated on load when p.alpha is set
@@ -1009,7 +1122,9 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
 template <int CI_T, int CO_T, int S>
 int launch_wgrad_b16_s2(const WgradParams& p, hipStream_t stream) {
   constexpr int PW = (S - 1) * 2 + 3;
-  constexpr size_t lds = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  constexpr size_t stages = 2 * (size_t)(3 * PW * CI_T + S * CO_T) * sizeof(__bf16);
+  constexpr bool merge = true;
+  constexpr size_t lds = (merge && stages < kWgradMergeLds4) ? kWgradMergeLds4 : stages;
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   if (p.alpha) {
     auto kern = conv_wgrad_bf16_kernel<CI_T, CO_T, S, 1, false, __bf16, __bf16, true, 2>;
@@ -1021,6 +1136,25 @@ int launch_wgrad_b16_s2(const WgradParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   }
   UNET_CHECK_LAUNCH("conv_wgrad_bf16(b16, stride 2)");
+  return UNET_OK;
+}
+
+// the 8-wave form (fp32 tensors)
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_taps8(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)S * (CI_T + 9 * CO_T) * sizeof(float);
+  static_assert(lds <= 160 * 1024 && lds >= 96 * 1024, "8-wave stages / merge space");
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, true, float, float, 8>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+  } else {
+    auto kern = conv_wgrad_taps_kernel<CI_T, CO_T, S, false, float, float, 8>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_taps(8 waves)");
   return UNET_OK;
 }
 
@@ -1052,25 +1186,28 @@ int launch_wgrad_taps(const WgradParams& p, hipStream_t stream) {
 }
 
 // plan of the low-resolution tap GEMM: Q pixels, (Cx x Cout) channel tiles
-WgradPlan make_plan_taps(long long Q, int Cx, int Cout) {
+// wide: the 8-wave kernel (fp32 tensors)
+WgradPlan make_plan_taps(long long Q, int Cx, int Cout, bool wide) {
   WgradPlan pl{};
   pl.ci_t = (Cx % 64 == 0) ? 64 : 32;
   pl.co_t = (Cout % 64 == 0) ? 64 : 32;
   if (pl.ci_t == 64 && pl.co_t == 32) pl.ci_t = 32;  // instantiated: 32x32, 32x64, 64x64
   const int nsb = (pl.ci_t / 32) * (pl.co_t / 32);
-  pl.npp = 4 / nsb;
-  pl.S = nsb == 1 ? 32 : 16;
+  pl.nw = wide ? 8 : 4;
+  pl.npp = pl.nw / nsb;
+  pl.sps = 1;
+  pl.S = (nsb == 1 ? 32 : 16) * (wide ? 2 : 1);
   pl.segs_per_row = 0;
   pl.total_segs = (int)ceil_div64(Q, pl.S);
   const int tiles = (Cx / pl.ci_t) * (Cout / pl.co_t);
-  int split = ceil_div(512, tiles);
+  int split = ceil_div(wide ? 256 : 512, tiles);
   const int max_split = ceil_div(pl.total_segs, 4);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   pl.segs_per_block = ceil_div(pl.total_segs, split);
   pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
   const size_t E = (size_t)9 * Cx * Cout;
-  const int slabs = pl.split * pl.npp;
+  const int slabs = pl.split * pl.sps;
   pl.ws_floats = (size_t)slabs * E + 2 * (size_t)ceil_div(slabs, kSlabChunk) * E;
   return pl;
 }
@@ -1078,6 +1215,16 @@ WgradPlan make_plan_taps(long long Q, int Cx, int Cout) {
 // kernel instantiation for a plan (tile, segment length, stride, operand mode)
 int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int prec,
                       hipStream_t stream) {
+  if (pl.nw == 8) {
+    if (pl.ci_t == 32 && pl.co_t == 32)
+      return stride == 1 ? launch_wgrad8_s<32, 32, 1>(p, pl.S, stream)
+                         : launch_wgrad8_s<32, 32, 2>(p, pl.S, stream);
+    if (pl.ci_t == 32)
+      return stride == 1 ? launch_wgrad8_s<32, 64, 1>(p, pl.S, stream)
+                         : launch_wgrad8_s<32, 64, 2>(p, pl.S, stream);
+    return stride == 1 ? launch_wgrad8_s<64, 64, 1>(p, pl.S, stream)
+                       : launch_wgrad8_s<64, 64, 2>(p, pl.S, stream);
+  }
   // bf16 operands: stride 1 and a segment that splits into whole 16-pixel k-groups per wave
   const bool use_bf16 = prec != 0 && stride == 1 && (pl.S / 16) % pl.npp == 0 && pl.S >= 16;
   if (use_bf16 && prec == 3) {
@@ -1124,15 +1271,17 @@ int wgrad_batch_chunk(int N, int H, int W, int Cx, int Cout, int stride) {
   return unet_conv::batch_chunk(N, a > b ? a : b);
 }
 
-size_t wgrad_ws_floats(int N, int H, int W, int Cx, int Cout, int stride, int prec) {
+size_t wgrad_ws_floats(int N, int H, int W, int Cx, int Cout, int stride, int prec,
+                       bool wide = false) {
   if (Cx == 3) return make_plan(N, H, W, Cx, Cout, stride, prec).ws_floats;
   const int nmax = wgrad_batch_chunk(N, H, W, Cx, Cout, stride);
   if (nmax < 1) return 0;
   const size_t E = (size_t)9 * Cx * Cout;
   size_t slabs = 0;
   for (int nb = 0; nb < N; nb += nmax) {
-    const WgradPlan pl = make_plan(N - nb < nmax ? N - nb : nmax, H, W, Cx, Cout, stride, prec);
-    slabs += (size_t)pl.split * pl.npp;
+    const WgradPlan pl = make_plan(N - nb < nmax ? N - nb : nmax, H, W, Cx, Cout, stride, prec,
+                                   wide);
+    slabs += (size_t)pl.split * pl.sps;
   }
   return slabs * E + 2 * (size_t)ceil_div((int)slabs, kSlabChunk) * E;
 }
@@ -1167,7 +1316,9 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
   // one size for every operand mode (the bf16x3 plan uses shorter segments on 64x64 tiles)
   const size_t a = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0);
   const size_t b = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 3);
-  return (a > b ? a : b) * sizeof(float);
+  const size_t c = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0, true);
+  const size_t m = a > b ? a : b;
+  return (m > c ? m : c) * sizeof(float);
 }
 
 static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
@@ -1186,8 +1337,14 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   UNET_REQUIRE(Cx == 3 || (Cx > 0 && Cx % 32 == 0), "conv3x3_bwd_weight: Cx %d unsupported", Cx);
   UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_bwd_weight: bad ci slice");
   const int pprec = (prec == 3 && stride == 1) ? 3 : 0;
-  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride, pprec);
-  const size_t need = wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec) * sizeof(float);
+  // fp32 tensors on the fp32 matrix cores: the 8-wave kernel (parts merged in LDS)
+  // fp32 tensors on the fp32 matrix cores: with >= 4 channel tiles the 8-wave kernel (one
+  // workgroup per CU, <= 64 pixel splits, 16 pixel pairs per barrier); the 32 / 64-channel layers
+  // keep two independent 4-wave workgroups per CU (measured 4-6 % faster there: their 128..256
+  // pixel splits leave the 8-wave form few MFMAs per barrier and long reductions)
+  const bool wide = prec == 0 && !b16 && Cx != 3 && wgrad_tiles(Cx, Cout) >= 4;
+  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride, pprec, wide);
+  const size_t need = wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec, wide) * sizeof(float);
   if (workspace_bytes < need || need == 0) {
     unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     return UNET_E_WORKSPACE;
@@ -1229,7 +1386,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int nslab = pl.stem_blocks;
     float* ping = ws + (size_t)pl.stem_blocks * n;
     float* pong = ping + (size_t)ceil_div(pl.stem_blocks, kSlabChunk) * n;
-    while (nslab > 8) {
+    while (nslab > 16) {
       const int chunks = ceil_div(nslab, kSlabChunk);
       dim3 g((unsigned)ceil_div(n / 4, 256), chunks);
       hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
@@ -1250,7 +1407,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int nslab = 0;
     for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
       const int nc = N - nb < nmax ? N - nb : nmax;
-      const WgradPlan pc = make_plan(nc, H, W, Cx, Cout, stride, pprec);
+      const WgradPlan pc = make_plan(nc, H, W, Cx, Cout, stride, pprec, wide);
       WgradParams p{};
       p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
                                            (size_t)nb * H * W * Cx * es);
@@ -1269,12 +1426,12 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       p.slope = slope;
       const int rc = launch_wgrad_plan(p, pc, stride, prec, stream);
       if (rc != UNET_OK) return rc;
-      nslab += pc.split * pc.npp;
+      nslab += pc.split * pc.sps;
     }
     const float* cur = ws;
     float* ping = ws + (size_t)nslab * E;
     float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
-    while (nslab > 8) {
+    while (nslab > 16) {
       const int chunks = ceil_div(nslab, kSlabChunk);
       dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
       hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
@@ -1288,6 +1445,10 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       dim3 rgrid(Cout / 32, Cx / 32);
       hipLaunchKernelGGL(wgrad_reduce_center_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw,
                          nslab, Cx, Cout, ci_offset, Cin_total);
+    } else if ((long long)Cx * Cout <= 128 * 128) {   // few output tiles: one tap per block
+      dim3 rgrid(Cout / 32, Cx / 8, 9);
+      hipLaunchKernelGGL(wgrad_reduce_tap_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab,
+                         Cx, Cout, ci_offset, Cin_total);
     } else {
       dim3 rgrid(Cout / 32, Cx / 8);
       hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
@@ -1396,14 +1557,15 @@ int up_wgrad_chunk(int N, int h, int w, int Cx, int Cout) {
   const long long a = (long long)h * w * Cx * 4, b = (long long)h * w * 9 * Cout * 4;
   return unet_conv::batch_chunk(N, a > b ? a : b);
 }
-size_t up_wgrad_ws_floats(int N, int h, int w, int Cx, int Cout) {
+size_t up_wgrad_ws_floats(int N, int h, int w, int Cx, int Cout, bool wide) {
   const int nmax = up_wgrad_chunk(N, h, w, Cx, Cout);
   if (nmax < 1) return 0;
   const size_t E = (size_t)9 * Cx * Cout;
   size_t slabs = 0;
   for (int nb = 0; nb < N; nb += nmax) {
-    const WgradPlan pl = make_plan_taps((long long)(N - nb < nmax ? N - nb : nmax) * h * w, Cx, Cout);
-    slabs += (size_t)pl.split * pl.npp;
+    const WgradPlan pl =
+        make_plan_taps((long long)(N - nb < nmax ? N - nb : nmax) * h * w, Cx, Cout, wide);
+    slabs += (size_t)pl.split * pl.sps;
   }
   return slabs * E + 2 * (size_t)ceil_div((int)slabs, kSlabChunk) * E;
 }
@@ -1411,7 +1573,9 @@ size_t up_wgrad_ws_floats(int N, int h, int w, int Cx, int Cout) {
 
 extern "C" size_t unet_conv3x3_up_bwd_weight_workspace_bytes(int N, int h, int w, int Cx, int Cout) {
   if (N <= 0 || h <= 0 || w <= 0 || Cx <= 0 || Cout <= 0) return 0;
-  return up_wgrad_ws_floats(N, h, w, Cx, Cout) * sizeof(float);
+  const size_t a = up_wgrad_ws_floats(N, h, w, Cx, Cout, false);
+  const size_t b = up_wgrad_ws_floats(N, h, w, Cx, Cout, true);
+  return (a > b ? a : b) * sizeof(float);
 }
 
 static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D, float* dw_oihw,
@@ -1450,7 +1614,8 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
   UNET_REQUIRE(!x->alpha || x->beta, "conv3x3_up_bwd_weight: alpha without beta");
   const int nmax = up_wgrad_chunk(N, h, w, Cx, Cout);
   UNET_REQUIRE(nmax >= 1, "conv3x3_up_bwd_weight: one image exceeds the 2 GiB buffer-descriptor range");
-  const size_t need = up_wgrad_ws_floats(N, h, w, Cx, Cout) * sizeof(float);
+  const bool wide = !b16 && wgrad_tiles(Cx, Cout) >= 4;   // as in conv_bwd_weight_impl
+  const size_t need = up_wgrad_ws_floats(N, h, w, Cx, Cout, wide) * sizeof(float);
   if (workspace_bytes < need) {
     unet_set_error("conv3x3_up_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     return UNET_E_WORKSPACE;
@@ -1461,7 +1626,7 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
   for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
     const int nc = N - nb < nmax ? N - nb : nmax;
     const long long Q = (long long)nc * h * w;
-    const WgradPlan pl = make_plan_taps(Q, Cx, Cout);
+    const WgradPlan pl = make_plan_taps(Q, Cx, Cout, wide);
     WgradParams p{};
     p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x->x) +
                                          (size_t)nb * h * w * Cx * es);
@@ -1479,16 +1644,22 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
     p.beta = x->alpha ? x->beta + (size_t)nb * Cx : nullptr;
     p.slope = slope;
     int rc;
-    if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
-    else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
-    else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
+    if (wide) {
+      if (pl.ci_t == 64) rc = launch_wgrad_taps8<64, 64, 32>(p, stream);
+      else if (pl.co_t == 64) rc = launch_wgrad_taps8<32, 64, 32>(p, stream);
+      else rc = launch_wgrad_taps8<32, 32, 64>(p, stream);
+    } else {
+      if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
+      else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
+      else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
+    }
     if (rc != UNET_OK) return rc;
-    nslab += pl.split * pl.npp;
+    nslab += pl.split * pl.sps;
   }
   const float* cur = ws;
   float* ping = ws + (size_t)nslab * E;
   float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
-  while (nslab > 8) {
+  while (nslab > 16) {
     const int chunks = ceil_div(nslab, kSlabChunk);
     dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
     hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
@@ -1498,9 +1669,15 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
     float* t = ping; ping = pong; pong = t;
     nslab = chunks;
   }
-  dim3 rgrid(Cout / 32, Cx / 8);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
-                     Cout, ci_offset, Cin_total);
+  if ((long long)Cx * Cout <= 128 * 128) {
+    dim3 rgrid(Cout / 32, Cx / 8, 9);
+    hipLaunchKernelGGL(wgrad_reduce_tap_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab,
+                       Cx, Cout, ci_offset, Cin_total);
+  } else {
+    dim3 rgrid(Cout / 32, Cx / 8);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
+                       Cout, ci_offset, Cin_total);
+  }
   UNET_CHECK_LAUNCH("wgrad_reduce");
   return UNET_OK;
 }

@@ -387,11 +387,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const TS* __re
 }
 
 // ---- SGD with Nesterov momentum ------------------------------------------------
+// hyper != nullptr: {lr, mu, wd, gscale} are read from device memory (graph-captured steps)
 __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p,
                                                            const float* __restrict__ g,
                                                            float* __restrict__ buf, long long n,
                                                            float lr, float mu, float wd,
-                                                           int first_step, float gscale) {
+                                                           int first_step, float gscale,
+                                                           const float* __restrict__ hyper) {
+  if (hyper) { lr = hyper[0]; mu = hyper[1]; wd = hyper[2]; gscale = hyper[3]; }
   const long long stride = (long long)gridDim.x * 256;
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -565,8 +568,22 @@ extern "C" int unet_sgd_nesterov_step(float* params, const float* grads, float* 
                "sgd_nesterov_step: arenas must be 16-byte aligned");
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, params, grads, momentum, (long long)n, lr, mu,
-                     weight_decay, first_step, grad_scale);
+                     weight_decay, first_step, grad_scale, (const float*)nullptr);
   UNET_CHECK_LAUNCH("sgd_nesterov");
+  return UNET_OK;
+}
+
+extern "C" int unet_sgd_nesterov_step_dev(float* params, const float* grads, float* momentum,
+                                          int64_t n, const float* hyper, int first_step,
+                                          unet_stream_t stream) {
+  UNET_REQUIRE(params && grads && momentum && hyper && n > 0, "sgd_nesterov_step_dev: bad argument");
+  UNET_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0) &&
+                   ((uintptr_t)momentum % 16 == 0),
+               "sgd_nesterov_step_dev: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, params, grads, momentum, (long long)n, 0.f, 0.f, 0.f,
+                     first_step, 1.f, hyper);
+  UNET_CHECK_LAUNCH("sgd_nesterov(dev)");
   return UNET_OK;
 }
 

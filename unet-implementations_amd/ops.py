@@ -823,6 +823,14 @@ def sgd_nesterov_step(params, grads, momentum, lr, mu, weight_decay, first_step,
         _timer.end("sgd_nesterov", 0.0, 1, t0, nbytes=4.0 * (5 if not first_step else 4) * n)
 
 
+def sgd_nesterov_step_dev(params, grads, momentum, hyper, first_step):
+    """As sgd_nesterov_step with {lr, mu, weight_decay, grad_scale} read from the device tensor
+    `hyper` (fp32 [4]): what a graph-captured train step launches."""
+    n = params.numel()
+    check(lib().unet_sgd_nesterov_step_dev(_ptr(params), _ptr(grads), _ptr(momentum), n,
+                                           _ptr(hyper), 1 if first_step else 0, _stream()))
+
+
 def add_inplace(a, b):
     check(lib().unet_add_inplace(_ptr(a), _ptr(b), a.numel(), _stream()))
     return a

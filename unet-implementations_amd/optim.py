@@ -28,6 +28,32 @@ class FusedSGD(torch.optim.Optimizer):
         self._flat_buf = None
         self._steps = 0
         self.grad_scale = 1.0
+        # graph-captured steps (train.GraphedTrainStep): lr / momentum / weight decay / grad_scale
+        # are read by the kernel from this device tensor, refreshed by sync_device_hyper()
+        self._hyper = None
+        self._hyper_host = None
+
+    def use_device_hyper(self, on=True):
+        """Make the flat-arena step read its hyper-parameters from device memory, so that a step
+        captured in a HIP graph follows later changes of `param_groups[0]['lr']` (LR schedule)."""
+        if not on:
+            self._hyper = self._hyper_host = None
+            return
+        arena, _ = self._model.flat_parameters()
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=arena.device)
+        self._hyper_host = None
+        self.sync_device_hyper()
+
+    def sync_device_hyper(self):
+        """Copy {lr, momentum, weight_decay, grad_scale} to the device tensor if they changed."""
+        if self._hyper is None:
+            return
+        g = self.param_groups[0]
+        vals = (float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]),
+                float(self.grad_scale))
+        if vals != self._hyper_host:
+            self._hyper.copy_(torch.tensor(vals, dtype=torch.float32))
+            self._hyper_host = vals
 
     def _flat_ready(self):
         """True when one launch over the arenas is equivalent to the per-parameter update."""
@@ -78,9 +104,15 @@ class FusedSGD(torch.optim.Optimizer):
                         self._flat_buf[off:off + p.numel()].view_as(p).copy_(st["momentum_buffer"])
                         first = False
                     st["momentum_buffer"] = self._flat_buf[off:off + p.numel()].view_as(p)
-            ops.sgd_nesterov_step(arena, garena, self._flat_buf, g["lr"], g["momentum"],
-                                  g["weight_decay"], first, self.grad_scale)
+            if self._hyper is not None:
+                ops.sgd_nesterov_step_dev(arena, garena, self._flat_buf, self._hyper, first)
+            else:
+                ops.sgd_nesterov_step(arena, garena, self._flat_buf, g["lr"], g["momentum"],
+                                      g["weight_decay"], first, self.grad_scale)
         else:
+            if self._hyper is not None:
+                raise RuntimeError("device-side hyper-parameters need the flat-arena step (every "
+                                   "parameter and gradient a view of the UNet arenas)")
             for g in self.param_groups:
                 for p in g["params"]:
                     if p.grad is None:

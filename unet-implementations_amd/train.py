@@ -61,6 +61,72 @@ def train_step(model, optimizer, loss_function, images, masks, grad_sync=None):
     return loss.detach()
 
 
+class GraphedTrainStep:
+    """`train_step` captured once in a HIP graph and replayed: one host call per step instead of
+    the ~330 ctypes calls / ~250 kernel launches of the eager walk (5 ms of host time per step;
+    the bf16 mode's whole step is 8-11 ms).  The step order is the reference's
+    (Our_UNet/src/train.py:634-664); shapes are fixed at capture (the reference trains on fixed
+    512x512 crops), dropout masks are drawn inside the graph by torch's graph-safe generator,
+    the learning rate is read from device memory (FusedSGD.use_device_hyper) so an LR schedule
+    needs no re-capture.
+
+        step = GraphedTrainStep(model, optimizer, loss_function, images, masks)
+        loss = step(images, masks)        # device scalar, no host sync
+
+    Capturing runs `warmup` throw-away steps first (kernel attributes, workspaces, the packing
+    table); parameters, momentum and the step counter are restored afterwards.  The bucketed
+    all-reduce hook of ddp.GradBucketAllReduce is not captured: use the eager `train_step` there.
+    """
+
+    def __init__(self, model, optimizer, loss_function, images, masks, warmup=2):
+        if not images.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs ROCm tensors (no CPU fallback exists)")
+        if model.grad_ready_hook is not None:
+            raise RuntimeError("the data-parallel gradient hook cannot be captured in a graph")
+        if not isinstance(optimizer, FusedSGD):
+            raise TypeError("GraphedTrainStep needs the FusedSGD optimizer")
+        self.model, self.optimizer, self.loss_function = model, optimizer, loss_function
+        self.images = images.detach().clone()
+        self.masks = masks.detach().clone()
+        arena, _ = model.flat_parameters()
+        keep_arena = arena.detach().clone()
+        had_buf = optimizer._flat_buf is not None
+        keep_buf = optimizer._flat_buf.detach().clone() if had_buf else None
+        keep_steps = optimizer._steps
+        optimizer.use_device_hyper(True)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                train_step(model, optimizer, loss_function, self.images, self.masks)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model, optimizer, loss_function, self.images, self.masks)
+        # undo the throw-away steps (the captured step itself did not execute)
+        with torch.no_grad():
+            arena.copy_(keep_arena)
+            if had_buf:
+                optimizer._flat_buf.copy_(keep_buf)
+            else:      # zero momentum == "first step" of torch's SGD (buf <- g)
+                optimizer._flat_buf.zero_()
+        optimizer._steps = keep_steps
+
+    def __call__(self, images, masks):
+        if images.shape != self.images.shape or masks.shape != self.masks.shape:
+            raise ValueError("GraphedTrainStep was captured for batches of shape "
+                             f"{tuple(self.images.shape)} / {tuple(self.masks.shape)}")
+        if images.data_ptr() != self.images.data_ptr():
+            self.images.copy_(images, non_blocking=True)
+        if masks.data_ptr() != self.masks.data_ptr():
+            self.masks.copy_(masks, non_blocking=True)
+        self.optimizer.sync_device_hyper()
+        self.graph.replay()
+        self.optimizer._steps += 1
+        return self.loss
+
+
 @torch.no_grad()
 def validate(model, val_loader, loss_function, device, ignore_label=255):
     """Counterpart of validate() (Our_UNet/src/train.py:510-589): eval-mode forward, loss, and

@@ -485,6 +485,10 @@ class _UNetFunction(torch.autograd.Function):
         # pixels run the split patch kernel (forward + data gradient), the rest the fp32 kernels
         x3 = fused and bf16 == "bf16x3"
 
+        # test hook: a list that receives (layer name, raw conv output y, statistics [4,N,C]) of
+        # every fused layer in forward order (tests/test_net_gpu.py: the LeakyReLU branch pattern)
+        dbg_fwd = getattr(model, "_debug_forward", None)
+
         def run_layer_fused(l, s0, s1):
             """s0 / s1: ops.Act operands; returns the Act of this layer's output."""
             w = l.conv.weight
@@ -502,6 +506,8 @@ class _UNetFunction(torch.autograd.Function):
             if need_grad:
                 saved.append(dict(layer=l, x0=s0, x1=s1, y=y, st=st, mask=m, wd=wd,
                                   wd3=table.wd3[k] if w3 is not None else None))
+            if dbg_fwd is not None:
+                dbg_fwd.append((l.name, y, st))
             return ops.Act(y, st[2], st[3])
 
         def run_up_layer_fused(l, low, skip):
@@ -520,6 +526,8 @@ class _UNetFunction(torch.autograd.Function):
                 if need_grad:
                     saved.append(dict(layer=l, x0=None, x1=skip, y=y, st=st, mask=m,
                                       wd=table.wd[k], wd3=None, x0_low=low))
+                if dbg_fwd is not None:
+                    dbg_fwd.append((l.name, y, st))
                 return ops.Act(y, st[2], st[3])
             out = run_layer_fused(l, ops.Act(ops.upsample2x_in_fwd(low, slope)), skip)
             if need_grad:
