@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 2
+#define UNET_ABI_VERSION 3
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -461,6 +461,30 @@ int unet_conv3x3_bwd_data_bs_bf16x3(const float* dy, const float* wd, const uint
 int unet_conv3x3_up_bwd_data_bs(const float* D, const float* wd, int Cin_total, int ci_offset,
                                 float* g, int N, int h, int w, int Cout, int Ccols, int accumulate,
                                 unet_bwd_stats* bs, unet_stream_t stream);
+/* ---- Winograd F(2x2, 3x3) form of the stride-1 3x3 layers (csrc/conv_wino.hip) ------------
+ * 2.25x fewer matrix-core FLOPs than the direct kernels for the layers it tiles (image as
+ * 8 x 32 pixels, >= 64 reduction channels in multiples of 8, output channels in multiples of
+ * 64, >= 256 workgroups).  The transformed weights U = G g G^T (16 floats per filter, stored in
+ * the kernel's LDS image order) are produced once per step by unet_pack_wino_weights:
+ *   uf (forward,       Cout % 64 == 0, Cin % 8 == 0)  and/or
+ *   ud (data gradient, Cin % 64 == 0, Cout % 8 == 0),  unet_wino_weight_floats() floats each.
+ * Same arithmetic as nn.Conv2d / its data gradient (Our_UNet/models/unet.py:106-115) up to
+ * fp32 rounding of the transforms (<= 3e-6 of max |y| measured). */
+int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
+size_t unet_wino_weight_floats(int Cout, int Cin);
+int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin,
+                           unet_stream_t stream);
+/* unet_conv_in_fwd (ksize 3, stride 1) on the Winograd kernel: y = conv3x3(cat(act(s0),
+ * act(s1))) + bias and the per-tile statistics of y (256 pixels per tile). */
+int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                          const float* uf, const float* bias, float* y, void* workspace,
+                          size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
+                          unet_stream_t stream);
+/* unet_conv3x3_bwd_data_bs (stride 1, accumulate 0) on the Winograd kernel; ud covers the whole
+ * weight [Cout][Cin_total], ci_offset % 64 == 0; bs may be NULL. */
+int unet_conv3x3_bwd_data_bs_wino(const float* dy, const float* ud, int Cin_total, int ci_offset,
+                                  float* dx, int N, int H, int W, int Cout, int Ccols,
+                                  unet_bwd_stats* bs, unet_stream_t stream);
 /* unet_instnorm_lrelu_drop_bwd with the reductions already summarised per tile
  * (partial[(n * tiles + t) * C + c] = (S1, S2)). */
 int unet_instnorm_lrelu_drop_bwd_partials(const float* ga, const float* y, const float* mean,

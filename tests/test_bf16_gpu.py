@@ -246,12 +246,20 @@ def test_bf16_pipeline_vs_oracle_with_the_same_rounding_points(ua):
     """Whole network in the mixed-precision mode against the ORACLE evaluated with bf16 operand
     and storage rounding (`bf16_storage=True`), not against the HIP fp32 path.  bf16 noise is
     amplified through 23 conv + InstanceNorm layers, so two bf16 evaluations with different
-    summation orders differ from each other as much as each differs from fp32 (max-norm ~1e-1
-    on the logits): the check is therefore on the DISTANCE TO THE EXACT fp32 RESULT - the HIP
-    pipeline must be no further from it than the oracle's own bf16 evaluation (x1.5), on the
-    logits (rms), the loss and every gradient tensor (cosine)."""
+    summation orders differ from each other as much as each differs from fp32 (relative L2
+    0.25-0.45 on the encoder's activation gradients at this size): the check is therefore on the
+    DISTANCE TO THE EXACT fp32 RESULT - the HIP pipeline must be no further from it than the
+    oracle's own bf16 evaluation (x1.5 + a floor), on the logits (rms), the loss and EVERY
+    gradient tensor, the 32..512-element InstanceNorm vectors included (relative L2).
+
+    128 x 128 images: at 64 x 64 the 1/32-resolution layers normalise over four pixels, the
+    relative error of every encoder gradient is 0.6-0.8 for the emulation and the HIP run alike,
+    and the ratio of two such errors on a 32-element vector scatters by +-50 % (the 2-2.8x cosine
+    gaps of round 2's diagnostic on four norm vectors; layer by layer the activation gradients of
+    the two are equally far from fp32 at 64, 128 and 256 pixels -
+    tests/tools/diag_bf16_layers.py, profiles/r03_bf16_layers_vs_emulation.txt)."""
     sd0 = O.fill_state_dict(3)
-    img, tgt = O.synthetic_batch(1, 2, 64, 64)
+    img, tgt = O.synthetic_batch(1, 2, 128, 128)
     masks = O.draw_dropout_masks(4, 2)
 
     def oracle(emulate):
@@ -270,18 +278,21 @@ def test_bf16_pipeline_vs_oracle_with_the_same_rounding_points(ua):
     cosd = lambda a, b: 1 - F.cosine_similarity(a.double().reshape(1, -1),
                                                 b.double().reshape(1, -1)).item()
     flat = lambda d: torch.cat([d[k].double().reshape(-1) for k in g32])
-    # the whole 19.66 M-element gradient (measured: HIP 0.177, emulation 0.175 from fp32)
     d_hip, d_emu = cosd(flat(grads), flat(g32)), cosd(flat(gem), flat(g32))
     assert d_hip <= 1.3 * d_emu + 1e-2, f"gradient 1-cos vs fp32: HIP {d_hip:.3e}, emulation {d_emu:.3e}"
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return ((a - b).norm() / b.norm()).item()
+
     bad = []
     for k, g in grads.items():
-        # per tensor for the convolution weights; the 32..512-element InstanceNorm vectors are
-        # too short for a cosine under this much bf16 noise (they are in the whole-gradient check)
-        if g.numel() < 4096:
+        if g32[k].abs().max() < 1e-4:      # conv biases under InstanceNorm: ~0 in every run
             continue
-        c_hip, c_emu = cosd(g, g32[k]), cosd(gem[k], g32[k])
-        if c_hip > 1.5 * c_emu + 1e-2:
-            bad.append(f"{k}: 1-cos HIP {c_hip:.3e} vs emulation {c_emu:.3e}")
+        r_hip, r_emu = rel(g, g32[k]), rel(gem[k], g32[k])
+        if r_hip > 1.5 * r_emu + 0.05:
+            bad.append(f"{k} ({g.numel()} elements): relative L2 vs fp32 HIP {r_hip:.3e}, "
+                       f"emulation {r_emu:.3e}")
     assert not bad, "\n".join(bad)
 
 

@@ -139,6 +139,83 @@ def test_conv_in_fwd(ua, case, with_mask):
     assert (st[3].cpu().double() - beta_ref).abs().max() <= 5e-5 * scale
 
 
+WINO_CASES = [  # (N, H, W, C0, C1, Cout, act0, act1): shapes the Winograd kernel tiles
+    (4, 128, 128, 64, 0, 64, True, False),     # one column tile, 8 chunks
+    (2, 128, 128, 128, 0, 128, True, False),   # two column tiles
+    (4, 64, 64, 256, 0, 256, True, False),     # the 256-channel layer shape
+    (2, 128, 256, 32, 32, 64, False, True),    # two sources (virtual concat), plain src0, H != W
+    (8, 32, 32, 64, 0, 512, True, False),      # image = one tile column
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_conv_in_fwd_winograd(ua, case, with_mask):
+    """The Winograd F(2x2,3x3) form of the fused forward (csrc/conv_wino.hip) against the fp64
+    convolution of the activated sources - same tolerances as the direct kernels - and against
+    the direct kernel behind the same entry point."""
+    N, H, W, C0, C1, Cout, act0, act1 = case
+    assert ua.ops.conv_wino_supported(N, H, W, C0, C1, Cout)
+    x0 = rnd(N, C0, H, W, seed=1)
+    x1 = rnd(N, C1, H, W, seed=2) if C1 else None
+    c0 = coeffs(N, C0, 10) if act0 else None
+    c1 = coeffs(N, C1, 20) if (act1 and C1) else None
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=(2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma = rnd(Cout, seed=5) * 0.2 + 1.0
+    beta = rnd(Cout, seed=6) * 0.2
+    mask = None
+    if with_mask:
+        keep = torch.rand(N, Cout, generator=torch.Generator().manual_seed(7)) < 0.7
+        mask = keep.float() / 0.7
+    a0 = act_ref(x0, *c0) if c0 else x0.double()
+    parts = [a0]
+    if C1:
+        parts.append(act_ref(x1, *c1) if c1 else x1.double())
+    y_ref = F.conv2d(torch.cat(parts, 1), w.double(), b.double(), padding=1)
+    mean_ref = y_ref.mean(dim=(2, 3))
+    rstd_ref = 1.0 / torch.sqrt(y_ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+    wk, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    uf, _ = ua.ops.pack_wino_weights(w.to(DEV), want_d=False)
+    s0 = make_src(ua, x0, c0)
+    s1 = make_src(ua, x1, c1) if C1 else None
+    args = (s0, s1, SLOPE, wk, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV), 1e-5,
+            None if mask is None else mask.to(DEV))
+    y, st = ua.ops.conv_in_fwd(*args, wu=uf)
+    check(from_nhwc(y), y_ref, 2e-5, "y (Winograd)")
+    assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), rstd_ref, 5e-5, "rstd (Winograd)")
+    y32, st32 = ua.ops.conv_in_fwd(*args)
+    check(y, y32, 2e-5, "Winograd vs direct")
+    check(st[2], st32[2], 5e-5, "alpha: Winograd vs direct")
+
+
+@pytest.mark.parametrize("case", [(4, 128, 128, 64, 64, 0), (4, 64, 64, 256, 256, 0),
+                                  (2, 128, 128, 128, 128, 0), (4, 64, 64, 256, 256, 512)])
+def test_data_gradient_winograd(ua, case):
+    """Winograd data gradient vs the direct kernel, with the BSTATS epilogue (reductions of the
+    next InstanceNorm backward) and with a column slice of a wider weight (the skip half of a
+    decoder stage's first convolution: ci_offset > 0, no reductions)."""
+    N, H, W, Cout, Ccols, ci_off = case
+    cin_total = ci_off + Ccols
+    dy = to_nhwc(rnd(N, Cout, H, W, seed=1))
+    w = rnd(Cout, cin_total, 3, 3, seed=2, scale=0.1)
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    _, ud = ua.ops.pack_wino_weights(w.to(DEV), want_f=False)
+    assert ua.ops.conv_wino_supported(N, H, W, Cout, 0, Ccols)
+    ref = ua.ops.conv3x3_bwd_data(dy, wd, ci_off, Ccols, H, W, 1)
+    if ci_off:
+        g = ua.ops.conv3x3_bwd_data(dy, wd, ci_off, Ccols, H, W, 1, ud=ud)
+        check(g, ref, 2e-5, "Winograd data gradient (slice) vs direct")
+        return
+    y, st, gamma, beta, mask = _next_norm(ua, N, Ccols, H, W, 10)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, 1, nxt=nn, ud=ud)
+    check(g, ref, 2e-5, "Winograd data gradient vs direct")
+    assert nn.tiles == H * W // 256
+    _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
+
+
 X3_FUSED_CASES = [  # shapes the split patch kernel takes in the fused pipeline
     (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # 128 columns, two sources
     (2, 256, 256, 64, 0, 64, 1, 3, True, False),     # 64 columns, 8-row tiles

@@ -106,6 +106,12 @@ SIGNATURES = {
                                             _p]),
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_data_bs": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
+    "unet_conv_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_wino_weight_floats": (_sz, [_i, _i]),
+    "unet_pack_wino_weights": (_i, [_p, _p, _p, _i, _i, _p]),
+    "unet_conv_in_fwd_wino": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,
+                                   _i, _p]),
+    "unet_conv3x3_bwd_data_bs_wino": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv3x3_bwd_data_bs_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv3x3_bwd_data_bs_bf16x3": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs,
                                              _p]),
@@ -173,7 +179,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.unet_abi_version() != 2:
+    if handle.unet_abi_version() != 3:
         raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

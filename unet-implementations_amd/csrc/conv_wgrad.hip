@@ -745,6 +745,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Wide form for the large gradients (Cx * Cout > 128 * 128): a block sums 64 co x CI ci x 9 taps
+// with 16-byte loads along co (256-byte row segments instead of 128) and writes runs of CI * 9
+// contiguous floats per output channel.
+template <int CI>
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial,
+                                                                float* __restrict__ dw, int split,
+                                                                int Cx, int Cout, int ci_off,
+                                                                int Cin_total) {
+  __shared__ float tile[9 * CI][65];
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * CI;
+  const int c4 = threadIdx.x & 15, r = threadIdx.x >> 4;   // 16 rows x 16 float4 per pass
+  const size_t slab = (size_t)9 * Cx * Cout;
+  for (int rr = r; rr < 9 * CI; rr += 16) {
+    const int t = rr / CI, ci = rr - t * CI;
+    const float* src = partial + ((size_t)t * Cx + ci0 + ci) * Cout + co0 + c4 * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < split; ++k) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab);
+    tile[rr][c4 * 4 + 0] = s[0]; tile[rr][c4 * 4 + 1] = s[1];
+    tile[rr][c4 * 4 + 2] = s[2]; tile[rr][c4 * 4 + 3] = s[3];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * CI * 9; i += 256) {
+    const int co = i / (CI * 9), rem = i - co * (CI * 9);
+    const int ci = rem / 9, t = rem - ci * 9;
+    dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[t * CI + ci][co];
+  }
+}
+
 // The same with one tap per block (grid.z = 9): 9x the workgroups for the layers whose
 // gradient is small (32 / 64 channels: 4 / 16 blocks of the kernel above, each thread walking
 // split x 9 dependent slab rows, would run for tens of microseconds on a near-idle chip).
@@ -1449,6 +1477,13 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       dim3 rgrid(Cout / 32, Cx / 8, 9);
       hipLaunchKernelGGL(wgrad_reduce_tap_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab,
                          Cx, Cout, ci_offset, Cin_total);
+    } else if (Cout % 64 == 0 && Cx % 16 == 0) {
+      if ((long long)Cx * Cout >= 512 * 512)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel<16>, dim3(Cout / 64, Cx / 16), dim3(256), 0,
+                           stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
+      else
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel<8>, dim3(Cout / 64, Cx / 8), dim3(256), 0,
+                           stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
     } else {
       dim3 rgrid(Cout / 32, Cx / 8);
       hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
@@ -1673,6 +1708,13 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
     dim3 rgrid(Cout / 32, Cx / 8, 9);
     hipLaunchKernelGGL(wgrad_reduce_tap_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab,
                        Cx, Cout, ci_offset, Cin_total);
+  } else if (Cout % 64 == 0 && Cx % 16 == 0) {
+    if ((long long)Cx * Cout >= 512 * 512)
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel<16>, dim3(Cout / 64, Cx / 16), dim3(256), 0,
+                         stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel<8>, dim3(Cout / 64, Cx / 8), dim3(256), 0,
+                         stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
   } else {
     dim3 rgrid(Cout / 32, Cx / 8);
     hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,

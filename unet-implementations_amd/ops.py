@@ -142,11 +142,23 @@ class PackTable:
     """Device table for `unet_pack_conv3x3_weights_batched`: one entry per 3x3 layer with
     persistent destination buffers (fp32 layouts always, bf16x3 planes on request)."""
 
-    def __init__(self, weights, planes):
+    def __init__(self, weights, planes, wino=None):
+        """wino: per weight a pair (forward, data gradient) of flags - also keep the Winograd
+        forms U = G g G^T of that layer (csrc/conv_wino.hip), refreshed by run()."""
         import struct
         self.wf, self.wd, self.wf3, self.wd3 = [], [], [], []
         self.src_ptrs = [w.data_ptr() for w in weights]
         self.planes = planes
+        self.wino = tuple(wino) if wino is not None else tuple((False, False) for _ in weights)
+        self.uf, self.ud, self._wino_jobs = [], [], []
+        for w, (ff, fd) in zip(weights, self.wino):
+            cout, cin = w.shape[0], w.shape[1]
+            uf = _f32((16 * cout * cin,), w) if ff else None
+            ud = _f32((16 * cout * cin,), w) if fd else None
+            self.uf.append(uf)
+            self.ud.append(ud)
+            if uf is not None or ud is not None:
+                self._wino_jobs.append((w, uf, ud, cout, cin))
         raw = b""
         tiles = 0
         for w in weights:
@@ -167,13 +179,17 @@ class PackTable:
         self.n, self.tiles = len(weights), tiles
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(weights[0].device)
 
-    def matches(self, weights, planes):
-        return planes == self.planes and len(weights) == self.n and \
+    def matches(self, weights, planes, wino=None):
+        wino = tuple(wino) if wino is not None else tuple((False, False) for _ in weights)
+        return planes == self.planes and len(weights) == self.n and wino == self.wino and \
             all(w.data_ptr() == p for w, p in zip(weights, self.src_ptrs))
 
     def run(self):
         check(lib().unet_pack_conv3x3_weights_batched(self.table.data_ptr(), self.n, self.tiles,
                                                       _stream()))
+        for w, uf, ud, cout, cin in self._wino_jobs:
+            check(lib().unet_pack_wino_weights(_ptr(w.detach()), _ptr(uf), _ptr(ud), cout, cin,
+                                               _stream()))
 
 
 # ---- convolution ---------------------------------------------------------------
@@ -240,12 +256,29 @@ class NextNorm:
 
 
 def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False,
-                     bf16=False, wd3=None, nxt=None):
+                     bf16=False, wd3=None, nxt=None, ud=None):
     """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols).
-    nxt (NextNorm, fp32 path): dx is final for that layer - also emit its backward reductions."""
+    nxt (NextNorm, fp32 path): dx is final for that layer - also emit its backward reductions.
+    ud: the Winograd data-gradient form of the weight (fp32 tensors, stride 1, no accumulate,
+    shape checked by the caller with conv_wino_supported)."""
     N, Ho, Wo, Cout = dy.shape
     cin_total = wd.shape[1]
     assert wd.shape[0] == 9 and wd.shape[2] == Cout
+    if ud is not None and not _is_b16(dy) and stride == 1 and not accumulate and _prec(bf16) == 0:
+        dx = out if out is not None else _f32((N, H, W, ccols), dy)
+        assert dx.shape == (N, H, W, ccols)
+        bs = nxt.c_struct() if nxt is not None else None
+        t0 = _timer.begin("conv") if _timer is not None else None
+        check(lib().unet_conv3x3_bwd_data_bs_wino(_ptr(dy), _ptr(ud), cin_total, ci_offset,
+                                                  _ptr(dx), N, H, W, Cout, ccols,
+                                                  ctypes.byref(bs) if bs is not None else None,
+                                                  _stream()))
+        if nxt is not None:
+            nxt.tiles = bs.tiles_out
+        if t0 is not None:
+            alg = 2.0 * N * H * W * 9 * ccols * Cout
+            _timer.end("conv_igemm", alg, 1, t0, executed=alg * 16.0 / 36.0)
+        return dx
     if _is_b16(dy):     # mixed-precision pipeline: bf16 tensors, bf16 matrix cores
         dx = out if out is not None else _b16((N, H, W, ccols), dy)
         assert dx.shape == (N, H, W, ccols) and _is_b16(dx)
@@ -466,8 +499,23 @@ def _act(a):
     return a, ctypes.byref(st)
 
 
+def conv_wino_supported(N, H, W, C0, C1, Cout):
+    """Does the Winograd kernel tile conv3x3(stride 1) of [N,H,W,C0+C1] -> Cout (forward), or the
+    data gradient with K = C0 reduction channels and Cout columns?"""
+    return bool(lib().unet_conv_wino_supported(N, H, W, C0, C1, Cout))
+
+
+def pack_wino_weights(w_oihw, want_f=True, want_d=True):
+    """(uf, ud): the Winograd forms of a 3x3 weight (flat fp32 tensors of 16*Cout*Cin floats)."""
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    uf = _f32((16 * cout * cin,), w_oihw) if want_f else None
+    ud = _f32((16 * cout * cin,), w_oihw) if want_d else None
+    check(lib().unet_pack_wino_weights(_ptr(w_oihw), _ptr(uf), _ptr(ud), cout, cin, _stream()))
+    return uf, ud
+
+
 def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b16=False,
-                w3=None):
+                w3=None, wu=None):
     """Fused layer forward: y = conv(cat(act(s0), act(s1))) + bias and the InstanceNorm
     statistics of y.  Returns (y, st) with st = [mean, rstd, alpha, beta] as [4, N, Cout];
     alpha / beta carry the dropout `mask` [N, Cout] (or None) folded in.
@@ -503,6 +551,10 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
         m3, s3 = u8.c_mean_std()
         check(lib().unet_stem_u8_fwd(_ptr(u8.x), m3, s3, _ptr(w), _ptr(bias), _ptr(y), _ptr(ws),
                                      ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
+    elif wu is not None and not b16 and ksize == 3 and stride == 1:
+        # Winograd F(2x2, 3x3) form (the caller checked conv_wino_supported)
+        check(lib().unet_conv_in_fwd_wino(r0, r1, slope, _ptr(wu), _ptr(bias), _ptr(y), _ptr(ws),
+                                          ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     elif w3 is not None and not b16 and C0 != 3:
         check(lib().unet_conv_in_fwd_bf16x3(r0, r1, slope, _ptr(w), _ptr(w3), _ptr(bias), ksize,
                                             stride, _ptr(y), _ptr(ws), ws.numel(),
@@ -511,9 +563,11 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
         check(fwd(r0, r1, slope, _ptr(w), _ptr(bias), ksize, stride, _ptr(y), _ptr(ws),
                   ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     if t0 is not None:   # the convolution launch alone (its epilogue includes the statistics)
+        alg = 2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout
+        wino = wu is not None and not b16 and ksize == 3 and stride == 1
         _timer.end("conv_stem_fwd" if C0 == 3 else
                    ("conv_igemm_bf16" if b16 else ("conv_igemm_bf16x3" if w3 is not None else "conv_igemm")),
-                   2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout, 1, t0)
+                   alg, 1, t0, executed=alg * 16.0 / 36.0 if wino else None)
     check(fin(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma), _ptr(beta), eps, _ptr(mask),
               _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), N, Ho * Wo, Cout, _stream()))
     return y, st

@@ -210,6 +210,9 @@ class UNet(nn.Module):
         # fp32 operand mode only: keep just the raw conv outputs in HBM (statistics from the
         # conv epilogue, InstanceNorm + LeakyReLU + dropout applied by the consumers on load)
         self.fused_pipeline = True
+        # fp32 fused pipeline: run the stride-1 3x3 layers the Winograd F(2x2,3x3) kernel tiles
+        # on it (2.25x fewer matrix-core FLOPs, a few extra fp32 roundings: csrc/conv_wino.hip)
+        self.winograd = True
         # normalisation constants of forward(..., input_layout="nhwc_u8") (ImageNet, as the
         # reference's dataset: Our_UNet/src/train.py:303-308)
         self.input_mean, self.input_std = ops.IMAGENET_MEAN, ops.IMAGENET_STD
@@ -446,11 +449,24 @@ class _UNetFunction(torch.autograd.Function):
             raise ValueError("matmul_precision must be 'fp32', 'bf16' or 'bf16x3'")
         bf16 = model.matmul_precision      # operand mode handed to every conv call
 
-        # one launch packs every 3x3 weight into the kernels' layouts (persistent buffers)
+        # one launch packs every 3x3 weight into the kernels' layouts (persistent buffers); in
+        # the fp32 mode the stride-1 layers with >= 64 channels also get their Winograd forms
+        # U = G g G^T (forward: the C -> C layers; data gradient: those and the skip halves of
+        # the decoder's first convolutions) - ops.conv_wino_supported decides per call
         convs = [l.conv.weight for l in layers if l.ksize == 3]
+        wino = None
+        if bf16 == "fp32" and model.fused_pipeline and model.winograd:
+            wino = []
+            for l in layers:
+                if l.ksize != 3:
+                    continue
+                co, ci = l.conv.weight.shape[0], l.conv.weight.shape[1]
+                s1 = l.stride == 1 and min(co, ci) >= 64
+                wino.append((s1 and not l.first_of_decoder and co % 64 == 0 and ci % 8 == 0,
+                             s1 and ci % 64 == 0 and co % 8 == 0))
         table = model.__dict__.get("_pack_table")
-        if table is None or not table.matches(convs, bf16 == "bf16x3"):
-            table = model.__dict__["_pack_table"] = ops.PackTable(convs, bf16 == "bf16x3")
+        if table is None or not table.matches(convs, bf16 == "bf16x3", wino):
+            table = model.__dict__["_pack_table"] = ops.PackTable(convs, bf16 == "bf16x3", wino)
         table.run()
         packed = {id(w): k for k, w in enumerate(convs)}
 
@@ -500,12 +516,22 @@ class _UNetFunction(torch.autograd.Function):
                 wk, wd = table.wf[k], table.wd[k]
             w3 = table.wf3[k] if (x3 and l.ksize == 3) else None
             m = mask_of[id(l)]
+            wu = ud = None
+            if l.ksize == 3 and not b16 and not x3:
+                n_, h_, w_, c0_ = s0.shape
+                c1_ = 0 if s1 is None else s1.shape[3]
+                if table.uf[k] is not None and \
+                        ops.conv_wino_supported(n_, h_, w_, c0_, c1_, w.shape[0]):
+                    wu = table.uf[k]
+                if table.ud[k] is not None and c1_ == 0 and \
+                        ops.conv_wino_supported(n_, h_, w_, w.shape[0], 0, c0_):
+                    ud = table.ud[k]
             y, st = ops.conv_in_fwd(s0, s1, slope, wk, l.conv.bias.detach(), l.ksize, l.stride,
                                     l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps, m,
-                                    b16=b16, w3=w3)
+                                    b16=b16, w3=w3, wu=wu)
             if need_grad:
                 saved.append(dict(layer=l, x0=s0, x1=s1, y=y, st=st, mask=m, wd=wd,
-                                  wd3=table.wd3[k] if w3 is not None else None))
+                                  wd3=table.wd3[k] if w3 is not None else None, ud=ud))
             if dbg_fwd is not None:
                 dbg_fwd.append((l.name, y, st))
             return ops.Act(y, st[2], st[3])
@@ -524,8 +550,12 @@ class _UNetFunction(torch.autograd.Function):
                                            l.norm.weight.detach(), l.norm.bias.detach(),
                                            l.norm.eps, m)
                 if need_grad:
+                    # Winograd form of the data gradient into the skip half
+                    n_, h_, w_, c1_ = skip.shape
+                    ud1 = table.ud[k] if (table.ud[k] is not None and ops.conv_wino_supported(
+                        n_, h_, w_, w.shape[0], 0, c1_)) else None
                     saved.append(dict(layer=l, x0=None, x1=skip, y=y, st=st, mask=m,
-                                      wd=table.wd[k], wd3=None, x0_low=low))
+                                      wd=table.wd[k], wd3=None, x0_low=low, ud1=ud1))
                 if dbg_fwd is not None:
                     dbg_fwd.append((l.name, y, st))
                 return ops.Act(y, st[2], st[3])
@@ -689,7 +719,8 @@ class _UNetFunction(torch.autograd.Function):
                 if need_dx1:
                     dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], x1.shape[1],
                                                x1.shape[2], 1, wd3=rec["wd3"],
-                                               bf16="bf16x3" if rec["wd3"] is not None else False)
+                                               bf16="bf16x3" if rec["wd3"] is not None else False,
+                                               ud=rec.get("ud1"))
                 return g_low, dx1
             if want_dw and fused:      # the weight gradient activates its operand on load
                 ops.conv_in_bwd_weight(x0, slope, dy, dw, 0, l.ksize, l.stride, x3=x3_bwd)
@@ -714,7 +745,7 @@ class _UNetFunction(torch.autograd.Function):
             if need_dx:
                 dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
                                            accumulate=dx0_acc, bf16=ctx.bf16, wd3=rec["wd3"],
-                                           nxt=nxt)
+                                           nxt=nxt, ud=rec.get("ud"))
                 if nxt is not None:
                     saved[i - 1]["nxt"] = nxt
             if x1 is not None and need_dx1:
