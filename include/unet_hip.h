@@ -480,6 +480,13 @@ int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src* s1, float 
                           const float* uf, const float* bias, float* y, void* workspace,
                           size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
                           unet_stream_t stream);
+/* unet_conv_up_in_fwd on the Winograd kernel (the bilinear gather of the low-resolution source
+ * runs inside its loader): low = [N][H/2][W/2][C0], skip = [N][H][W][C1]. */
+int unet_conv_up_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
+int unet_conv_up_in_fwd_wino(const unet_act_src* low, const unet_act_src* skip, float slope,
+                             const float* uf, const float* bias, float* y, void* workspace,
+                             size_t workspace_bytes, int* stats_px_out, int N, int H, int W,
+                             int Cout, unet_stream_t stream);
 /* unet_conv3x3_bwd_data_bs (stride 1, accumulate 0) on the Winograd kernel; ud covers the whole
  * weight [Cout][Cin_total], ci_offset % 64 == 0; bs may be NULL. */
 int unet_conv3x3_bwd_data_bs_wino(const float* dy, const float* ud, int Cin_total, int ci_offset,

@@ -143,7 +143,7 @@ WINO_CASES = [  # (N, H, W, C0, C1, Cout, act0, act1): shapes the Winograd kerne
     (4, 128, 128, 64, 0, 64, True, False),     # one column tile, 8 chunks
     (2, 128, 128, 128, 0, 128, True, False),   # two column tiles
     (4, 64, 64, 256, 0, 256, True, False),     # the 256-channel layer shape
-    (2, 128, 256, 32, 32, 64, False, True),    # two sources (virtual concat), plain src0, H != W
+    (2, 128, 256, 32, 32, 64, True, True),     # two sources (virtual concat), H != W
     (8, 32, 32, 64, 0, 512, True, False),      # image = one tile column
 ]
 
@@ -598,6 +598,36 @@ def test_conv_up_in_fwd(ua, case):
     y2, _ = ua.ops.conv_in_fwd(up, s_skip, SLOPE, wf, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV),
                                1e-5, None)
     check(y, y2, 2e-6, "fused vs materialised up-sampling")
+
+
+@pytest.mark.parametrize("case", [(2, 128, 128, 128, 64, 128), (8, 32, 32, 64, 32, 512),
+                                  (1, 256, 256, 64, 32, 64), (4, 64, 64, 512, 256, 256)])
+def test_conv_up_in_fwd_winograd(ua, case):
+    """The decoder stage's first convolution on the Winograd kernel (bilinear gather of the
+    low-resolution source inside its loader) against F.interpolate + torch.cat + F.conv2d and
+    against the direct up-sampling-loader kernel; image borders on every side."""
+    N, H, W, C0, C1, Cout = case
+    assert ua.ops.conv_up_wino_supported(N, H, W, C0, C1, Cout)
+    low = rnd(N, C0, H // 2, W // 2, seed=1)
+    skip = rnd(N, C1, H, W, seed=2)
+    c0, c1 = coeffs(N, C0, 10), coeffs(N, C1, 20)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=(2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma, beta = rnd(Cout, seed=5) * 0.2 + 1.0, rnd(Cout, seed=6) * 0.2
+    parts = [F.interpolate(act_ref(low, *c0), scale_factor=2, mode="bilinear", align_corners=False),
+             act_ref(skip, *c1)]
+    y_ref = F.conv2d(torch.cat(parts, 1), w.double(), b.double(), padding=1)
+    wf, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    uf, _ = ua.ops.pack_wino_weights(w.to(DEV), want_d=False)
+    s_low, s_skip = make_src(ua, low, c0), make_src(ua, skip, c1)
+    args = (s_low, s_skip, SLOPE, wf, b.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, None)
+    y, st = ua.ops.conv_up_in_fwd(*args, wu=uf)
+    check(from_nhwc(y), y_ref, 2e-5, "y (Winograd, up-sampling loader)")
+    assert (st[0].cpu().double() - y_ref.mean(dim=(2, 3))).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), 1.0 / torch.sqrt(y_ref.var(dim=(2, 3), unbiased=False) + 1e-5), 5e-5, "rstd")
+    y2, st2 = ua.ops.conv_up_in_fwd(*args)
+    check(y, y2, 2e-5, "Winograd vs direct up-sampling loader")
+    check(st[2], st2[2], 5e-5, "alpha")
 
 
 # --------------------------------------------------------------------------- reductions from the producer

@@ -9,6 +9,8 @@ ops = ua.ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 N = 8
 LAYERS = [("enc1.3", 64, 256), ("enc2.4", 128, 128), ("enc3.4", 256, 64), ("enc4.4", 512, 32)]
+UP = [("dec0.0", 512, 512, 512, 32), ("dec1.0", 512, 256, 256, 64), ("dec2.0", 256, 128, 128, 128),
+      ("dec3.0", 128, 64, 64, 256)]
 
 
 def timeit(fn):
@@ -43,3 +45,21 @@ for name, C, H in LAYERS:
     t_dw = timeit(lambda: dg(ud))
     print(f"{name:8s} {fl * 1e-9:7.1f} | {t_fd * 1e6:9.1f} {fl / t_fd * 1e-12:6.1f} | {t_fw * 1e6:9.1f} "
           f"{fl / t_fw * 1e-12:6.1f} | {t_dd * 1e6:9.1f} | {t_dw * 1e6:9.1f} {fl / t_dw * 1e-12:6.1f}", flush=True)
+
+print("decoder first convolutions (up-sampling loader): direct us / TF/s | Winograd us / alg TF/s")
+for name, C0, C1, Cout, H in UP:
+    low = torch.randn(N, H // 2, H // 2, C0, device="cuda")
+    skip = torch.randn(N, H, H, C1, device="cuda")
+    a0, b0 = torch.rand(N, C0, device="cuda") + 0.5, torch.randn(N, C0, device="cuda")
+    a1, b1 = torch.rand(N, C1, device="cuda") + 0.5, torch.randn(N, C1, device="cuda")
+    w = torch.randn(Cout, C0 + C1, 3, 3, device="cuda") * (2.0 / (9 * (C0 + C1))) ** 0.5
+    b = torch.zeros(Cout, device="cuda")
+    g1 = torch.ones(Cout, device="cuda"); bb = torch.zeros(Cout, device="cuda")
+    wf, _ = ops.pack_conv3x3_weights(w, want_wd=False)
+    uf, _ = ops.pack_wino_weights(w, want_d=False)
+    sl, ss = ops.Act(low, a0, b0), ops.Act(skip, a1, b1)
+    fl = 2.0 * N * H * H * 9 * (C0 + C1) * Cout
+    t_d = timeit(lambda: ops.conv_up_in_fwd(sl, ss, 0.01, wf, b, g1, bb, 1e-5, None))
+    t_w = timeit(lambda: ops.conv_up_in_fwd(sl, ss, 0.01, wf, b, g1, bb, 1e-5, None, wu=uf))
+    print(f"{name:8s} {fl * 1e-9:7.1f} | {t_d * 1e6:9.1f} {fl / t_d * 1e-12:6.1f} | {t_w * 1e6:9.1f} "
+          f"{fl / t_w * 1e-12:6.1f}", flush=True)

@@ -68,7 +68,12 @@ struct WinoParams {
   const float* wu;     // packed U: [n tile of 64][K chunk of 8][xi 16][n 64][k 8 swizzled]
 };
 
-template <bool ACT, bool STATS, bool BSTATS>
+// UP: source 0 is the LOW-resolution tensor [N][H/2][W/2][C0] of a decoder stage's first
+// convolution, conv3x3(cat(upsample2x(act(low)), act(skip))): its patch pixels are gathered
+// bilinearly (align_corners=False at exactly 2x: taps {0.75, 0.25}, edge clamped; activation on
+// the four taps, PyTorch's blend order, zero padding after the blend - as conv_patch_up_kernel)
+// on their way into the raw patch, so the up-sampled tensor never exists.
+template <bool ACT, bool STATS, bool BSTATS, bool UP = false>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) {
   const IgemmParams& p = wp.g;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
 
   // ---- raw patch slots: 340 pixels x 2 channel halves; thread -> slots tid, tid + 512 ----
   const int half = tid & 1;
-  int g_lin[2], r_lds[2];
+  int g_lin[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = tid + 512 * i;
@@ -104,82 +109,127 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
     const bool ok = slot < 2 * WN_PPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     g_lin[i] = ok ? (n * H + iy) * W + ix : -1;
-    // slots past the patch write into the unused tail of the channel planes (no branch)
-    r_lds[i] = (half * 4) * WN_RP + (slot < 2 * WN_PPIX ? pix : WN_PPIX + (tid & 31));
+  }
+  // UP: per slot the clamped low-resolution pixel of tap (0,0) and four flag bits: step to the
+  // right / lower neighbour (0 where clamped) and the parity of the patch column / row
+  int l_lin[2], l_meta[2];
+  const int lw = W >> 1;
+  if (UP) {
+    const int h = H >> 1, w = W >> 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int slot = tid + 512 * i;
+      const int pix = slot < 2 * WN_PPIX ? slot >> 1 : 0;
+      const int prow = pix / WN_PW, pcol = pix - prow * WN_PW;
+      int gy0 = (y0 >> 1) - 1 + (prow >> 1), gx0 = (x0 >> 1) - 1 + (pcol >> 1);
+      int gy1 = gy0 + 1, gx1 = gx0 + 1;
+      gy0 = gy0 < 0 ? 0 : (gy0 > h - 1 ? h - 1 : gy0);
+      gy1 = gy1 < 0 ? 0 : (gy1 > h - 1 ? h - 1 : gy1);
+      gx0 = gx0 < 0 ? 0 : (gx0 > w - 1 ? w - 1 : gx0);
+      gx1 = gx1 < 0 ? 0 : (gx1 > w - 1 ? w - 1 : gx1);
+      l_lin[i] = (n * h + gy0) * w + gx0;
+      l_meta[i] = (gx1 - gx0) | ((gy1 - gy0) << 1) | ((pcol & 1) << 2) | ((prow & 1) << 3);
+    }
   }
   f32x4 pr[2];
+  f32x4 pt[UP ? 2 : 1][3];   // UP: the other three taps of a slot
+  bool pup = false;           // the chunk in the registers is a low-resolution (gathered) one
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
-  bool chas = false;
-  auto load_raw = [&](int chunk) {     // G: global -> registers (+ this chunk's coefficients)
+  // G: global -> registers, one slot per call.  Slot 1's call also fetches the chunk's coefficients
+  // and source kind: it runs AFTER both slots of the previous chunk were stored
+  auto load_raw = [&](int chunk, auto ic) {
+    constexpr int i = decltype(ic)::value;
     const int c = chunk * WN_KC;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int Cs = first ? p.C0 : p.C1;
     const int cc = (first ? c : c - p.C0) + half * 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    if (UP && first) {   // uniform
+      if (i == 1) pup = true;
+      const unsigned o = (unsigned)(l_lin[i] * Cs + cc);
+      const unsigned dx = (l_meta[i] & 1) ? (unsigned)Cs : 0u;
+      const unsigned dy = (l_meta[i] & 2) ? (unsigned)(lw * Cs) : 0u;
+      pr[i] = buf_ld4<float>(rs, o, 0u);
+      if constexpr (UP) {
+        pt[i][0] = buf_ld4<float>(rs, o + dx, 0u);
+        pt[i][1] = buf_ld4<float>(rs, o + dy, 0u);
+        pt[i][2] = buf_ld4<float>(rs, o + dy + dx, 0u);
+      }
+    } else {
+      if (UP && i == 1) pup = false;
       pr[i] = buf_ld4<float>(rs, (unsigned)(g_lin[i] * Cs + cc), g_lin[i] < 0 ? 0x80000000u : 0u);
-    if (ACT) {   // branch-free: a plain source reads (and discards) its own first floats
+    }
+    if (ACT && i == 1) {   // (ACT: every source is an activated tensor - the entry points check)
       const float* al = first ? p.act0_alpha : p.act1_alpha;
       const float* be = first ? p.act0_beta : p.act1_beta;
-      chas = al != nullptr;
-      const float* dummy = first ? p.src0 : p.src1;
-      // (the loaded coefficients are only looked at when the patch is stored, an iteration later)
-      ca = *reinterpret_cast<const f32x4*>((chas ? al : dummy) + (size_t)n * Cs + cc);
-      cb = *reinterpret_cast<const f32x4*>((chas ? be : dummy) + (size_t)n * Cs + cc);
+      // the loaded coefficients are only looked at when the patch is stored, an iteration later
+      ca = *reinterpret_cast<const f32x4*>(al + (size_t)n * Cs + cc);
+      cb = *reinterpret_cast<const f32x4*>(be + (size_t)n * Cs + cc);
     }
   };
   auto store_raw = [&](auto ic) {      // R: activate, registers -> LDS raw patch (zero padding)
     constexpr int i = decltype(ic)::value;
     f32x4 v = pr[i];
     if (ACT) {
-      f32x4 a1, b1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a1[k] = chas ? ca[k] : 1.f;
-        b1[k] = chas ? cb[k] : 0.f;
+      const f32x4 a1 = ca, b1 = cb;
+      const float sl = p.slope;
+      bool done = false;
+      if constexpr (UP) {
+        if (pup) {   // uniform: activate the four taps, blend, then the zero padding
+          // odd patch row = even image row 2k: taps (k-1, k) weigh (0.25, 0.75); even patch
+          // row = odd image row: (0.75, 0.25); columns alike (y0, x0 are even)
+          const f32x4 p00 = act4f(v, a1, b1, sl, 1.f), p01 = act4f(pt[i][0], a1, b1, sl, 1.f);
+          const f32x4 p10 = act4f(pt[i][1], a1, b1, sl, 1.f);
+          const f32x4 p11 = act4f(pt[i][2], a1, b1, sl, 1.f);
+          const float wx1 = (l_meta[i] & 4) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+          const float wy1 = (l_meta[i] & 8) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+          v = ((p00 * wx0 + p01 * wx1) * wy0 + (p10 * wx0 + p11 * wx1) * wy1) *
+              (g_lin[i] >= 0 ? 1.f : 0.f);
+          done = true;
+        }
       }
-      v = act4(v, a1, b1, chas ? p.slope : 1.f, g_lin[i] >= 0);
+      if (!done) v = act4(v, a1, b1, sl, g_lin[i] >= 0);
     }
-    float* d = Rs + r_lds[i];
+    // (recomputed, not kept: slots past the patch write into the unused tail of the channel
+    // planes, so the store needs no branch)
+    const int rpix = i == 0 ? (tid >> 1)
+                            : (tid < 2 * WN_PPIX - 512 ? 256 + (tid >> 1) : WN_PPIX + (tid & 31));
+    float* d = Rs + (half * 4) * WN_RP + rpix;
     d[0] = v[0]; d[WN_RP] = v[1]; d[2 * WN_RP] = v[2]; d[3 * WN_RP] = v[3];
   };
   // ---- input transform: thread -> (tile = tid >> 3, channel = tid & 7) ----
   const int t_tile = tid >> 3, t_ch = tid & 7;
   const int t_src = t_ch * WN_RP + (2 * (t_tile >> 4)) * WN_PW + 2 * (t_tile & 15);
   const int t_dst = t_tile * 8 + wn_swz(t_tile, t_ch);
-  // T: V = B^T (d B) of this thread's 4 x 4 window, in eight short pieces that ride behind the
-  // MFMAs of eight xi: the column pass per input row (two 8-byte reads), then the row pass per
-  // output row with its four LDS writes
-  float tc[4][4];
-  auto t_cols = [&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    const f32x2v lo = *reinterpret_cast<const f32x2v*>(Rs + t_src + i * WN_PW);
-    const f32x2v hi = *reinterpret_cast<const f32x2v*>(Rs + t_src + i * WN_PW + 2);
-    tc[i][0] = lo[0] - hi[0];
-    tc[i][1] = lo[1] + hi[0];
-    tc[i][2] = hi[0] - lo[1];
-    tc[i][3] = lo[1] - hi[1];
-  };
-  auto t_rows = [&](auto ac, float* Vb) {
+  // T: V = (B^T d) B of this thread's 4 x 4 window, one OUTPUT row per piece: the two input rows
+  // it combines are read (8-byte reads), combined, put through the column pass and written, so
+  // nothing of the transform stays in registers between pieces (each input row is read twice)
+  auto t_row = [&](auto ac, float* Vb) {
     constexpr int a = decltype(ac)::value;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = a == 0 ? tc[0][j] - tc[2][j]
-                    : a == 1 ? tc[1][j] + tc[2][j]
-                    : a == 2 ? tc[2][j] - tc[1][j]
-                             : tc[1][j] - tc[3][j];
-      Vb[(4 * a + j) * 512 + t_dst] = v;
-    }
+    constexpr int r0 = a == 0 ? 0 : (a == 1 ? 1 : (a == 2 ? 2 : 1));   // first row
+    constexpr int r1 = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));   // second row
+    const f32x2v lo0 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r0 * WN_PW);
+    const f32x2v hi0 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r0 * WN_PW + 2);
+    const f32x2v lo1 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r1 * WN_PW);
+    const f32x2v hi1 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r1 * WN_PW + 2);
+    // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    const f32x2v lo = a == 1 ? lo0 + lo1 : lo0 - lo1;
+    const f32x2v hi = a == 1 ? hi0 + hi1 : hi0 - hi1;
+    Vb[(4 * a + 0) * 512 + t_dst] = lo[0] - hi[0];
+    Vb[(4 * a + 1) * 512 + t_dst] = lo[1] + hi[0];
+    Vb[(4 * a + 2) * 512 + t_dst] = hi[0] - lo[1];
+    Vb[(4 * a + 3) * 512 + t_dst] = lo[1] - hi[1];
   };
   // ---- U chunk: 32 KB contiguous in global, by DMA (8 waves x 4 x 1 KB) ----
-  const float* ubase = wp.wu + (size_t)((p.n_off / WN_BN + tn) * chunks) * WN_BUF + lane * 4;
+  // (uniform base + 32-bit lane offset: no loop-invariant 64-bit address register per lane)
+  const float* ubase = wp.wu + (size_t)((p.n_off / WN_BN + tn) * chunks) * WN_BUF;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave) * 1024;
   auto dma_u = [&](int chunk, float* Ub, auto ic) {   // piece i of this wave's four
     constexpr int i = decltype(ic)::value;
-    const float* src = ubase + (size_t)chunk * WN_BUF + wave * 1024;
+    const float* src = ubase + (size_t)chunk * WN_BUF + uwave;
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + i * 256),
-        (__attribute__((address_space(3))) void*)(Ub + wave * 1024 + i * 256), 16, 0, 0);
+        (const __attribute__((address_space(1))) void*)(src + i * 256 + lane * 4),
+        (__attribute__((address_space(3))) void*)(Ub + uwave + i * 256), 16, 0, 0);
   };
 
   // ---- MFMA fragments: wave -> tiles 16 tg .. +15, output channels 32 nh .. +31 ----
@@ -193,30 +243,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   for (int x = 0; x < 16; ++x)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x2v fa[2], fb0[2], fb1[2];     // fragments of xi, one xi ahead of its MFMAs
-  auto frag = [&](int slot, const float* Vb, const float* Ub, int x) {
-    fa[slot] = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
-    fb0[slot] = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off);
-    fb1[slot] = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off + 128);
+  f32x2v fa, fb0, fb1;     // fragments of one xi; the next xi's are read right behind its MFMAs
+  auto frag = [&](const float* Vb, const float* Ub, int x) {
+    fa = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
+    fb0 = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off);
+    fb1 = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off + 128);
   };
   auto mm = [&](auto xc) {
     constexpr int x = decltype(xc)::value;
-    constexpr int sl = x & 1;
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb0[sl][0], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb1[sl][0], acc[x][1], 0, 0, 0);
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb0[sl][1], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb1[sl][1], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb0[0], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb1[0], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb0[1], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb1[1], acc[x][1], 0, 0, 0);
   };
 
   // ---- prologue: chunk 0 staged, chunk 1 in flight ----
-  load_raw(0);
+  load_raw(0, wn_ic<0>{});
+  load_raw(0, wn_ic<1>{});
   wn_for<0, 4>([&](auto ic) { dma_u(0, Us, ic); });
   store_raw(wn_ic<0>{});
   store_raw(wn_ic<1>{});
-  load_raw(chunks > 1 ? 1 : 0);
+  load_raw(chunks > 1 ? 1 : 0, wn_ic<0>{});
+  load_raw(chunks > 1 ? 1 : 0, wn_ic<1>{});
   __syncthreads();
-  wn_for<0, 4>(t_cols);
-  wn_for<0, 4>([&](auto ac) { t_rows(ac, Vs); });
+  wn_for<0, 4>([&](auto ac) { t_row(ac, Vs); });
   for (int c = 0; c < chunks; ++c) {
     const int buf = c & 1;
     const float* Vb = Vs + buf * WN_BUF;
@@ -226,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     // Branch-free body (the last iterations re-stage the final chunk into the idle stage).  One
     // stage per xi: its 4 MFMAs, the fragment reads of the next xi, and one piece of the staging
     // work for chunk c + 1 (first half: raw patch to LDS, next loads, U by DMA; second half:
-    // the input transform), fenced so nothing bunches up in front of a barrier.
+    // the input transform, one output row per xi), fenced so nothing bunches up before a barrier.
     const int c1 = c + 1 < chunks ? c + 1 : chunks - 1;
     const int c2 = c + 2 < chunks ? c + 2 : chunks - 1;
     // every DMA of this wave has landed; every wave is done with stage buf ^ 1 and with Rs.
@@ -235,15 +285,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    frag(0, Vb, Ub, 0);
+    frag(Vb, Ub, 0);
     wn_for<0, 8>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
-      frag((x + 1) & 1, Vb, Ub, x + 1);
       mm(xc);
+      frag(Vb, Ub, x + 1);
       if constexpr (x == 0) store_raw(wn_ic<0>{});      // chunk c + 1 (loaded an iteration ago)
-      if constexpr (x == 1) store_raw(wn_ic<1>{});
-      if constexpr (x == 2) load_raw(c2);
-      if constexpr (x >= 3 && x < 7) dma_u(c1, Un, wn_ic<x - 3>{});
+      if constexpr (x == 1) load_raw(c2, wn_ic<0>{});
+      if constexpr (x == 2) store_raw(wn_ic<1>{});
+      if constexpr (x == 3) load_raw(c2, wn_ic<1>{});
+      if constexpr (x >= 4) dma_u(c1, Un, wn_ic<x - 4>{});
       __builtin_amdgcn_sched_barrier(0);
     });
     // the raw patch of chunk c + 1 is complete (LDS writes only: no wait for the loads in flight)
@@ -252,21 +303,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     asm volatile("" ::: "memory");
     wn_for<8, 16>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
-      if constexpr (x + 1 < 16) frag((x + 1) & 1, Vb, Ub, x + 1);
       mm(xc);
-      if constexpr (x < 12) t_cols(wn_ic<x - 8>{});
-      else t_rows(wn_ic<x - 12>{}, Vn);
+      if constexpr (x + 1 < 16) frag(Vb, Ub, x + 1);
+      if constexpr (x < 12) t_row(wn_ic<x - 8>{}, Vn);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
 
   // ---- epilogue: Y = A^T M A per (tile, channel), register-local ----
-  // lane holds tiles 16 tg + 4 (lane >> 4) + r (r = 0..3) = tile row tg, tile column
-  // 4 (lane >> 4) + r, of channels 32 nh + 16 b + (lane & 15)
+  // (lane geometry re-derived here - the empty asm hides it from common-subexpression
+  // elimination - so that nothing epilogue-only stays in a register through the K loop)
+  int etid = threadIdx.x;
+  asm volatile("" : "+v"(etid));
+  const int fm_e = etid & 15, fk_e = (etid >> 4) & 3, tg_e = (etid >> 6) & 3, nh_e = etid >> 8;
+  // lane holds tiles 16 tg_e + 4 (lane >> 4) + r (r = 0..3) = tile row tg_e, tile column
+  // 4 (lane >> 4) + r, of channels 32 nh_e + 16 b + (lane & 15)
   float yv[2][4][4];   // [block][r][2 dy + dx]
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const int col = n0 + 32 * nh + 16 * b + fm;
+    const int col = n0 + 32 * nh_e + 16 * b + fm_e;
     const float bv = p.bias ? p.bias[p.n_off + col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -283,10 +338,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       }
     }
   }
-  const int oy = y0 + 2 * tg, ox = x0 + 2 * (4 * fk);
+  const int oy = y0 + 2 * tg_e, ox = x0 + 2 * (4 * fk_e);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const int col = n0 + 32 * nh + 16 * b + fm;
+    const int col = n0 + 32 * nh_e + 16 * b + fm_e;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -317,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       // lanes l, l ^ 16, l ^ 32 hold the other tile columns of the same channel
       wf_merge_eq(mean, m2, __shfl_xor(mean, 16, 64), __shfl_xor(m2, 16, 64), 16.f);
       wf_merge_eq(mean, m2, __shfl_xor(mean, 32, 64), __shfl_xor(m2, 32, 64), 32.f);
-      if (fk == 0) red[tg * WN_BN + 32 * nh + 16 * b + fm] = float2{mean, m2};
+      if (fk_e == 0) red[tg_e * WN_BN + 32 * nh_e + 16 * b + fm_e] = float2{mean, m2};
     }
     float2 out;
     if (block_col_stats<WN_BN, 4>(red, 0, 0, false, float2{0.f, 0.f}, 64.f, out))
@@ -327,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int col = n0 + 32 * nh + 16 * b + fm;
+      const int col = n0 + 32 * nh_e + 16 * b + fm_e;
       const BwdCoef cf = bwd_coef(p, n, col);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -343,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
         }
       s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
       s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (fk == 0) red[tg * WN_BN + 32 * nh + 16 * b + fm] = float2{s1, s2};
+      if (fk_e == 0) red[tg_e * WN_BN + 32 * nh_e + 16 * b + fm_e] = float2{s1, s2};
     }
     float2 out;
     if (block_col_sums<WN_BN, 4>(red, out))
@@ -395,9 +450,9 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
   }
 }
 
-template <bool ACT, bool STATS, bool BSTATS>
+template <bool ACT, bool STATS, bool BSTATS, bool UP = false>
 int launch_wino(const WinoParams& wp, hipStream_t stream) {
-  auto kern = conv_wino_kernel<ACT, STATS, BSTATS>;
+  auto kern = conv_wino_kernel<ACT, STATS, BSTATS, UP>;
   UNET_SET_DYN_LDS(kern, WN_LDS);
   const IgemmParams& p = wp.g;
   const long long blocks =
@@ -410,13 +465,14 @@ int launch_wino(const WinoParams& wp, hipStream_t stream) {
 // shapes the kernel tiles: image as 8 x 32 pixels, K in chunks of 8, 64-wide column tiles, every
 // tensor inside one 2 GiB buffer descriptor, and enough workgroups / K depth to pay for the
 // per-workgroup prologue (one workgroup per CU: nothing else overlaps it)
-bool wino_shape_ok(int N, int H, int W, int K0, int K1, int ncols, int n_off) {
+bool wino_shape_ok(int N, int H, int W, int K0, int K1, int ncols, int n_off, bool up = false) {
   const int K = K0 + K1;
   if (H % WN_TH || W % WN_TW || K0 % WN_KC || K1 % WN_KC || ncols % WN_BN || n_off % WN_BN)
     return false;
-  if (K < 64) return false;
+  if (K < 64 || (up && K0 < WN_KC)) return false;
   const long long px = (long long)N * H * W;
-  if (px * (K0 > K1 ? K0 : K1) * 4 >= (1LL << 31) || px * ncols * 4 >= (1LL << 31)) return false;
+  const long long b0 = (up ? px / 4 : px) * K0 * 4, b1 = px * K1 * 4;
+  if (b0 >= (1LL << 31) || b1 >= (1LL << 31) || px * ncols * 4 >= (1LL << 31)) return false;
   return px / (WN_TH * WN_TW) * (ncols / WN_BN) >= 256;
 }
 
@@ -427,6 +483,10 @@ using namespace unet_conv;
 
 extern "C" int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout) {
   return wino_shape_ok(N, H, W, C0, C1, Cout, 0) ? 1 : 0;
+}
+
+extern "C" int unet_conv_up_wino_supported(int N, int H, int W, int C0, int C1, int Cout) {
+  return wino_shape_ok(N, H, W, C0, C1, Cout, 0, true) ? 1 : 0;
 }
 
 extern "C" size_t unet_wino_weight_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin; }
@@ -450,18 +510,19 @@ extern "C" int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud,
 // Fused layer forward (as unet_conv_in_fwd with ksize 3, stride 1) on the Winograd kernel;
 // wu = the forward form of unet_pack_wino_weights.  The shape must satisfy
 // unet_conv_wino_supported.  Workspace / stats_px_out as unet_conv_in_fwd.
-extern "C" int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src* s1, float slope,
-                                     const float* wu, const float* bias, float* y, void* workspace,
-                                     size_t workspace_bytes, int* stats_px_out, int N, int H,
-                                     int W, int Cout, unet_stream_t stream) {
+static int conv_in_fwd_wino_impl(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                                 const float* wu, const float* bias, float* y, void* workspace,
+                                 size_t workspace_bytes, int* stats_px_out, int N, int H, int W,
+                                 int Cout, hipStream_t stream, bool up) {
   UNET_REQUIRE(s0 && s0->x && wu && y && stats_px_out, "conv_in_fwd_wino: null pointer");
   const int C0 = s0->C, C1 = s1 ? s1->C : 0;
   UNET_REQUIRE(C1 == 0 || s1->x, "conv_in_fwd_wino: second source is null with C1=%d", C1);
-  UNET_REQUIRE((!s0->alpha || s0->beta) && (!s1 || !s1->alpha || s1->beta),
-               "conv_in_fwd_wino: alpha without beta");
-  UNET_REQUIRE(wino_shape_ok(N, H, W, C0, C1, Cout, 0),
+  UNET_REQUIRE(s0->alpha && s0->beta && (!s1 || (s1->alpha && s1->beta)),
+               "conv_in_fwd_wino: the Winograd loader takes activated sources (alpha / beta set)");
+  UNET_REQUIRE(wino_shape_ok(N, H, W, C0, C1, Cout, 0, up),
                "conv_in_fwd_wino: shape N=%d %dx%d C=(%d,%d)->%d not tiled by the Winograd kernel",
                N, H, W, C0, C1, Cout);
+  UNET_REQUIRE(!up || (H % 2 == 0 && W % 2 == 0 && C1 > 0), "conv_up_in_fwd_wino: bad shape");
   const int tiles = H * W / 256;
   const size_t need = (size_t)N * tiles * Cout * sizeof(float2);
   if (workspace && workspace_bytes < need) {
@@ -471,11 +532,11 @@ extern "C" int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src*
   WinoParams wp{};
   IgemmParams& p = wp.g;
   p.src0 = s0->x; p.src1 = s1 ? s1->x : nullptr; p.C0 = C0; p.C1 = C1;
-  p.act0_alpha = s0->alpha; p.act0_beta = s0->alpha ? s0->beta : nullptr;
-  p.act1_alpha = (s1 && s1->alpha) ? s1->alpha : nullptr;
-  p.act1_beta = (s1 && s1->alpha) ? s1->beta : nullptr;
+  p.act0_alpha = s0->alpha; p.act0_beta = s0->beta;
+  p.act1_alpha = s1 ? s1->alpha : nullptr;
+  p.act1_beta = s1 ? s1->beta : nullptr;
   p.slope = slope;
-  p.src0_bytes = (unsigned)((long long)N * H * W * C0 * 4);
+  p.src0_bytes = (unsigned)((long long)N * (up ? H / 2 : H) * (up ? W / 2 : W) * C0 * 4);
   p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 4);
   p.bias = bias; p.n_off = 0;
   p.out = y; p.ldo = Cout; p.N = N; p.Hin = p.Hl = p.Hout = H; p.Win = p.Wl = p.Wout = W;
@@ -484,7 +545,26 @@ extern "C" int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src*
   p.stats_tiles = tiles;
   wp.wu = wu;
   *stats_px_out = workspace ? 256 : 0;
-  return launch_wino<true, true, false>(wp, (hipStream_t)stream);
+  if (up) return launch_wino<true, true, false, true>(wp, stream);
+  return launch_wino<true, true, false>(wp, stream);
+}
+
+extern "C" int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                                     const float* wu, const float* bias, float* y, void* workspace,
+                                     size_t workspace_bytes, int* stats_px_out, int N, int H,
+                                     int W, int Cout, unet_stream_t stream) {
+  return conv_in_fwd_wino_impl(s0, s1, slope, wu, bias, y, workspace, workspace_bytes,
+                               stats_px_out, N, H, W, Cout, (hipStream_t)stream, false);
+}
+
+// unet_conv_up_in_fwd on the Winograd kernel: low = [N][H/2][W/2][C0], skip = [N][H][W][C1].
+extern "C" int unet_conv_up_in_fwd_wino(const unet_act_src* low, const unet_act_src* skip,
+                                        float slope, const float* wu, const float* bias, float* y,
+                                        void* workspace, size_t workspace_bytes,
+                                        int* stats_px_out, int N, int H, int W, int Cout,
+                                        unet_stream_t stream) {
+  return conv_in_fwd_wino_impl(low, skip, slope, wu, bias, y, workspace, workspace_bytes,
+                               stats_px_out, N, H, W, Cout, (hipStream_t)stream, true);
 }
 
 // Data gradient (as unet_conv3x3_bwd_data_bs with stride 1, accumulate 0) on the Winograd

@@ -578,9 +578,15 @@ def conv_up_in_fwd_supported(low, skip, Cout):
     return bool(lib().unet_conv_up_in_fwd_supported(N, H, W, low.shape[3], C1, Cout))
 
 
-def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask):
+def conv_up_wino_supported(N, H, W, C0, C1, Cout):
+    """Winograd form of conv_up_in_fwd for output [N,H,W,Cout], low-res source C0, skip C1?"""
+    return bool(lib().unet_conv_up_wino_supported(N, H, W, C0, C1, Cout))
+
+
+def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask, wu=None):
     """y = conv3x3(cat(upsample2x(act(low)), act(skip))) + bias with the up-sampling in the
-    loader, plus the InstanceNorm statistics of y (as conv_in_fwd)."""
+    loader, plus the InstanceNorm statistics of y (as conv_in_fwd).  wu: the Winograd forward
+    form of the weight (shape checked by the caller with conv_up_wino_supported)."""
     low, rl = _act(low)
     skip, rs = _act(skip)
     N, H, W, C1 = skip.shape
@@ -593,10 +599,16 @@ def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask):
     ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1), skip.x)
     px = ctypes.c_int(0)
     t0 = _timer.begin("conv") if _timer is not None else None
-    check(lib().unet_conv_up_in_fwd(rl, rs, slope, _ptr(wf), _ptr(bias), _ptr(y), _ptr(ws),
-                                    ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
+    if wu is not None:
+        check(lib().unet_conv_up_in_fwd_wino(rl, rs, slope, _ptr(wu), _ptr(bias), _ptr(y),
+                                             _ptr(ws), ws.numel(), ctypes.byref(px), N, H, W, Cout,
+                                             _stream()))
+    else:
+        check(lib().unet_conv_up_in_fwd(rl, rs, slope, _ptr(wf), _ptr(bias), _ptr(y), _ptr(ws),
+                                        ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     if t0 is not None:
-        _timer.end("conv_igemm", 2.0 * N * H * W * 9 * (C0 + C1) * Cout, 1, t0)
+        alg = 2.0 * N * H * W * 9 * (C0 + C1) * Cout
+        _timer.end("conv_igemm", alg, 1, t0, executed=alg * 16.0 / 36.0 if wu is not None else None)
     check(lib().unet_conv_in_stats_finalize(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma),
                                             _ptr(beta), eps, _ptr(mask), _ptr(st[0]), _ptr(st[1]),
                                             _ptr(st[2]), _ptr(st[3]), N, H * W, Cout, _stream()))

@@ -451,8 +451,9 @@ class _UNetFunction(torch.autograd.Function):
 
         # one launch packs every 3x3 weight into the kernels' layouts (persistent buffers); in
         # the fp32 mode the stride-1 layers with >= 64 channels also get their Winograd forms
-        # U = G g G^T (forward: the C -> C layers; data gradient: those and the skip halves of
-        # the decoder's first convolutions) - ops.conv_wino_supported decides per call
+        # U = G g G^T (forward, incl. the up-sampling loader of the decoder's first convolutions;
+        # data gradient: the C -> C layers and the skip halves of the decoder's first
+        # convolutions) - ops.conv_wino_supported / conv_up_wino_supported decide per call
         convs = [l.conv.weight for l in layers if l.ksize == 3]
         wino = None
         if bf16 == "fp32" and model.fused_pipeline and model.winograd:
@@ -462,7 +463,7 @@ class _UNetFunction(torch.autograd.Function):
                     continue
                 co, ci = l.conv.weight.shape[0], l.conv.weight.shape[1]
                 s1 = l.stride == 1 and min(co, ci) >= 64
-                wino.append((s1 and not l.first_of_decoder and co % 64 == 0 and ci % 8 == 0,
+                wino.append((s1 and co % 64 == 0 and ci % 8 == 0,
                              s1 and ci % 64 == 0 and co % 8 == 0))
         table = model.__dict__.get("_pack_table")
         if table is None or not table.matches(convs, bf16 == "bf16x3", wino):
@@ -520,7 +521,8 @@ class _UNetFunction(torch.autograd.Function):
             if l.ksize == 3 and not b16 and not x3:
                 n_, h_, w_, c0_ = s0.shape
                 c1_ = 0 if s1 is None else s1.shape[3]
-                if table.uf[k] is not None and \
+                if table.uf[k] is not None and s0.alpha is not None and \
+                        (s1 is None or s1.alpha is not None) and \
                         ops.conv_wino_supported(n_, h_, w_, c0_, c1_, w.shape[0]):
                     wu = table.uf[k]
                 if table.ud[k] is not None and c1_ == 0 and \
@@ -546,9 +548,13 @@ class _UNetFunction(torch.autograd.Function):
                 # the bilinear gather runs inside the conv's patch loader: no up-sampled tensor
                 k = packed[id(w)]
                 m = mask_of[id(l)]
+                n_, h_, w_, c1_ = skip.shape
+                wu = table.uf[k] if (table.uf[k] is not None and low.alpha is not None and
+                                     skip.alpha is not None and ops.conv_up_wino_supported(
+                                         n_, h_, w_, low.shape[3], c1_, w.shape[0])) else None
                 y, st = ops.conv_up_in_fwd(low, skip, slope, table.wf[k], l.conv.bias.detach(),
                                            l.norm.weight.detach(), l.norm.bias.detach(),
-                                           l.norm.eps, m)
+                                           l.norm.eps, m, wu=wu)
                 if need_grad:
                     # Winograd form of the data gradient into the skip half
                     n_, h_, w_, c1_ = skip.shape
