@@ -23,7 +23,7 @@
 //     or the next layer's InstanceNorm-backward reductions (BSTATS, data gradient).
 //
 // LDS: V 2 x 32 KB + U 2 x 32 KB (double-buffered per 8-channel chunk, XOR-swizzled so the
-// 8-byte fragment reads are conflict-free without padding) + 12.5 KB raw patch = 140.5 KB.
+// 8-byte fragment reads are conflict-free without padding) + 11.4 KB raw patch = 139.4 KB.
 // Error: the transforms add a few fp32 roundings per output (coefficients 1 and 1/2 only);
 // measured <= 3e-6 of max |y| against the direct kernel, well inside the 1e-4 logits bound.
 //
@@ -52,15 +52,20 @@ constexpr int WN_PW = WN_TW + 2, WN_PH = WN_TH + 2;
 constexpr int WN_PPIX = WN_PH * WN_PW;      // 340 patch pixels
 constexpr int WN_BN = 64;                   // output channels of a workgroup
 constexpr int WN_KC = 8;                    // channels per chunk
-constexpr int WN_RP = 392;                  // channel-plane pitch of the raw patch: 8 mod 64
+constexpr int WN_RP = 356;                  // channel-plane pitch of the raw patch: 4 mod 32
 constexpr int WN_BUF = 16 * 64 * WN_KC;     // floats of one V / U stage (32 KB)
 constexpr size_t WN_LDS = (size_t)(4 * WN_BUF + WN_KC * WN_RP) * sizeof(float);
 
 // position of channel k (0..7) of row `row` (tile or output channel) inside its 8-float group:
-// channel pairs XOR-swizzled by bit 3 of the row so that the 32 lanes of a ds_read_b64 group
-// (16 rows x 2 pairs) cover 64 distinct banks
+// channel pairs XOR-swizzled by bits 2-3 of the row.  A fragment read is 16 rows x one pair per
+// 16 lanes; hipcc fuses neighbouring ds_read_b64 into ds_read2(st64)_b64, which the LDS serves
+// in 16-lane groups over 32 banks (rows r, r+4, r+8, r+12 share a bank residue: their pairs must
+// differ), while a plain ds_read_b64 is served in 32-lane groups over 64 banks (rows r, r+8
+// collide: the pair sets of the two lane halves must differ).  This swizzle is conflict-free
+// under both (the first layout, XOR by bit 3 only, measured 0.43 conflict cycles per active
+// LDS cycle once the reads were fused).
 __host__ __device__ __forceinline__ int wn_swz(int row, int k) {
-  return 2 * ((k >> 1) ^ (2 * ((row >> 3) & 1))) + (k & 1);
+  return 2 * ((k >> 1) ^ ((row >> 2) & 3)) + (k & 1);
 }
 
 struct WinoParams {
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     // (recomputed, not kept: slots past the patch write into the unused tail of the channel
     // planes, so the store needs no branch)
     const int rpix = i == 0 ? (tid >> 1)
-                            : (tid < 2 * WN_PPIX - 512 ? 256 + (tid >> 1) : WN_PPIX + (tid & 31));
+                            : (tid < 2 * WN_PPIX - 512 ? 256 + (tid >> 1) : WN_PPIX + (tid & 15));
     float* d = Rs + (half * 4) * WN_RP + rpix;
     d[0] = v[0]; d[WN_RP] = v[1]; d[2 * WN_RP] = v[2]; d[3 * WN_RP] = v[3];
   };
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   // ---- MFMA fragments: wave -> tiles 16 tg .. +15, output channels 32 nh .. +31 ----
   const int tg = wave & 3, nh = wave >> 2;
   const int fm = lane & 15, fk = lane >> 4;
-  const int fsw = 2 * (fk ^ (2 * (fm >> 3)));
+  const int fsw = 2 * (fk ^ ((fm >> 2) & 3));
   const int a_off = (16 * tg + fm) * 8 + fsw;
   const int b_off = (32 * nh + fm) * 8 + fsw;
   f32x4 acc[16][2];
