@@ -35,7 +35,8 @@ def hbm_traffic(args):
     pmc_traffic.py).  A committed measurement of the default workload, not of this run."""
     if args.matmul != "fp32" or args.hw != 512 or args.batch != 8 or args.clip:
         return None, None
-    for name in ("r02_conv_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
+    for name in ("r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json",
+                 "r01_igemm_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -76,15 +77,18 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
     exe = k["executed"] / sec * 1e-12
     roof = {
         # `achieved` / `frac`: the MFMA FLOPs the kernels actually ISSUE over their measured time
-        # (matrix-pipe utilisation against the dense peak).  The data gradient of the up-sampled
-        # operand runs on the low-resolution grid and issues 1/4 of the reference layer's 3x3
-        # FLOPs; crediting the reference's (algorithmic) count gives `algorithmic` /
-        # `algorithmic_frac`, which is the figure to compare with a direct convolution.
+        # (matrix-pipe utilisation against the dense peak).  Two reassociations issue fewer
+        # FLOPs than the reference layer's 3x3 convolution: the data gradient of the up-sampled
+        # operand runs on the low-resolution grid (1/4) and the Winograd kernels multiply 16
+        # instead of 36 times per 2x2 output tile (4/9).  Crediting the reference's (algorithmic)
+        # count gives `algorithmic` / `algorithmic_frac` - the figure to compare with a direct
+        # convolution, whose ceiling is the peak itself (`algorithmic_frac` > 1 is possible).
         "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s", "frac": exe / peak,
         "algorithmic": ach, "algorithmic_frac": ach / peak,
         "traffic": traffic, "traffic_source": src,
         "kernel": "convolution forward + data-gradient group ("
-                  + {"fp32": "conv_patch_f32_kernel, conv_patch_up_kernel, conv_patch_s2_kernel, "
+                  + {"fp32": "conv_wino_kernel (Winograd F(2x2,3x3): 16/36 of the direct MFMA FLOPs), "
+                             "conv_patch_f32_kernel, conv_patch_up_kernel, conv_patch_s2_kernel, "
                              "conv_c32_kernel, conv_igemm_kernel, conv_dgrad_s2_patch_kernel",
                      "bf16": "conv_patch_b16_kernel, conv_igemm_bf16_kernel on bf16 tensors",
                      "bf16x3": "conv_patch_split_kernel on the fused pipeline + the fp32 kernels "

@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-GROUP = re.compile(r"conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel")
+GROUP = re.compile(r"conv_wino_kernel|conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel")
 
 
 def per_launch(path, counter):
@@ -34,7 +34,7 @@ out = {"kernel": GROUP.pattern.replace("|", " | ") + " (3x3 forward + data gradi
        "write_bytes_per_launch": write,
        "hbm_bytes_per_launch": 2.0 * fetch + write,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                 "`bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-kernel-timer`; "
+                 "`bench.py --steps 2 --warmup 1 --no-alt --no-graph --no-cpu-baseline --no-kernel-timer`; "
                  "FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests "
                  "as 64 B for 16-B/lane coalesced reads); WRITE_SIZE (KiB) taken as is"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -316,6 +316,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   }
 
   // ---- epilogue: Y = A^T M A per (tile, channel), register-local ----
+  // (tried: rows = channels / columns = tiles, i.e. the MFMA operands swapped, for 16-byte
+  // stores of four consecutive channels per lane - the K loop itself ran 3-5 % slower with the
+  // U fragment in the A slot, which cost more than the wider stores gained)
   // (lane geometry re-derived here - the empty asm hides it from common-subexpression
   // elimination - so that nothing epilogue-only stays in a register through the K loop)
   int etid = threadIdx.x;
@@ -411,47 +414,63 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   }
 }
 
-// U = G g G^T of one (output column n, reduction channel k) filter, scattered into the kernel's
-// LDS image order.  fwd: n = co, k = ci, g = w[co][ci]; dgrad: n = ci, k = co, g = w rotated by
-// 180 degrees (the data gradient is the correlation of dy with the flipped filter).
+// U = G g G^T in the kernel's LDS image order.  One thread = one output column n and one chunk of
+// 8 reduction channels: it transforms 8 filters and writes, per xi, their 8 (swizzled) values as
+// two 16-byte stores - consecutive lanes = consecutive n, so a wave writes 2 KB runs.
+// dir 0 (blockIdx.y): forward, n = co, k = ci, g = w[co][ci]; dir 1: data gradient, n = ci,
+// k = co, g = w rotated by 180 degrees (the correlation of dy with the flipped filter).
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w,
                                                         float* __restrict__ uf,
                                                         float* __restrict__ ud, int Cout, int Cin) {
-  const long long total = (long long)Cout * Cin;
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-    const int co = (int)(i / Cin), ci = (int)(i - (long long)co * Cin);
-    float g[3][3];
+  const int dir = blockIdx.y;
+  float* dst = dir == 0 ? uf : ud;
+  if (!dst) return;
+  const int Nn = dir == 0 ? Cout : Cin, Kt = dir == 0 ? Cin : Cout;
+  const int kchunks = Kt / WN_KC;
+  const long long items = (long long)Nn * kchunks;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= items) return;
+  const int nl = (int)(idx & 63);
+  const long long rest = idx >> 6;
+  const int kc = (int)(rest % kchunks), tn = (int)(rest / kchunks);
+  const int nn = tn * WN_BN + nl;
+  float u[16][8];   // [xi][channel of the chunk]
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = w[i * 9 + t];
+  for (int k = 0; k < 8; ++k) {
+    const int kk = kc * WN_KC + k;
+    const int co = dir == 0 ? nn : kk, ci = dir == 0 ? kk : nn;
+    const float* g = w + ((size_t)co * Cin + ci) * 9;
+    float t4[4][3];
 #pragma unroll
-    for (int dir = 0; dir < 2; ++dir) {
-      float* dst = dir == 0 ? uf : ud;
-      if (!dst) continue;
-      const int nn = dir == 0 ? co : ci, kk = dir == 0 ? ci : co;
-      const int Kt = dir == 0 ? Cin : Cout;
-      if ((dir == 0 ? Cout : Cin) % WN_BN != 0 || Kt % WN_KC != 0) continue;
-      float t4[4][3];
-#pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        const float g0 = dir == 0 ? g[0][v] : g[2][2 - v];
-        const float g1 = dir == 0 ? g[1][v] : g[1][2 - v];
-        const float g2 = dir == 0 ? g[2][v] : g[0][2 - v];
-        t4[0][v] = g0;
-        t4[1][v] = 0.5f * (g0 + g1 + g2);
-        t4[2][v] = 0.5f * (g0 - g1 + g2);
-        t4[3][v] = g2;
-      }
-      float* blk = dst + ((size_t)(nn / WN_BN) * (Kt / WN_KC) + kk / WN_KC) * WN_BUF +
-                   (nn % WN_BN) * 8 + wn_swz(nn % WN_BN, kk % WN_KC);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        blk[(4 * a + 0) * 512] = t4[a][0];
-        blk[(4 * a + 1) * 512] = 0.5f * (t4[a][0] + t4[a][1] + t4[a][2]);
-        blk[(4 * a + 2) * 512] = 0.5f * (t4[a][0] - t4[a][1] + t4[a][2]);
-        blk[(4 * a + 3) * 512] = t4[a][2];
-      }
+    for (int v = 0; v < 3; ++v) {
+      const float g0 = dir == 0 ? g[0 + v] : g[6 + 2 - v];
+      const float g1 = dir == 0 ? g[3 + v] : g[3 + 2 - v];
+      const float g2 = dir == 0 ? g[6 + v] : g[0 + 2 - v];
+      t4[0][v] = g0;
+      t4[1][v] = 0.5f * (g0 + g1 + g2);
+      t4[2][v] = 0.5f * (g0 - g1 + g2);
+      t4[3][v] = g2;
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      u[4 * a + 0][k] = t4[a][0];
+      u[4 * a + 1][k] = 0.5f * (t4[a][0] + t4[a][1] + t4[a][2]);
+      u[4 * a + 2][k] = 0.5f * (t4[a][0] - t4[a][1] + t4[a][2]);
+      u[4 * a + 3][k] = t4[a][2];
+    }
+  }
+  // wn_swz: the channel PAIRS of this row are XOR-permuted by bits 2-3 of the row - two
+  // conditional pair swaps (selects, no indexed register access)
+  const bool s1 = (nl >> 2) & 1, s2 = (nl >> 3) & 1;
+  float* blk = dst + ((size_t)tn * kchunks + kc) * WN_BUF + nl * 8;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) {
+    f32x2v p0 = {u[x][0], u[x][1]}, p1 = {u[x][2], u[x][3]}, p2 = {u[x][4], u[x][5]},
+           p3 = {u[x][6], u[x][7]};
+    const f32x2v q0 = s1 ? p1 : p0, q1 = s1 ? p0 : p1, q2 = s1 ? p3 : p2, q3 = s1 ? p2 : p3;
+    p0 = s2 ? q2 : q0; p1 = s2 ? q3 : q1; p2 = s2 ? q0 : q2; p3 = s2 ? q1 : q3;
+    *reinterpret_cast<f32x4*>(blk + x * 512) = f32x4{p0[0], p0[1], p1[0], p1[1]};
+    *reinterpret_cast<f32x4*>(blk + x * 512 + 4) = f32x4{p2[0], p2[1], p3[0], p3[1]};
   }
 }
 
@@ -503,11 +522,9 @@ extern "C" int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud,
                "pack_wino_weights: forward form needs Cout %% 64 == 0, Cin %% 8 == 0");
   UNET_REQUIRE(!ud || (Cin % WN_BN == 0 && Cout % WN_KC == 0),
                "pack_wino_weights: data-gradient form needs Cin %% 64 == 0, Cout %% 8 == 0");
-  const long long total = (long long)Cout * Cin;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     w_oihw, uf, ud, Cout, Cin);
+  const long long items = (long long)Cout * Cin / WN_KC;     // (column, 8-channel chunk) per form
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((items + 255) / 256), 2), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, uf, ud, Cout, Cin);
   UNET_CHECK_LAUNCH("wino_pack");
   return UNET_OK;
 }
