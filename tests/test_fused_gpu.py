@@ -292,6 +292,9 @@ WGRAD_CASES = [  # (N, H, W, Cx, Cout, stride, ksize, act)
     (2, 2, 2, 512, 512, 1, 1, True),     # 1x1 (centre tap)
     (1, 16, 16, 64, 64, 1, 3, False),    # plain operand through the same entry point
     (2, 8, 128, 3, 32, 1, 3, False),     # RGB stem
+    (2, 32, 64, 64, 64, 1, 3, True),     # Winograd F(3x3,2x2) form: 64 chunks of 8 tiles
+    (1, 64, 32, 128, 64, 1, 3, True),    # Winograd, two ci tiles, image borders on every chunk
+    (3, 16, 48, 64, 128, 1, 3, False),   # Winograd, plain operand, 3 chunks per tile row
 ]
 
 

@@ -1080,6 +1080,284 @@ int launch_wgrad8_s(const WgradParams& p, int S, hipStream_t stream) {
   return UNET_E_INVALID;
 }
 
+// ---------------------------------------------------------------------------
+// Winograd F(3x3, 2x2) weight gradient of a stride-1 3x3 convolution on the fp32 matrix cores:
+// per 2x2 tile of dy (e) and its 4x4 input window (d)
+//     dW_tile = A^T [ (G e G^T) .* (B^T d B) ] A,
+// 16 multiplies instead of the 36 of the direct form (2.25x fewer MFMA FLOPs); the sum over
+// tiles and images is linear, so it is taken in the transform domain: 16 independent GEMMs
+//     M_xi[ci][co] = sum over tiles of V_xi[tile][ci] * E_xi[tile][co]
+// with K = tiles, and A^T M A is applied once per workgroup in the epilogue.
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]   (F(3,2): the last row differs from F(2,3))
+//   G   = [1 0; 1/2 1/2; 1/2 -1/2; 0 1],   A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1].
+// Workgroup = 8 waves (one per CU) owning a 64 ci x 64 co tile for all 16 xi (wave w: 16 ci x
+// 32 co, v_mfma_f32_16x16x4_f32, 128 accumulator VGPRs) and a contiguous range of K chunks; a
+// chunk = 8 horizontally adjacent tiles (16 x 2 output pixels).  Per chunk the 4 x 18 pixel
+// window of x (activated on load in the fused pipeline) and the 2 x 16 pixels of dy are staged
+// raw ([pixel][64 channels], 16-byte stores), then every thread transforms one (channel, tile
+// pair, half of the xi rows) of each operand - channel = lane, so all LDS traffic of the
+// transforms is conflict-free - into V / E stored as [xi][tile pair][channel][2] (bit 5 of the
+// offset XOR-flipped for odd pairs: conflict-free 8-byte fragment reads).  Slabs, reductions
+// and the OIHW scatter are those of conv_wgrad_kernel.
+// ---------------------------------------------------------------------------
+constexpr int WW_XP = 4 * 18, WW_DP = 2 * 16;          // staged pixels of x / dy per chunk
+constexpr int WW_BUF = 16 * 512;                        // floats of one V / E stage
+constexpr size_t WW_LDS = (size_t)(4 * WW_BUF + (WW_XP + WW_DP) * 64) * sizeof(float);
+
+template <bool ACT>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                       // [buf][xi][pair 4][ci 64][2]
+  float* Es = smem + 2 * WW_BUF;          // [buf][xi][pair 4][co 64][2]
+  float* Rx = smem + 4 * WW_BUF;          // [pixel 72][ci 64]
+  float* Rd = Rx + WW_XP * 64;            // [pixel 32][co 64]
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+  const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+  const int sp = bid;
+  const int ci0 = ci_t * 64, co0 = co_t * 64;
+  const int g_begin = sp * p.segs_per_block;
+  const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
+  const int cw = p.W >> 4, th = p.H >> 1;      // chunks per tile row, tile rows per image
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+  // ---- raw slots: x 72 pixels x 16 channel groups = 1152 (thread: tid, +512, +1024 < 1152),
+  //      dy 32 x 16 = 512 (one per thread); the channel group is tid & 15 for every slot
+  const int grp4 = (tid & 15) * 4;
+  int x_pix[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x_pix[i] = (tid + 512 * i) >> 4;      // 0..95 (>= 72: no slot)
+  const int d_pixl = tid >> 4;                                      // 0..31
+  f32x4 rx[3], rd;
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  unsigned okm = 0;
+  auto load_raw = [&](int g) {
+    const int cc = g % cw;
+    const int r = g / cw;
+    const int tr = r % th, n = r / th;
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int prow = x_pix[i] / 18, pcol = x_pix[i] - prow * 18;
+      const int iy = 2 * tr - 1 + prow, ix = 16 * cc - 1 + pcol;
+      const bool ok = x_pix[i] < WW_XP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      okm |= (ok ? 1u : 0u) << i;
+      rx[i] = buf_ld4<float>(rsx, (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + ci0 + grp4),
+                             ok ? 0u : 0x80000000u);
+    }
+    {
+      const int oy = 2 * tr + (d_pixl >> 4), ox = 16 * cc + (d_pixl & 15);
+      rd = buf_ld4<float>(rsd, (unsigned)(((n * p.H + oy) * p.W + ox) * p.Cout + co0 + grp4), 0u);
+    }
+    if (ACT) {   // the loaded coefficients are only looked at when the patch is stored
+      const size_t o = (size_t)n * p.Cx + ci0 + grp4;
+      ca = *reinterpret_cast<const f32x4*>(p.alpha + o);
+      cb = *reinterpret_cast<const f32x4*>(p.beta + o);
+    }
+  };
+  auto store_x = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    f32x4 v = rx[i];
+    if (ACT) v = act4(v, ca, cb, p.slope, (okm >> i) & 1u);
+    if (i < 2 || tid + 1024 < WW_XP * 16)
+      *reinterpret_cast<f32x4*>(Rx + x_pix[i] * 64 + grp4) = v;
+  };
+  auto store_d = [&]() { *reinterpret_cast<f32x4*>(Rd + d_pixl * 64 + grp4) = rd; };
+
+  // ---- transforms: thread -> (channel = lane, tile pair = wave & 3, xi rows {2h, 2h+1}) ----
+  const int t_pair = wave & 3, t_half = wave >> 2;
+  const int t_off = t_pair * 128 + ((lane * 2) ^ (32 * (t_pair & 1)));
+  // one xi row a of V = B^T d B for the two tiles of the pair: combine two window rows over the
+  // pair's 6 columns, column pass per tile, two 8-byte writes per xi
+  auto t_v = [&](auto ac, float* Vb) {
+    constexpr int a = decltype(ac)::value;                       // 0..3
+    constexpr int r0 = a == 0 ? 0 : (a == 1 ? 1 : (a == 2 ? 2 : 3));
+    constexpr int r1 = a == 0 ? 2 : (a == 1 ? 2 : 1);
+    const float* src = Rx + (4 * t_pair) * 64 + lane;
+    float c[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float u0 = src[(r0 * 18 + j) * 64], u1 = src[(r1 * 18 + j) * 64];
+      c[j] = a == 1 ? u0 + u1 : u0 - u1;
+    }
+    float* dst = Vb + (4 * a) * 512 + t_off;
+    *reinterpret_cast<f32x2v*>(dst) = f32x2v{c[0] - c[2], c[2] - c[4]};
+    *reinterpret_cast<f32x2v*>(dst + 512) = f32x2v{c[1] + c[2], c[3] + c[4]};
+    *reinterpret_cast<f32x2v*>(dst + 1024) = f32x2v{c[2] - c[1], c[4] - c[3]};
+    *reinterpret_cast<f32x2v*>(dst + 1536) = f32x2v{c[3] - c[1], c[5] - c[3]};
+  };
+  // one xi row a of E = G e G^T for the two tiles of the pair (4 dy columns)
+  auto t_e = [&](auto ac, float* Eb) {
+    constexpr int a = decltype(ac)::value;
+    const float* src = Rd + (4 * t_pair) * 64 + lane;
+    float gq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float e0 = src[j * 64], e1 = src[(16 + j) * 64];
+      gq[j] = a == 0 ? e0 : (a == 1 ? 0.5f * (e0 + e1) : (a == 2 ? 0.5f * (e0 - e1) : e1));
+    }
+    float* dst = Eb + (4 * a) * 512 + t_off;
+    *reinterpret_cast<f32x2v*>(dst) = f32x2v{gq[0], gq[2]};
+    *reinterpret_cast<f32x2v*>(dst + 512) = f32x2v{0.5f * (gq[0] + gq[1]), 0.5f * (gq[2] + gq[3])};
+    *reinterpret_cast<f32x2v*>(dst + 1024) = f32x2v{0.5f * (gq[0] - gq[1]), 0.5f * (gq[2] - gq[3])};
+    *reinterpret_cast<f32x2v*>(dst + 1536) = f32x2v{gq[1], gq[3]};
+  };
+  // the four transform pieces of this thread (its two xi rows of both operands)
+  auto t_piece = [&](auto kc, float* Vb, float* Eb) {
+    constexpr int k = decltype(kc)::value;
+    if (t_half == 0) {          // uniform per wave
+      if constexpr (k == 0) t_v(template_ic<0>{}, Vb);
+      if constexpr (k == 1) t_v(template_ic<1>{}, Vb);
+      if constexpr (k == 2) t_e(template_ic<0>{}, Eb);
+      if constexpr (k == 3) t_e(template_ic<1>{}, Eb);
+    } else {
+      if constexpr (k == 0) t_v(template_ic<2>{}, Vb);
+      if constexpr (k == 1) t_v(template_ic<3>{}, Vb);
+      if constexpr (k == 2) t_e(template_ic<2>{}, Eb);
+      if constexpr (k == 3) t_e(template_ic<3>{}, Eb);
+    }
+  };
+
+  // ---- MFMA fragments: wave -> ci rows 16 tg .. +15, co columns 32 nh .. +31 ----
+  const int tg = wave & 3, nh = wave >> 2;
+  const int fm = lane & 15, fk = lane >> 4;
+  const int a_off = fk * 128 + (((16 * tg + fm) * 2) ^ (32 * (fk & 1)));
+  const int b_off = fk * 128 + (((32 * nh + fm) * 2) ^ (32 * (fk & 1)));
+  const int b_off1 = fk * 128 + (((32 * nh + 16 + fm) * 2) ^ (32 * (fk & 1)));
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2v fa, fb0, fb1;
+  auto frag = [&](const float* Vb, const float* Eb, int x) {
+    fa = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
+    fb0 = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off);
+    fb1 = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off1);
+  };
+  auto mm = [&](auto xc) {
+    constexpr int x = decltype(xc)::value;
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb0[0], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb1[0], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb0[1], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb1[1], acc[x][1], 0, 0, 0);
+  };
+
+  if (g_begin < g_end) {
+    // prologue: chunk 0 transformed into stage 0, chunk 1 in the registers
+    load_raw(g_begin);
+    for_range<0, 3>(store_x);
+    store_d();
+    load_raw(g_begin + 1 < g_end ? g_begin + 1 : g_begin);
+    __syncthreads();
+    for_range<0, 4>([&](auto kc) { t_piece(kc, Vs, Es); });
+    for (int g = g_begin; g < g_end; ++g) {
+      const int buf = (g - g_begin) & 1;
+      const float* Vb = Vs + buf * WW_BUF;
+      const float* Eb = Es + buf * WW_BUF;
+      float* Vn = Vs + (buf ^ 1) * WW_BUF;
+      float* En = Es + (buf ^ 1) * WW_BUF;
+      const int g2 = g + 2 < g_end ? g + 2 : g_end - 1;   // branch-free tail: re-stage the last chunk
+      // stage buf is complete, every wave is done with stage buf ^ 1 and with the raw buffers
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      frag(Vb, Eb, 0);
+      for_range<0, 8>([&](auto xc) {
+        constexpr int x = decltype(xc)::value;
+        mm(xc);
+        frag(Vb, Eb, x + 1);
+        if constexpr (x < 3) store_x(template_ic<x>{});   // chunk g + 1 (loaded an iteration ago)
+        if constexpr (x == 3) store_d();
+        if constexpr (x == 4) load_raw(g2);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw chunk g + 1 complete (LDS only)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for_range<8, 16>([&](auto xc) {
+        constexpr int x = decltype(xc)::value;
+        mm(xc);
+        if constexpr (x + 1 < 16) frag(Vb, Eb, x + 1);
+        if constexpr (x < 12) t_piece(template_ic<x - 8>{}, Vn, En);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  }
+
+  // ---- epilogue: dW = A^T M A per (ci, co), register-local; lane holds ci = 16 tg + 4 fk + r,
+  //      co = 32 nh + 16 b + fm ----
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[0][j] = acc[0 + j][b][r] + acc[4 + j][b][r] + acc[8 + j][b][r];
+        s[1][j] = acc[4 + j][b][r] - acc[8 + j][b][r];
+        s[2][j] = acc[4 + j][b][r] + acc[8 + j][b][r] + acc[12 + j][b][r];
+      }
+      const int row = ci0 + 16 * tg + 4 * fk + r, col = co0 + 32 * nh + 16 * b + fm;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        float* out = p.partial + ((size_t)(sp * 9 + u * 3) * p.Cx + row) * p.Cout + col;
+        const size_t ts = (size_t)p.Cx * p.Cout;
+        out[0] = s[u][0] + s[u][1] + s[u][2];
+        out[ts] = s[u][1] - s[u][2];
+        out[2 * ts] = s[u][1] + s[u][2] + s[u][3];
+      }
+    }
+}
+
+int launch_wgrad_wino(const WgradParams& p, hipStream_t stream) {
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_wino_kernel<true>;
+    UNET_SET_DYN_LDS(kern, WW_LDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WW_LDS, stream, p);
+  } else {
+    auto kern = conv_wgrad_wino_kernel<false>;
+    UNET_SET_DYN_LDS(kern, WW_LDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WW_LDS, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_wino");
+  return UNET_OK;
+}
+
+// shapes the Winograd weight gradient tiles: stride 1, 64-wide channel tiles, an image that
+// splits into chunks of 8 tiles (16 x 2 pixels), enough chunks to split over workgroups
+bool wgrad_wino_ok(int N, int H, int W, int Cx, int Cout, int stride) {
+  if (stride != 1 || Cx % 64 || Cout % 64 || H % 2 || W % 16) return false;
+  const long long chunks = (long long)N * (H / 2) * (W / 16);
+  return chunks >= 32 && chunks < (1LL << 30);   // >= 8 chunks for each of >= 4 pixel splits
+}
+
+// plan: K chunks (`segments`) split over ~256 / tiles workgroups per channel tile
+WgradPlan make_plan_wino(int N, int H, int W, int Cx, int Cout) {
+  WgradPlan pl{};
+  pl.nw = 8; pl.ci_t = pl.co_t = 64; pl.npp = 2; pl.sps = 1; pl.S = 16;
+  pl.segs_per_row = W / 16;
+  pl.total_segs = N * (H / 2) * (W / 16);
+  const int tiles = (Cx / 64) * (Cout / 64);
+  int split = ceil_div(256, tiles);
+  const int max_split = ceil_div(pl.total_segs, 8);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  pl.segs_per_block = ceil_div(pl.total_segs, split);
+  pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
+  const size_t E = (size_t)9 * Cx * Cout;
+  pl.ws_floats = (size_t)pl.split * E + 2 * (size_t)ceil_div(pl.split, kSlabChunk) * E;
+  return pl;
+}
+
 template <int CI_T, int CO_T, int S, int STRIDE, bool ACT, typename TS>
 int launch_wgrad_t(const WgradParams& p, hipStream_t stream);
 
@@ -1345,8 +1623,13 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
   const size_t a = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0);
   const size_t b = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 3);
   const size_t c = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0, true);
-  const size_t m = a > b ? a : b;
-  return (m > c ? m : c) * sizeof(float);
+  size_t m = a > b ? a : b;
+  if (c > m) m = c;
+  if (Cx != 3 && wgrad_wino_ok(N, H, W, Cx, Cout, stride)) {
+    const size_t d = make_plan_wino(N, H, W, Cx, Cout).ws_floats;
+    if (d > m) m = d;
+  }
+  return m * sizeof(float);
 }
 
 static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
@@ -1371,8 +1654,14 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   // keep two independent 4-wave workgroups per CU (measured 4-6 % faster there: their 128..256
   // pixel splits leave the 8-wave form few MFMAs per barrier and long reductions)
   const bool wide = prec == 0 && !b16 && Cx != 3 && wgrad_tiles(Cx, Cout) >= 4;
-  const WgradPlan pl = make_plan(N, H, W, Cx, Cout, stride, pprec, wide);
-  const size_t need = wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec, wide) * sizeof(float);
+  // fp32 tensors, stride-1 3x3 layers with 64-wide channel tiles: the Winograd F(3x3,2x2) form
+  const bool wino = prec == 0 && !b16 && !center_only && Cx != 3 &&
+                    wgrad_wino_ok(N, H, W, Cx, Cout, stride) &&
+                    wgrad_batch_chunk(N, H, W, Cx, Cout, stride) >= N;
+  const WgradPlan pl = wino ? make_plan_wino(N, H, W, Cx, Cout)
+                            : make_plan(N, H, W, Cx, Cout, stride, pprec, wide);
+  const size_t need = (wino ? pl.ws_floats
+                            : wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec, wide)) * sizeof(float);
   if (workspace_bytes < need || need == 0) {
     unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     return UNET_E_WORKSPACE;
@@ -1435,7 +1724,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int nslab = 0;
     for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
       const int nc = N - nb < nmax ? N - nb : nmax;
-      const WgradPlan pc = make_plan(nc, H, W, Cx, Cout, stride, pprec, wide);
+      const WgradPlan pc = wino ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide);
       WgradParams p{};
       p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
                                            (size_t)nb * H * W * Cx * es);
@@ -1452,7 +1741,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       p.alpha = act_alpha ? act_alpha + (size_t)nb * Cx : nullptr;
       p.beta = act_alpha ? act_beta + (size_t)nb * Cx : nullptr;
       p.slope = slope;
-      const int rc = launch_wgrad_plan(p, pc, stride, prec, stream);
+      const int rc = wino ? launch_wgrad_wino(p, stream) : launch_wgrad_plan(p, pc, stride, prec, stream);
       if (rc != UNET_OK) return rc;
       nslab += pc.split * pc.sps;
     }
