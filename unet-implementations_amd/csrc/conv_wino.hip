@@ -248,18 +248,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   for (int x = 0; x < 16; ++x)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x2v fa, fb0, fb1;     // fragments of one xi; the next xi's are read right behind its MFMAs
-  auto frag = [&](const float* Vb, const float* Ub, int x) {
-    fa = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
-    fb0 = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off);
-    fb1 = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off + 128);
+  // fragments: read one xi ahead of their MFMAs into the other register set (the up-sampling
+  // variant has no registers to spare: one set, read right behind the MFMAs that used it)
+  constexpr int FS = UP ? 1 : 2;
+  f32x2v fa[FS], fb0[FS], fb1[FS];
+  auto frag = [&](const float* Vb, const float* Ub, auto xc) {
+    constexpr int x = decltype(xc)::value;
+    constexpr int sl = x % FS;
+    fa[sl] = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
+    fb0[sl] = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off);
+    fb1[sl] = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off + 128);
   };
   auto mm = [&](auto xc) {
     constexpr int x = decltype(xc)::value;
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb0[0], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb1[0], acc[x][1], 0, 0, 0);
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb0[1], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb1[1], acc[x][1], 0, 0, 0);
+    constexpr int sl = x % FS;
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb0[sl][0], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb1[sl][0], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb0[sl][1], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb1[sl][1], acc[x][1], 0, 0, 0);
+  };
+  // one stage: with two fragment sets the reads of xi + 1 are issued BEFORE the MFMAs of xi
+  auto stage = [&](const float* Vb, const float* Ub, auto xc) {
+    constexpr int x = decltype(xc)::value;
+    if constexpr (FS == 2) {
+      if constexpr (x + 1 < 16) frag(Vb, Ub, wn_ic<x + 1>{});
+      mm(xc);
+    } else {
+      mm(xc);
+      if constexpr (x + 1 < 16) frag(Vb, Ub, wn_ic<x + 1>{});
+    }
   };
 
   // ---- prologue: chunk 0 staged, chunk 1 in flight ----
@@ -290,11 +307,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    frag(Vb, Ub, 0);
+    frag(Vb, Ub, wn_ic<0>{});
     wn_for<0, 8>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
-      mm(xc);
-      frag(Vb, Ub, x + 1);
+      stage(Vb, Ub, xc);
       if constexpr (x == 0) store_raw(wn_ic<0>{});      // chunk c + 1 (loaded an iteration ago)
       if constexpr (x == 1) load_raw(c2, wn_ic<0>{});
       if constexpr (x == 2) store_raw(wn_ic<1>{});
@@ -308,8 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     asm volatile("" ::: "memory");
     wn_for<8, 16>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
-      mm(xc);
-      if constexpr (x + 1 < 16) frag(Vb, Ub, x + 1);
+      stage(Vb, Ub, xc);
       if constexpr (x < 12) t_row(wn_ic<x - 8>{}, Vn);
       __builtin_amdgcn_sched_barrier(0);
     });
