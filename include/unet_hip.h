@@ -480,6 +480,9 @@ int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src* s1, float 
                           const float* uf, const float* bias, float* y, void* workspace,
                           size_t workspace_bytes, int* stats_px_out, int N, int H, int W, int Cout,
                           unet_stream_t stream);
+/* 1 when unet_conv3x3_bwd_weight / unet_conv_in_bwd_weight (ksize 3, fp32 tensors) run this
+ * shape on the Winograd F(3x3,2x2) weight-gradient kernel (bench.py: executed FLOPs). */
+int unet_conv3x3_bwd_weight_is_winograd(int N, int H, int W, int Cx, int Cout, int stride);
 /* unet_conv_up_in_fwd on the Winograd kernel (the bilinear gather of the low-resolution source
  * runs inside its loader): low = [N][H/2][W/2][C0], skip = [N][H][W][C1]. */
 int unet_conv_up_wino_supported(int N, int H, int W, int C0, int C1, int Cout);

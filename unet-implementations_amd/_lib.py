@@ -111,6 +111,7 @@ SIGNATURES = {
     "unet_pack_wino_weights": (_i, [_p, _p, _p, _i, _i, _p]),
     "unet_conv_in_fwd_wino": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,
                                    _i, _p]),
+    "unet_conv3x3_bwd_weight_is_winograd": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_conv_up_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_conv_up_in_fwd_wino": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i,
                                       _i, _i, _p]),

@@ -1634,6 +1634,15 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
   return m * sizeof(float);
 }
 
+// 1 when the fp32 entry points (unet_conv3x3_bwd_weight, unet_conv_in_bwd_weight with ksize 3)
+// run this shape on the Winograd F(3x3,2x2) kernel (16/36 of the direct matrix FLOPs)
+extern "C" int unet_conv3x3_bwd_weight_is_winograd(int N, int H, int W, int Cx, int Cout,
+                                                   int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cx <= 3 || Cout <= 0) return 0;
+  return (wgrad_wino_ok(N, H, W, Cx, Cout, stride) &&
+          wgrad_batch_chunk(N, H, W, Cx, Cout, stride) >= N) ? 1 : 0;
+}
+
 static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* dw_oihw,
                                 int ci_offset, int Cin_total, float* db, void* workspace,
                                 size_t workspace_bytes, int N, int H, int W, int Cout, int stride,

@@ -641,9 +641,12 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride, x3=False
     check(fn(rx, slope, _ptr(dy), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], ksize, stride,
              _ptr(ws), ws.numel(), N, H, W, Cout, _stream()))
     if t0 is not None:
+        alg = 2.0 * N * dy.shape[1] * dy.shape[2] * ksize * ksize * Cx * Cout
+        wino = not b16 and not x3 and ksize == 3 and \
+            bool(lib().unet_conv3x3_bwd_weight_is_winograd(N, H, W, Cx, Cout, stride))
         _timer.end("conv_stem_wgrad" if Cx == 3 else
                    ("conv_wgrad_bf16" if b16 else ("conv_wgrad_bf16x3" if x3 else "conv_wgrad")),
-                   2.0 * N * dy.shape[1] * dy.shape[2] * ksize * ksize * Cx * Cout, 2, t0)
+                   alg, 2, t0, executed=alg * 16.0 / 36.0 if wino else None)
     return dw_oihw
 
 
