@@ -1236,20 +1236,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
   for (int x = 0; x < 16; ++x)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x2v fa[2], fb0[2], fb1[2];   // fragments, read one xi ahead of their MFMAs
-  auto frag = [&](const float* Vb, const float* Eb, auto xc) {
-    constexpr int x = decltype(xc)::value;
-    fa[x & 1] = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
-    fb0[x & 1] = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off);
-    fb1[x & 1] = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off1);
+  // fragments of one xi; the next xi's are read right behind its MFMAs (measured: reading them
+  // one stage ahead into a second register set, fenced or not, is 2-4 % slower in this kernel,
+  // whose stages carry 16-byte LDS stores)
+  f32x2v fa, fb0, fb1;
+  auto frag = [&](const float* Vb, const float* Eb, int x) {
+    fa = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
+    fb0 = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off);
+    fb1 = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off1);
   };
   auto mm = [&](auto xc) {
     constexpr int x = decltype(xc)::value;
-    constexpr int sl = x & 1;
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb0[sl][0], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb1[sl][0], acc[x][1], 0, 0, 0);
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb0[sl][1], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb1[sl][1], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb0[0], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb1[0], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb0[1], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb1[1], acc[x][1], 0, 0, 0);
   };
 
   if (g_begin < g_end) {
@@ -1271,11 +1272,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      frag(Vb, Eb, template_ic<0>{});
+      frag(Vb, Eb, 0);
       for_range<0, 8>([&](auto xc) {
         constexpr int x = decltype(xc)::value;
-        frag(Vb, Eb, template_ic<x + 1>{});
         mm(xc);
+        frag(Vb, Eb, x + 1);
         if constexpr (x < 3) store_x(template_ic<x>{});   // chunk g + 1 (loaded an iteration ago)
         if constexpr (x == 3) store_d();
         if constexpr (x == 4) load_raw(g2);
@@ -1286,8 +1287,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
       asm volatile("" ::: "memory");
       for_range<8, 16>([&](auto xc) {
         constexpr int x = decltype(xc)::value;
-        if constexpr (x + 1 < 16) frag(Vb, Eb, template_ic<x + 1>{});
         mm(xc);
+        if constexpr (x + 1 < 16) frag(Vb, Eb, x + 1);
         if constexpr (x < 12) t_piece(template_ic<x - 8>{}, Vn, En);
         __builtin_amdgcn_sched_barrier(0);
       });

@@ -23,7 +23,7 @@
 //     or the next layer's InstanceNorm-backward reductions (BSTATS, data gradient).
 //
 // LDS: V 2 x 32 KB + U 2 x 32 KB (double-buffered per 8-channel chunk, XOR-swizzled so the
-// 8-byte fragment reads are conflict-free without padding) + 11.4 KB raw patch = 139.4 KB.
+// 8-byte fragment reads are conflict-free without padding) + 2 x 11.4 KB raw patch = 150.3 KB.
 // Error: the transforms add a few fp32 roundings per output (coefficients 1 and 1/2 only);
 // measured <= 3e-6 of max |y| against the direct kernel, well inside the 1e-4 logits bound.
 //
@@ -54,7 +54,7 @@ constexpr int WN_BN = 64;                   // output channels of a workgroup
 constexpr int WN_KC = 8;                    // channels per chunk
 constexpr int WN_RP = 356;                  // channel-plane pitch of the raw patch: 4 mod 32
 constexpr int WN_BUF = 16 * 64 * WN_KC;     // floats of one V / U stage (32 KB)
-constexpr size_t WN_LDS = (size_t)(4 * WN_BUF + WN_KC * WN_RP) * sizeof(float);
+constexpr size_t WN_LDS = (size_t)(4 * WN_BUF + 2 * WN_KC * WN_RP) * sizeof(float);
 
 // position of channel k (0..7) of row `row` (tile or output channel) inside its 8-float group:
 // channel pairs XOR-swizzled by bits 2-3 of the row.  A fragment read is 16 rows x one pair per
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                    // [buf][xi][tile 64][8]
   float* Us = smem + 2 * WN_BUF;       // [buf][xi][n 64][8]
-  float* Rs = smem + 4 * WN_BUF;       // [channel 8][WN_RP]: raw (activated) patch, pixel-major
+  float* Rs = smem + 4 * WN_BUF;       // [buf][channel 8][WN_RP]: raw (activated) patch, pixel-major
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.Hin, W = p.Win;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       cb = *reinterpret_cast<const f32x4*>(be + (size_t)n * Cs + cc);
     }
   };
-  auto store_raw = [&](auto ic) {      // R: activate, registers -> LDS raw patch (zero padding)
+  auto store_raw = [&](auto ic, float* Rb) {   // R: activate, registers -> LDS raw patch (zero padding)
     constexpr int i = decltype(ic)::value;
     f32x4 v = pr[i];
     if (ACT) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     // planes, so the store needs no branch)
     const int rpix = i == 0 ? (tid >> 1)
                             : (tid < 2 * WN_PPIX - 512 ? 256 + (tid >> 1) : WN_PPIX + (tid & 15));
-    float* d = Rs + (half * 4) * WN_RP + rpix;
+    float* d = Rb + (half * 4) * WN_RP + rpix;
     d[0] = v[0]; d[WN_RP] = v[1]; d[2 * WN_RP] = v[2]; d[3 * WN_RP] = v[3];
   };
   // ---- input transform: thread -> (tile = tid >> 3, channel = tid & 7) ----
@@ -209,14 +209,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   // T: V = (B^T d) B of this thread's 4 x 4 window, one OUTPUT row per piece: the two input rows
   // it combines are read (8-byte reads), combined, put through the column pass and written, so
   // nothing of the transform stays in registers between pieces (each input row is read twice)
-  auto t_row = [&](auto ac, float* Vb) {
+  auto t_row = [&](auto ac, const float* Rb, float* Vb) {
     constexpr int a = decltype(ac)::value;
     constexpr int r0 = a == 0 ? 0 : (a == 1 ? 1 : (a == 2 ? 2 : 1));   // first row
     constexpr int r1 = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));   // second row
-    const f32x2v lo0 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r0 * WN_PW);
-    const f32x2v hi0 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r0 * WN_PW + 2);
-    const f32x2v lo1 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r1 * WN_PW);
-    const f32x2v hi1 = *reinterpret_cast<const f32x2v*>(Rs + t_src + r1 * WN_PW + 2);
+    const f32x2v lo0 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r0 * WN_PW);
+    const f32x2v hi0 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r0 * WN_PW + 2);
+    const f32x2v lo1 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r1 * WN_PW);
+    const f32x2v hi1 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r1 * WN_PW + 2);
     // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
     const f32x2v lo = a == 1 ? lo0 + lo1 : lo0 - lo1;
     const f32x2v hi = a == 1 ? hi0 + hi1 : hi0 - hi1;
@@ -271,7 +271,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   auto stage = [&](const float* Vb, const float* Ub, auto xc) {
     constexpr int x = decltype(xc)::value;
     if constexpr (FS == 2) {
+      // the reads FIRST and fenced there: issued at the end of a stage (where hipcc likes to sink
+      // them) the next stage's wait drains the whole LDS queue - its own stores included
       if constexpr (x + 1 < 16) frag(Vb, Ub, wn_ic<x + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
       mm(xc);
     } else {
       mm(xc);
@@ -279,53 +282,51 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     }
   };
 
-  // ---- prologue: chunk 0 staged, chunk 1 in flight ----
+  // ---- prologue: chunk 0 transformed, chunk 1 raw in LDS, chunk 2 in the registers ----
+  constexpr int RB = WN_KC * WN_RP;
+  auto cl = [&](int c) { return c < chunks ? c : chunks - 1; };   // the tail re-stages the last chunk
   load_raw(0, wn_ic<0>{});
   load_raw(0, wn_ic<1>{});
   wn_for<0, 4>([&](auto ic) { dma_u(0, Us, ic); });
-  store_raw(wn_ic<0>{});
-  store_raw(wn_ic<1>{});
-  load_raw(chunks > 1 ? 1 : 0, wn_ic<0>{});
-  load_raw(chunks > 1 ? 1 : 0, wn_ic<1>{});
+  store_raw(wn_ic<0>{}, Rs);
+  store_raw(wn_ic<1>{}, Rs);
+  load_raw(cl(1), wn_ic<0>{});
+  load_raw(cl(1), wn_ic<1>{});
   __syncthreads();
-  wn_for<0, 4>([&](auto ac) { t_row(ac, Vs); });
+  wn_for<0, 4>([&](auto ac) { t_row(ac, Rs, Vs); });
+  store_raw(wn_ic<0>{}, Rs + RB);
+  store_raw(wn_ic<1>{}, Rs + RB);
+  load_raw(cl(2), wn_ic<0>{});
+  load_raw(cl(2), wn_ic<1>{});
   for (int c = 0; c < chunks; ++c) {
     const int buf = c & 1;
     const float* Vb = Vs + buf * WN_BUF;
     const float* Ub = Us + buf * WN_BUF;
     float* Vn = Vs + (buf ^ 1) * WN_BUF;
     float* Un = Us + (buf ^ 1) * WN_BUF;
-    // Branch-free body (the last iterations re-stage the final chunk into the idle stage).  One
-    // stage per xi: its 4 MFMAs, the fragment reads of the next xi, and one piece of the staging
-    // work for chunk c + 1 (first half: raw patch to LDS, next loads, U by DMA; second half:
-    // the input transform, one output row per xi), fenced so nothing bunches up before a barrier.
-    const int c1 = c + 1 < chunks ? c + 1 : chunks - 1;
-    const int c2 = c + 2 < chunks ? c + 2 : chunks - 1;
-    // every DMA of this wave has landed; every wave is done with stage buf ^ 1 and with Rs.
-    // (bare s_barrier: __syncthreads() would also put a vmcnt(0) in front of the SECOND barrier
-    // below, cutting the flight time of the loads issued in this iteration in half)
+    float* Rw = Rs + buf * RB;                 // raw patch of chunk c + 2 goes here
+    const float* Rr = Rs + (buf ^ 1) * RB;     // raw patch of chunk c + 1 (stored an iteration ago)
+    // Branch-free body, ONE barrier per chunk.  One stage per xi: its 4 MFMAs, the fragment reads
+    // of the next xi, and one piece of the staging pipeline, three chunks deep: the raw patch of
+    // chunk c + 2 from the registers to LDS, the loads of chunk c + 3, U of chunk c + 1 by DMA,
+    // the input transform of chunk c + 1 (raw patch double-buffered, so it needs no barrier of
+    // its own) - each stage fenced so nothing bunches up.
+    // At the barrier: every DMA of this wave has landed, every wave is done with stage buf ^ 1,
+    // with raw buffer `buf` (transformed an iteration ago) and has written raw buffer buf ^ 1.
+    // (bare s_barrier: __syncthreads() adds nothing we need)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     frag(Vb, Ub, wn_ic<0>{});
-    wn_for<0, 8>([&](auto xc) {
+    wn_for<0, 16>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
       stage(Vb, Ub, xc);
-      if constexpr (x == 0) store_raw(wn_ic<0>{});      // chunk c + 1 (loaded an iteration ago)
-      if constexpr (x == 1) load_raw(c2, wn_ic<0>{});
-      if constexpr (x == 2) store_raw(wn_ic<1>{});
-      if constexpr (x == 3) load_raw(c2, wn_ic<1>{});
-      if constexpr (x >= 4) dma_u(c1, Un, wn_ic<x - 4>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // the raw patch of chunk c + 1 is complete (LDS writes only: no wait for the loads in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    wn_for<8, 16>([&](auto xc) {
-      constexpr int x = decltype(xc)::value;
-      stage(Vb, Ub, xc);
-      if constexpr (x < 12) t_row(wn_ic<x - 8>{}, Vn);
+      if constexpr (x == 0) store_raw(wn_ic<0>{}, Rw);       // chunk c + 2 (loaded an iteration ago)
+      if constexpr (x == 1) load_raw(cl(c + 3), wn_ic<0>{});
+      if constexpr (x == 2) store_raw(wn_ic<1>{}, Rw);
+      if constexpr (x == 3) load_raw(cl(c + 3), wn_ic<1>{});
+      if constexpr (x >= 4 && x < 8) dma_u(cl(c + 1), Un, wn_ic<x - 4>{});
+      if constexpr (x >= 8 && x < 12) t_row(wn_ic<x - 8>{}, Rr, Vn);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
