@@ -47,12 +47,54 @@ __device__ __forceinline__ void wn_for(F&& f) {
   wn_for_impl<B>(std::make_integer_sequence<int, E - B>{}, f);
 }
 
+// Plain ds_read_b64 by hand.  hipcc fuses neighbouring 8-byte LDS reads into ds_read2(st64)_b64,
+// which the LDS serves at HALF the rate (8 array cycles per wave-instruction for 1 KB against
+// 2 for the 512 B of a ds_read_b64: MI355X guide, LDS table) - and these kernels keep the LDS
+// array busy for two thirds of their matrix time.  The compiler does not track the counter of
+// an asm read: lds_wait() is the s_waitcnt, tied to the registers it guards so that their uses
+// stay behind it.  (Its own waits stay valid: LDS returns in order, more reads in flight only
+// make a counted wait longer.)
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+template <int OFF>
+__device__ __forceinline__ f32x2v lds_rd64(unsigned a) {
+  f32x2v v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2v& a, f32x2v& b, f32x2v& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2v& a, f32x2v& b, f32x2v& c, f32x2v& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+// 16 bytes from (scalar base + 32-bit lane offset), untracked like the LDS reads above (hipcc
+// builds a 64-bit VALU address per load instead); the consumer sits behind an s_waitcnt vmcnt(0)
+__device__ __forceinline__ void gld4_sbase(f32x4& v, unsigned lane_off, const float* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(lane_off), "s"(sbase) : "memory");
+}
+// global -> LDS DMA of 16 bytes per lane: LDS base of the piece in M0, scalar base + lane offset
+// (M0 has no other user in these kernels: gfx9 LDS instructions do not read it)
+template <int OFF>
+__device__ __forceinline__ void dma16_sbase(unsigned m0v, unsigned lane_off, const float* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+               :: "s"(m0v), "v"(lane_off), "s"(sbase), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void reg_anchor(f32x4& a, f32x4& b) {
+  asm volatile("" : "+v"(a), "+v"(b) :: "memory");
+}
+
 constexpr int WN_TH = 8, WN_TW = 32;        // output pixels of a workgroup
 constexpr int WN_PW = WN_TW + 2, WN_PH = WN_TH + 2;
 constexpr int WN_PPIX = WN_PH * WN_PW;      // 340 patch pixels
 constexpr int WN_BN = 64;                   // output channels of a workgroup
 constexpr int WN_KC = 8;                    // channels per chunk
-constexpr int WN_RP = 356;                  // channel-plane pitch of the raw patch: 4 mod 32
+constexpr int WN_RP = 360;                  // channel-plane pitch of the raw patch: 40 mod 64, the
+                                            // transform's ds_read_b64 (32 lanes over 64 banks) are conflict-free
 constexpr int WN_BUF = 16 * 64 * WN_KC;     // floats of one V / U stage (32 KB)
 constexpr size_t WN_LDS = (size_t)(4 * WN_BUF + 2 * WN_KC * WN_RP) * sizeof(float);
 
@@ -104,8 +146,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
 
   // ---- raw patch slots: 340 pixels x 2 channel halves; thread -> slots tid, tid + 512 ----
+  // Everything the K loop needs per slot is loop-invariant and lives in a register or an
+  // immediate: on this chip every VALU instruction of either wave of a SIMD takes ~2.6 cycles
+  // away from the fp32 matrix pipe, SALU and LDS instructions ~1-3 (tools/micro/
+  // mfma_piece_cost.hip), so the loop is written for instruction count: buffer loads take the
+  // chunk's channel offset in their SCALAR offset, the zero padding is an EXEC mask on the LDS
+  // stores (the padding slots are zeroed once), LDS addresses are immediates (the loop is
+  // unrolled over the two stage parities), DMA / coefficient loads are scalar base + lane offset.
   const int half = tid & 1;
-  int g_lin[2];
+  unsigned voff0[UP ? 1 : 2], voff1[2];   // byte offsets into source 0 / 1, bit 31 = outside the image
+  bool okslot[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = tid + 512 * i;
@@ -113,7 +163,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     const int prow = pix / WN_PW, pcol = pix - prow * WN_PW;
     const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
     const bool ok = slot < 2 * WN_PPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    g_lin[i] = ok ? (n * H + iy) * W + ix : -1;
+    const unsigned lin = (unsigned)((n * H + iy) * W + ix);
+    okslot[i] = ok;
+    if (!UP) voff0[i] = ok ? (lin * (unsigned)p.C0 + half * 4) * 4u : 0x80000000u;
+    voff1[i] = ok ? (lin * (unsigned)p.C1 + half * 4) * 4u : 0x80000000u;
   }
   // UP: per slot the clamped low-resolution pixel of tap (0,0) and four flag bits: step to the
   // right / lower neighbour (0 where clamped) and the parity of the patch column / row
@@ -140,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   f32x4 pt[UP ? 2 : 1][3];   // UP: the other three taps of a slot
   bool pup = false;           // the chunk in the registers is a low-resolution (gathered) one
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  const unsigned hoff = (unsigned)half * 16u;   // this lane's 16 bytes of a chunk's coefficients
   // G: global -> registers, one slot per call.  Slot 1's call also fetches the chunk's coefficients
   // and source kind: it runs AFTER both slots of the previous chunk were stored
   auto load_raw = [&](int chunk, auto ic) {
@@ -148,10 +202,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int Cs = first ? p.C0 : p.C1;
-    const int cc = (first ? c : c - p.C0) + half * 4;
+    const int cc = first ? c : c - p.C0;      // (uniform: scalar registers)
     if (UP && first) {   // uniform
       if (i == 1) pup = true;
-      const unsigned o = (unsigned)(l_lin[i] * Cs + cc);
+      const unsigned o = (unsigned)(l_lin[i] * Cs + cc + half * 4);
       const unsigned dx = (l_meta[i] & 1) ? (unsigned)Cs : 0u;
       const unsigned dy = (l_meta[i] & 2) ? (unsigned)(lw * Cs) : 0u;
       pr[i] = buf_ld4<float>(rs, o, 0u);
@@ -162,25 +216,44 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       }
     } else {
       if (UP && i == 1) pup = false;
-      pr[i] = buf_ld4<float>(rs, (unsigned)(g_lin[i] * Cs + cc), g_lin[i] < 0 ? 0x80000000u : 0u);
+      unsigned vo = voff1[i];
+      if constexpr (!UP) vo = first ? voff0[i] : voff1[i];
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cc * 4, 0));
     }
     if (ACT && i == 1) {   // (ACT: every source is an activated tensor - the entry points check)
-      const float* al = first ? p.act0_alpha : p.act1_alpha;
-      const float* be = first ? p.act0_beta : p.act1_beta;
+      const float* al = (first ? p.act0_alpha : p.act1_alpha) + ((size_t)n * Cs + cc);
+      const float* be = (first ? p.act0_beta : p.act1_beta) + ((size_t)n * Cs + cc);
       // the loaded coefficients are only looked at when the patch is stored, an iteration later
-      ca = *reinterpret_cast<const f32x4*>(al + (size_t)n * Cs + cc);
-      cb = *reinterpret_cast<const f32x4*>(be + (size_t)n * Cs + cc);
+      // (scalar base + 32-bit lane offset by hand: hipcc builds a 64-bit VALU address; the
+      // chunk_body's s_waitcnt vmcnt(0) + anchor stand in for the compiler's tracking)
+      gld4_sbase(ca, hoff, al);
+      gld4_sbase(cb, hoff, be);
     }
   };
-  auto store_raw = [&](auto ic, float* Rb) {   // R: activate, registers -> LDS raw patch (zero padding)
+  // raw patch position of slot i (slots past the patch: never stored)
+  const int rpix1 = tid < 2 * WN_PPIX - 512 ? 256 + (tid >> 1) : WN_PPIX + (tid & 15);
+  float* const rdst0 = Rs + (half * 4) * WN_RP + (tid >> 1);
+  float* const rdst1 = Rs + (half * 4) * WN_RP + rpix1;
+  constexpr int RB = WN_KC * WN_RP;
+  // the zero padding: a slot outside the image is never written in the loop - zero it once in
+  // both raw buffers (the same thread owns the position for every chunk)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (!okslot[i] && tid + 512 * i < 2 * WN_PPIX) {
+      float* d = i == 0 ? rdst0 : rdst1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k * WN_RP] = d[RB + k * WN_RP] = 0.f;
+    }
+  auto store_raw = [&](auto ic, auto bc) {   // R: activate, registers -> LDS raw patch (buffer bc)
     constexpr int i = decltype(ic)::value;
+    constexpr int B = decltype(bc)::value;
     f32x4 v = pr[i];
     if (ACT) {
       const f32x4 a1 = ca, b1 = cb;
       const float sl = p.slope;
       bool done = false;
       if constexpr (UP) {
-        if (pup) {   // uniform: activate the four taps, blend, then the zero padding
+        if (pup) {   // uniform: activate the four taps, then blend
           // odd patch row = even image row 2k: taps (k-1, k) weigh (0.25, 0.75); even patch
           // row = odd image row: (0.75, 0.25); columns alike (y0, x0 are even)
           const f32x4 p00 = act4f(v, a1, b1, sl, 1.f), p01 = act4f(pt[i][0], a1, b1, sl, 1.f);
@@ -188,61 +261,72 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
           const f32x4 p11 = act4f(pt[i][2], a1, b1, sl, 1.f);
           const float wx1 = (l_meta[i] & 4) ? 0.75f : 0.25f, wx0 = 1.f - wx1;
           const float wy1 = (l_meta[i] & 8) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
-          v = ((p00 * wx0 + p01 * wx1) * wy0 + (p10 * wx0 + p11 * wx1) * wy1) *
-              (g_lin[i] >= 0 ? 1.f : 0.f);
+          v = (p00 * wx0 + p01 * wx1) * wy0 + (p10 * wx0 + p11 * wx1) * wy1;
           done = true;
         }
       }
-      if (!done) v = act4(v, a1, b1, sl, g_lin[i] >= 0);
+      if (!done) v = act4f(v, a1, b1, sl, 1.f);
     }
-    // (recomputed, not kept: slots past the patch write into the unused tail of the channel
-    // planes, so the store needs no branch)
-    const int rpix = i == 0 ? (tid >> 1)
-                            : (tid < 2 * WN_PPIX - 512 ? 256 + (tid >> 1) : WN_PPIX + (tid & 15));
-    float* d = Rb + (half * 4) * WN_RP + rpix;
-    d[0] = v[0]; d[WN_RP] = v[1]; d[2 * WN_RP] = v[2]; d[3 * WN_RP] = v[3];
+    if (okslot[i]) {   // (the zero padding: EXEC-masked stores, see above)
+      float* d = (i == 0 ? rdst0 : rdst1) + B * RB;
+      d[0] = v[0]; d[WN_RP] = v[1]; d[2 * WN_RP] = v[2]; d[3 * WN_RP] = v[3];
+    }
   };
   // ---- input transform: thread -> (tile = tid >> 3, channel = tid & 7) ----
   const int t_tile = tid >> 3, t_ch = tid & 7;
-  const int t_src = t_ch * WN_RP + (2 * (t_tile >> 4)) * WN_PW + 2 * (t_tile & 15);
-  const int t_dst = t_tile * 8 + wn_swz(t_tile, t_ch);
-  // T: V = (B^T d) B of this thread's 4 x 4 window, one OUTPUT row per piece: the two input rows
-  // it combines are read (8-byte reads), combined, put through the column pass and written, so
-  // nothing of the transform stays in registers between pieces (each input row is read twice)
-  auto t_row = [&](auto ac, const float* Rb, float* Vb) {
+  const unsigned t_ra = lds_addr(Rs + t_ch * WN_RP + (2 * (t_tile >> 4)) * WN_PW + 2 * (t_tile & 15));
+  float* const t_vdst = Vs + t_tile * 8 + wn_swz(t_tile, t_ch);
+  // T: V = (B^T d) B of this thread's 4 x 4 window, one OUTPUT row per piece, in two halves a
+  // stage apart: t_rd issues the 8-byte reads of the two input rows the row combines, t_wr (a
+  // stage later, behind that stage's fragment wait, which also covers these reads) combines
+  // them, runs the column pass and writes - no LDS latency is waited for on the spot (with the
+  // wait inside the piece both waves of a SIMD sat out an LDS round trip per row)
+  f32x2v tr[4];
+  auto t_rd = [&](auto ac, auto bc) {       // bc: raw buffer
     constexpr int a = decltype(ac)::value;
+    constexpr int B = decltype(bc)::value;
     constexpr int r0 = a == 0 ? 0 : (a == 1 ? 1 : (a == 2 ? 2 : 1));   // first row
     constexpr int r1 = a == 0 ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));   // second row
-    const f32x2v lo0 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r0 * WN_PW);
-    const f32x2v hi0 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r0 * WN_PW + 2);
-    const f32x2v lo1 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r1 * WN_PW);
-    const f32x2v hi1 = *reinterpret_cast<const f32x2v*>(Rb + t_src + r1 * WN_PW + 2);
+    tr[0] = lds_rd64<(B * RB + r0 * WN_PW) * 4>(t_ra);
+    tr[1] = lds_rd64<(B * RB + r0 * WN_PW) * 4 + 8>(t_ra);
+    tr[2] = lds_rd64<(B * RB + r1 * WN_PW) * 4>(t_ra);
+    tr[3] = lds_rd64<(B * RB + r1 * WN_PW) * 4 + 8>(t_ra);
+  };
+  auto t_wr = [&](auto ac, auto bc) {       // bc: V stage
+    constexpr int a = decltype(ac)::value;
+    constexpr int B = decltype(bc)::value;
+    lds_wait<15>(tr[0], tr[1], tr[2], tr[3]);   // (no-op wait: keeps the uses behind the stage's wait)
     // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-    const f32x2v lo = a == 1 ? lo0 + lo1 : lo0 - lo1;
-    const f32x2v hi = a == 1 ? hi0 + hi1 : hi0 - hi1;
-    Vb[(4 * a + 0) * 512 + t_dst] = lo[0] - hi[0];
-    Vb[(4 * a + 1) * 512 + t_dst] = lo[1] + hi[0];
-    Vb[(4 * a + 2) * 512 + t_dst] = hi[0] - lo[1];
-    Vb[(4 * a + 3) * 512 + t_dst] = lo[1] - hi[1];
+    const f32x2v lo = a == 1 ? tr[0] + tr[2] : tr[0] - tr[2];
+    const f32x2v hi = a == 1 ? tr[1] + tr[3] : tr[1] - tr[3];
+    float* Vb = t_vdst + B * WN_BUF;
+    Vb[(4 * a + 0) * 512] = lo[0] - hi[0];
+    Vb[(4 * a + 1) * 512] = lo[1] + hi[0];
+    Vb[(4 * a + 2) * 512] = hi[0] - lo[1];
+    Vb[(4 * a + 3) * 512] = lo[1] - hi[1];
   };
   // ---- U chunk: 32 KB contiguous in global, by DMA (8 waves x 4 x 1 KB) ----
-  // (uniform base + 32-bit lane offset: no loop-invariant 64-bit address register per lane)
+  // (uniform base + 32-bit lane offset: no 64-bit address arithmetic per lane)
   const float* ubase = wp.wu + (size_t)((p.n_off / WN_BN + tn) * chunks) * WN_BUF;
   const int uwave = __builtin_amdgcn_readfirstlane(wave) * 1024;
-  auto dma_u = [&](int chunk, float* Ub, auto ic) {   // piece i of this wave's four
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned u_m0 = __builtin_amdgcn_readfirstlane(lds_addr(Us + uwave));
+  auto dma_u = [&](int chunk, auto bc, auto ic) {   // piece i of this wave's four, into U stage bc
     constexpr int i = decltype(ic)::value;
-    const float* src = ubase + (size_t)chunk * WN_BUF + uwave;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + i * 256 + lane * 4),
-        (__attribute__((address_space(3))) void*)(Ub + uwave + i * 256), 16, 0, 0);
+    constexpr int B = decltype(bc)::value;
+    const float* src = ubase + (size_t)chunk * WN_BUF + uwave;          // (scalar)
+    const unsigned m0v = u_m0 + B * WN_BUF * 4;
+    // global_load_lds_dwordx4, scalar base + lane offset form; M0 = LDS base of the wave's part
+    // of the stage; the instruction offset (piece i) applies to the global AND the LDS address
+    dma16_sbase<i * 1024>(m0v, lane16, src);
   };
 
   // ---- MFMA fragments: wave -> tiles 16 tg .. +15, output channels 32 nh .. +31 ----
   const int tg = wave & 3, nh = wave >> 2;
   const int fm = lane & 15, fk = lane >> 4;
   const int fsw = 2 * (fk ^ ((fm >> 2) & 3));
-  const int a_off = (16 * tg + fm) * 8 + fsw;
-  const int b_off = (32 * nh + fm) * 8 + fsw;
+  const unsigned va = lds_addr(Vs + (16 * tg + fm) * 8 + fsw);   // this lane's byte addresses
+  const unsigned ub = lds_addr(Us + (32 * nh + fm) * 8 + fsw);
   f32x4 acc[16][2];
 #pragma unroll
   for (int x = 0; x < 16; ++x)
@@ -252,12 +336,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   // variant has no registers to spare: one set, read right behind the MFMAs that used it)
   constexpr int FS = UP ? 1 : 2;
   f32x2v fa[FS], fb0[FS], fb1[FS];
-  auto frag = [&](const float* Vb, const float* Ub, auto xc) {
+  auto frag = [&](auto bc, auto xc) {
     constexpr int x = decltype(xc)::value;
+    constexpr int B = decltype(bc)::value;
     constexpr int sl = x % FS;
-    fa[sl] = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
-    fb0[sl] = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off);
-    fb1[sl] = *reinterpret_cast<const f32x2v*>(Ub + x * 512 + b_off + 128);
+    fa[sl] = lds_rd64<(B * WN_BUF + x * 512) * 4>(va);
+    fb0[sl] = lds_rd64<(B * WN_BUF + x * 512) * 4>(ub);
+    fb1[sl] = lds_rd64<(B * WN_BUF + x * 512 + 128) * 4>(ub);
   };
   auto mm = [&](auto xc) {
     constexpr int x = decltype(xc)::value;
@@ -267,68 +352,99 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb0[sl][1], acc[x][0], 0, 0, 0);
     acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb1[sl][1], acc[x][1], 0, 0, 0);
   };
-  // one stage: with two fragment sets the reads of xi + 1 are issued BEFORE the MFMAs of xi
-  auto stage = [&](const float* Vb, const float* Ub, auto xc) {
+  // One stage = one xi.  Two fragment sets: the reads of xi + 1 (and, in the transform stages,
+  // the four raw-patch reads of a transform row: TR) are issued FIRST, then the wait for the
+  // fragments of xi (issued a stage ago: everything but the newest 3 + 4 reads), then the four
+  // MFMAs - which cover the LDS round trip of what was just issued.
+  auto stage = [&](auto bc, auto xc, auto trc) {
     constexpr int x = decltype(xc)::value;
+    constexpr int TR = decltype(trc)::value;     // 4 = a transform row was read ahead of the fragments
+    constexpr int sl = x % FS;
     if constexpr (FS == 2) {
-      // the reads FIRST and fenced there: issued at the end of a stage (where hipcc likes to sink
-      // them) the next stage's wait drains the whole LDS queue - its own stores included
-      if constexpr (x + 1 < 16) frag(Vb, Ub, wn_ic<x + 1>{});
+      if constexpr (x + 1 < 16) frag(bc, wn_ic<x + 1>{});
+      lds_wait<(x + 1 < 16 ? 3 : 0) + TR>(fa[sl], fb0[sl], fb1[sl]);
       __builtin_amdgcn_sched_barrier(0);
       mm(xc);
     } else {
+      lds_wait<0>(fa[sl], fb0[sl], fb1[sl]);
+      __builtin_amdgcn_sched_barrier(0);
       mm(xc);
-      if constexpr (x + 1 < 16) frag(Vb, Ub, wn_ic<x + 1>{});
+      if constexpr (x + 1 < 16) frag(bc, wn_ic<x + 1>{});
     }
   };
 
   // ---- prologue: chunk 0 transformed, chunk 1 raw in LDS, chunk 2 in the registers ----
-  constexpr int RB = WN_KC * WN_RP;
   auto cl = [&](int c) { return c < chunks ? c : chunks - 1; };   // the tail re-stages the last chunk
+  // (the coefficient loads and the DMA are not tracked by the compiler: explicit waits)
+  auto vm_done = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    reg_anchor(ca, cb);
+  };
   load_raw(0, wn_ic<0>{});
   load_raw(0, wn_ic<1>{});
-  wn_for<0, 4>([&](auto ic) { dma_u(0, Us, ic); });
-  store_raw(wn_ic<0>{}, Rs);
-  store_raw(wn_ic<1>{}, Rs);
+  wn_for<0, 4>([&](auto ic) { dma_u(0, wn_ic<0>{}, ic); });
+  vm_done();
+  store_raw(wn_ic<0>{}, wn_ic<0>{});
+  store_raw(wn_ic<1>{}, wn_ic<0>{});
   load_raw(cl(1), wn_ic<0>{});
   load_raw(cl(1), wn_ic<1>{});
   __syncthreads();
-  wn_for<0, 4>([&](auto ac) { t_row(ac, Rs, Vs); });
-  store_raw(wn_ic<0>{}, Rs + RB);
-  store_raw(wn_ic<1>{}, Rs + RB);
+  wn_for<0, 4>([&](auto ac) {
+    t_rd(ac, wn_ic<0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_wr(ac, wn_ic<0>{});
+  });
+  vm_done();
+  store_raw(wn_ic<0>{}, wn_ic<1>{});
+  store_raw(wn_ic<1>{}, wn_ic<1>{});
   load_raw(cl(2), wn_ic<0>{});
   load_raw(cl(2), wn_ic<1>{});
-  for (int c = 0; c < chunks; ++c) {
-    const int buf = c & 1;
-    const float* Vb = Vs + buf * WN_BUF;
-    const float* Ub = Us + buf * WN_BUF;
-    float* Vn = Vs + (buf ^ 1) * WN_BUF;
-    float* Un = Us + (buf ^ 1) * WN_BUF;
-    float* Rw = Rs + buf * RB;                 // raw patch of chunk c + 2 goes here
-    const float* Rr = Rs + (buf ^ 1) * RB;     // raw patch of chunk c + 1 (stored an iteration ago)
-    // Branch-free body, ONE barrier per chunk.  One stage per xi: its 4 MFMAs, the fragment reads
-    // of the next xi, and one piece of the staging pipeline, three chunks deep: the raw patch of
-    // chunk c + 2 from the registers to LDS, the loads of chunk c + 3, U of chunk c + 1 by DMA,
-    // the input transform of chunk c + 1 (raw patch double-buffered, so it needs no barrier of
-    // its own) - each stage fenced so nothing bunches up.
-    // At the barrier: every DMA of this wave has landed, every wave is done with stage buf ^ 1,
-    // with raw buffer `buf` (transformed an iteration ago) and has written raw buffer buf ^ 1.
-    // (bare s_barrier: __syncthreads() adds nothing we need)
+  // One chunk, stages of parity B (compile time: every LDS offset of the body is an immediate).
+  // Branch-free, ONE barrier.  One stage per xi: its 4 MFMAs, the fragment reads of the next xi,
+  // and one piece of the staging pipeline, three chunks deep: the raw patch of chunk c + 2 from
+  // the registers to LDS, the loads of chunk c + 3, U of chunk c + 1 by DMA, the input
+  // transform of chunk c + 1 (raw patch double-buffered, so it needs no barrier of its own) -
+  // each stage fenced so nothing bunches up.
+  // At the barrier: every DMA of this wave has landed, every wave is done with stage B ^ 1, with
+  // raw buffer B (transformed an iteration ago) and has written raw buffer B ^ 1.
+  // (bare s_barrier: __syncthreads() adds nothing we need)
+  auto chunk_body = [&](int c, auto bc) {
+    constexpr int B = decltype(bc)::value;
+    using NB = wn_ic<B ^ 1>;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    frag(Vb, Ub, wn_ic<0>{});
+    reg_anchor(ca, cb);   // (the coefficients are behind the wait)
+    frag(bc, wn_ic<0>{});
     wn_for<0, 16>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
-      stage(Vb, Ub, xc);
-      if constexpr (x == 0) store_raw(wn_ic<0>{}, Rw);       // chunk c + 2 (loaded an iteration ago)
+      if constexpr (FS == 2) {
+        // transform row x - 8 of chunk c + 1: read ahead of this stage's MFMAs, combined and
+        // written behind them
+        constexpr bool T = x >= 8 && x < 12;
+        if constexpr (T) t_rd(wn_ic<(T ? x - 8 : 0)>{}, NB{});
+        stage(bc, xc, wn_ic<(T ? 4 : 0)>{});
+        if constexpr (T) {
+          lds_wait<3>(tr[0], tr[1], tr[2], tr[3]);     // (only the fragment reads stay in flight)
+          t_wr(wn_ic<(T ? x - 8 : 0)>{}, NB{});
+        }
+      } else {
+        // one fragment set: the row is read behind stage x - 1's MFMAs (with the fragments of
+        // xi) and written behind this stage's, whose initial wait covers both
+        stage(bc, xc, wn_ic<0>{});
+        if constexpr (x >= 8 && x < 12) t_wr(wn_ic<(x >= 8 && x < 12 ? x - 8 : 0)>{}, NB{});
+        if constexpr (x >= 7 && x < 11) t_rd(wn_ic<(x >= 7 && x < 11 ? x - 7 : 0)>{}, NB{});
+      }
+      if constexpr (x == 0) store_raw(wn_ic<0>{}, bc);        // chunk c + 2 (loaded an iteration ago)
       if constexpr (x == 1) load_raw(cl(c + 3), wn_ic<0>{});
-      if constexpr (x == 2) store_raw(wn_ic<1>{}, Rw);
+      if constexpr (x == 2) store_raw(wn_ic<1>{}, bc);
       if constexpr (x == 3) load_raw(cl(c + 3), wn_ic<1>{});
-      if constexpr (x >= 4 && x < 8) dma_u(cl(c + 1), Un, wn_ic<x - 4>{});
-      if constexpr (x >= 8 && x < 12) t_row(wn_ic<x - 8>{}, Rr, Vn);
+      if constexpr (x >= 4 && x < 8) dma_u(cl(c + 1), NB{}, wn_ic<x - 4>{});
       __builtin_amdgcn_sched_barrier(0);
     });
+  };
+  for (int c = 0; c < chunks; c += 2) {
+    chunk_body(c, wn_ic<0>{});
+    if (c + 1 < chunks) chunk_body(c + 1, wn_ic<1>{});
   }
 
   // ---- epilogue: Y = A^T M A per (tile, channel), register-local ----
