@@ -16,10 +16,12 @@
 // Replaces the weight-gradient half of aten::convolution_backward reached from
 // loss.backward() (Our_UNet/src/train.py:663).
 #include "conv_params.h"
+#include "lds_asm.h"
 #include <utility>
 
 namespace {
 using unet_conv::act4;
+using unet_conv::act4f;
 template <int I> using template_ic = std::integral_constant<int, I>;
 // compile-time loop: f(integral_constant<int, I>) for I in [B, E)
 template <int B, int... I, typename F>
@@ -1104,6 +1106,13 @@ constexpr int WW_XP = 4 * 18, WW_DP = 2 * 16;          // staged pixels of x / d
 constexpr int WW_BUF = 16 * 512;                        // floats of one V / E stage
 constexpr size_t WW_LDS = (size_t)(4 * WW_BUF + (WW_XP + WW_DP) * 64) * sizeof(float);
 
+// The K loop is written for instruction count (lds_asm.h): loop-invariant lane offsets + scalar
+// chunk offsets for every global load, the chunk cursor (n, tile row, chunk column) advanced
+// with scalar compares, transforms as single v_add / v_sub (hipcc's v_pk_add_f32 forms cost
+// twice as much and a v_mov per operand pair), the 1/2 factors of G e G^T deferred to the
+// epilogue (exact: powers of two), LDS reads issued ahead of a stage's MFMAs and consumed behind
+// them, every LDS offset an immediate (the chunk body is instantiated per stage parity and per
+// transform half of the wave).
 template <bool ACT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1111,7 +1120,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
   float* Es = smem + 2 * WW_BUF;          // [buf][xi][pair 4][co 64][2]
   float* Rx = smem + 4 * WW_BUF;          // [pixel 72][ci 64]
   float* Rd = Rx + WW_XP * 64;            // [pixel 32][co 64]
-  typedef float f32x2v __attribute__((ext_vector_type(2)));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
@@ -1123,180 +1131,253 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
   const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
   const int cw = p.W >> 4, th = p.H >> 1;      // chunks per tile row, tile rows per image
 
+  // descriptors: x starts one image row + one pixel early, so the scalar offset of a chunk
+  // (its window starts at row 2 tr - 1, column 16 cc - 1) is never negative
+  const int xshift = (p.W + 1) * p.Cx;
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+      const_cast<float*>(p.x) - xshift, 0, (int)(p.x_bytes + 4u * (unsigned)xshift), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 
   // ---- raw slots: x 72 pixels x 16 channel groups = 1152 (thread: tid, +512, +1024 < 1152),
-  //      dy 32 x 16 = 512 (one per thread); the channel group is tid & 15 for every slot
+  //      dy 32 x 16 = 512 (one per thread); the channel group is tid & 15 for every slot.
+  //      Per slot: the lane's byte offset inside a chunk window and the border flags of its
+  //      window position (top row, bottom row, left column, right column, no such slot) ----
   const int grp4 = (tid & 15) * 4;
-  int x_pix[3];
+  unsigned voffx[3], fx[3];
+  float* xdst[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) x_pix[i] = (tid + 512 * i) >> 4;      // 0..95 (>= 72: no slot)
+  for (int i = 0; i < 3; ++i) {
+    const int pix = (tid + 512 * i) >> 4;                     // 0..95 (>= 72: no slot)
+    const int prow = pix / 18, pcol = pix - prow * 18;
+    voffx[i] = (unsigned)((prow * p.W + pcol) * p.Cx + ci0 + grp4) * 4u;
+    fx[i] = (prow == 0 ? 1u : 0u) | (prow == 3 ? 2u : 0u) | (pcol == 0 ? 4u : 0u) |
+            (pcol == 17 ? 8u : 0u) | (pix >= WW_XP ? 16u : 0u);
+    xdst[i] = Rx + (pix < WW_XP ? pix : 0) * 64 + grp4;
+  }
+  const bool slot2 = tid + 1024 < WW_XP * 16;
   const int d_pixl = tid >> 4;                                      // 0..31
+  const unsigned voffd = (unsigned)(((d_pixl >> 4) * p.W + (d_pixl & 15)) * p.Cout + co0 + grp4) * 4u;
+  float* const ddst = Rd + d_pixl * 64 + grp4;
   f32x4 rx[3], rd;
+  float okf[3] = {1.f, 1.f, 1.f};
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
-  unsigned okm = 0;
-  auto load_raw = [&](int g) {
-    const int cc = g % cw;
-    const int r = g / cw;
-    const int tr = r % th, n = r / th;
-    okm = 0;
+  // chunk cursor of the loader (scalar): chunk column, tile row, image
+  int l_cc, l_tr, l_n, l_g = g_begin;
+  {
+    const int r = g_begin / cw;
+    l_cc = g_begin - r * cw;
+    l_n = r / th;
+    l_tr = r - l_n * th;
+  }
+  auto load_raw = [&]() {     // loads chunk l_g, then advances the cursor (the tail re-loads the last chunk)
+    const unsigned m = (l_tr == 0 ? 1u : 0u) | (l_tr == th - 1 ? 2u : 0u) | (l_cc == 0 ? 4u : 0u) |
+                       (l_cc == cw - 1 ? 8u : 0u) | 16u;
+    const int pixbase = (l_n * p.H + 2 * l_tr) * p.W + 16 * l_cc;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int prow = x_pix[i] / 18, pcol = x_pix[i] - prow * 18;
-      const int iy = 2 * tr - 1 + prow, ix = 16 * cc - 1 + pcol;
-      const bool ok = x_pix[i] < WW_XP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      okm |= (ok ? 1u : 0u) << i;
-      rx[i] = buf_ld4<float>(rsx, (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cx + ci0 + grp4),
-                             ok ? 0u : 0x80000000u);
+      const bool ok = (fx[i] & m) == 0u;
+      okf[i] = ok ? 1.f : 0.f;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsx, ok ? voffx[i] : 0x80000000u, pixbase * p.Cx * 4, 0));
     }
-    {
-      const int oy = 2 * tr + (d_pixl >> 4), ox = 16 * cc + (d_pixl & 15);
-      rd = buf_ld4<float>(rsd, (unsigned)(((n * p.H + oy) * p.W + ox) * p.Cout + co0 + grp4), 0u);
-    }
+    rd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, voffd,
+                                                                          pixbase * p.Cout * 4, 0));
     if (ACT) {   // the loaded coefficients are only looked at when the patch is stored
-      const size_t o = (size_t)n * p.Cx + ci0 + grp4;
-      ca = *reinterpret_cast<const f32x4*>(p.alpha + o);
-      cb = *reinterpret_cast<const f32x4*>(p.beta + o);
+      const size_t o = (size_t)l_n * p.Cx + ci0;
+      gld4_sbase(ca, (unsigned)grp4 * 4u, p.alpha + o);
+      gld4_sbase(cb, (unsigned)grp4 * 4u, p.beta + o);
+    }
+    if (l_g + 1 < g_end) {     // uniform
+      ++l_g;
+      if (++l_cc == cw) { l_cc = 0; if (++l_tr == th) { l_tr = 0; ++l_n; } }
     }
   };
   auto store_x = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
     f32x4 v = rx[i];
-    if (ACT) v = act4(v, ca, cb, p.slope, (okm >> i) & 1u);
-    if (i < 2 || tid + 1024 < WW_XP * 16)
-      *reinterpret_cast<f32x4*>(Rx + x_pix[i] * 64 + grp4) = v;
+    if (ACT) v = act4f(v, ca, cb, p.slope, okf[i]);
+    if (i < 2 || slot2) *reinterpret_cast<f32x4*>(xdst[i]) = v;
   };
-  auto store_d = [&]() { *reinterpret_cast<f32x4*>(Rd + d_pixl * 64 + grp4) = rd; };
+  auto store_d = [&]() { *reinterpret_cast<f32x4*>(ddst) = rd; };
 
   // ---- transforms: thread -> (channel = lane, tile pair = wave & 3, xi rows {2h, 2h+1}) ----
-  const int t_pair = wave & 3, t_half = wave >> 2;
+  const int t_pair = wave & 3;
+  const int t_half = __builtin_amdgcn_readfirstlane(wave >> 2);
+  const unsigned t_xa = lds_addr(Rx + (4 * t_pair) * 64 + lane);   // window columns 4 pair .. +5
+  const unsigned t_da = lds_addr(Rd + (4 * t_pair) * 64 + lane);   // dy columns 4 pair .. +3
   const int t_off = t_pair * 128 + ((lane * 2) ^ (32 * (t_pair & 1)));
-  // one xi row a of V = B^T d B for the two tiles of the pair: combine two window rows over the
-  // pair's 6 columns, column pass per tile, two 8-byte writes per xi
-  auto t_v = [&](auto ac, float* Vb) {
-    constexpr int a = decltype(ac)::value;                       // 0..3
+  float* const t_vdst = Vs + t_off;
+  float* const t_edst = Es + t_off;
+  f32x2v tq[6];      // what a transform piece read ahead of its stage's MFMAs
+  // V = B^T d B, xi row a, for the two tiles of the pair: tv_rd reads the two window rows the
+  // row combines over the pair's 6 columns (one ds_read2st64_b32 per column), tv_wr combines
+  // them, runs the column pass per tile and writes four 8-byte (tile pair) values
+  auto tv_rd = [&](auto ac) {
+    constexpr int a = decltype(ac)::value;
     constexpr int r0 = a == 0 ? 0 : (a == 1 ? 1 : (a == 2 ? 2 : 3));
     constexpr int r1 = a == 0 ? 2 : (a == 1 ? 2 : 1);
-    const float* src = Rx + (4 * t_pair) * 64 + lane;
+    tq[0] = lds_rd2st64<r0 * 18 + 0, r1 * 18 + 0>(t_xa);
+    tq[1] = lds_rd2st64<r0 * 18 + 1, r1 * 18 + 1>(t_xa);
+    tq[2] = lds_rd2st64<r0 * 18 + 2, r1 * 18 + 2>(t_xa);
+    tq[3] = lds_rd2st64<r0 * 18 + 3, r1 * 18 + 3>(t_xa);
+    tq[4] = lds_rd2st64<r0 * 18 + 4, r1 * 18 + 4>(t_xa);
+    tq[5] = lds_rd2st64<r0 * 18 + 5, r1 * 18 + 5>(t_xa);
+  };
+  auto tv_wr = [&](auto ac, auto bc) {
+    constexpr int a = decltype(ac)::value;
+    constexpr int B = decltype(bc)::value;
     float c[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const float u0 = src[(r0 * 18 + j) * 64], u1 = src[(r1 * 18 + j) * 64];
-      c[j] = a == 1 ? u0 + u1 : u0 - u1;
-    }
-    float* dst = Vb + (4 * a) * 512 + t_off;
-    *reinterpret_cast<f32x2v*>(dst) = f32x2v{c[0] - c[2], c[2] - c[4]};
-    *reinterpret_cast<f32x2v*>(dst + 512) = f32x2v{c[1] + c[2], c[3] + c[4]};
-    *reinterpret_cast<f32x2v*>(dst + 1024) = f32x2v{c[2] - c[1], c[4] - c[3]};
-    *reinterpret_cast<f32x2v*>(dst + 1536) = f32x2v{c[3] - c[1], c[5] - c[3]};
+    for (int j = 0; j < 6; ++j) c[j] = a == 1 ? vadd(tq[j][0], tq[j][1]) : vsub(tq[j][0], tq[j][1]);
+    float* dst = t_vdst + B * WW_BUF + (4 * a) * 512;
+    *reinterpret_cast<f32x2v*>(dst) = f32x2v{vsub(c[0], c[2]), vsub(c[2], c[4])};
+    *reinterpret_cast<f32x2v*>(dst + 512) = f32x2v{vadd(c[1], c[2]), vadd(c[3], c[4])};
+    *reinterpret_cast<f32x2v*>(dst + 1024) = f32x2v{vsub(c[2], c[1]), vsub(c[4], c[3])};
+    *reinterpret_cast<f32x2v*>(dst + 1536) = f32x2v{vsub(c[3], c[1]), vsub(c[5], c[3])};
   };
-  // one xi row a of E = G e G^T for the two tiles of the pair (4 dy columns)
-  auto t_e = [&](auto ac, float* Eb) {
+  // E = G e G^T WITHOUT its factors 1/2 (rows / columns 1 and 2 carry one each: the epilogue
+  // scales M_xi instead - exact), xi row a, for the two tiles of the pair (4 dy columns)
+  auto te_rd = [&](auto ac) {
     constexpr int a = decltype(ac)::value;
-    const float* src = Rd + (4 * t_pair) * 64 + lane;
-    float gq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float e0 = src[j * 64], e1 = src[(16 + j) * 64];
-      gq[j] = a == 0 ? e0 : (a == 1 ? 0.5f * (e0 + e1) : (a == 2 ? 0.5f * (e0 - e1) : e1));
+    if constexpr (a == 0) {            // e0 only
+      tq[0] = lds_rd2st64<0, 1>(t_da);
+      tq[1] = lds_rd2st64<2, 3>(t_da);
+    } else if constexpr (a == 3) {     // e1 only
+      tq[0] = lds_rd2st64<16, 17>(t_da);
+      tq[1] = lds_rd2st64<18, 19>(t_da);
+    } else {                           // (e0, e1) per column
+      tq[0] = lds_rd2st64<0, 16>(t_da);
+      tq[1] = lds_rd2st64<1, 17>(t_da);
+      tq[2] = lds_rd2st64<2, 18>(t_da);
+      tq[3] = lds_rd2st64<3, 19>(t_da);
     }
-    float* dst = Eb + (4 * a) * 512 + t_off;
+  };
+  auto te_wr = [&](auto ac, auto bc) {
+    constexpr int a = decltype(ac)::value;
+    constexpr int B = decltype(bc)::value;
+    float gq[4];
+    if constexpr (a == 0 || a == 3) {
+      gq[0] = tq[0][0]; gq[1] = tq[0][1]; gq[2] = tq[1][0]; gq[3] = tq[1][1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gq[j] = a == 1 ? vadd(tq[j][0], tq[j][1]) : vsub(tq[j][0], tq[j][1]);
+    }
+    float* dst = t_edst + B * WW_BUF + (4 * a) * 512;
     *reinterpret_cast<f32x2v*>(dst) = f32x2v{gq[0], gq[2]};
-    *reinterpret_cast<f32x2v*>(dst + 512) = f32x2v{0.5f * (gq[0] + gq[1]), 0.5f * (gq[2] + gq[3])};
-    *reinterpret_cast<f32x2v*>(dst + 1024) = f32x2v{0.5f * (gq[0] - gq[1]), 0.5f * (gq[2] - gq[3])};
+    *reinterpret_cast<f32x2v*>(dst + 512) = f32x2v{vadd(gq[0], gq[1]), vadd(gq[2], gq[3])};
+    *reinterpret_cast<f32x2v*>(dst + 1024) = f32x2v{vsub(gq[0], gq[1]), vsub(gq[2], gq[3])};
     *reinterpret_cast<f32x2v*>(dst + 1536) = f32x2v{gq[1], gq[3]};
   };
-  // the four transform pieces of this thread (its two xi rows of both operands)
-  auto t_piece = [&](auto kc, float* Vb, float* Eb) {
-    constexpr int k = decltype(kc)::value;
-    if (t_half == 0) {          // uniform per wave
-      if constexpr (k == 0) t_v(template_ic<0>{}, Vb);
-      if constexpr (k == 1) t_v(template_ic<1>{}, Vb);
-      if constexpr (k == 2) t_e(template_ic<0>{}, Eb);
-      if constexpr (k == 3) t_e(template_ic<1>{}, Eb);
-    } else {
-      if constexpr (k == 0) t_v(template_ic<2>{}, Vb);
-      if constexpr (k == 1) t_v(template_ic<3>{}, Vb);
-      if constexpr (k == 2) t_e(template_ic<2>{}, Eb);
-      if constexpr (k == 3) t_e(template_ic<3>{}, Eb);
-    }
+  // the four transform pieces of a thread: its two xi rows (2 half, 2 half + 1) of both operands
+  auto t_reads = [&](auto kc, auto hc) -> int {      // returns nothing useful; NR below
+    constexpr int k = decltype(kc)::value, h = decltype(hc)::value;
+    if constexpr (k < 2) tv_rd(template_ic<2 * h + k>{}); else te_rd(template_ic<2 * h + k - 2>{});
+    return 0;
+  };
+  auto t_writes = [&](auto kc, auto hc, auto bc) {
+    constexpr int k = decltype(kc)::value, h = decltype(hc)::value;
+    if constexpr (k < 2) tv_wr(template_ic<2 * h + k>{}, bc); else te_wr(template_ic<2 * h + k - 2>{}, bc);
   };
 
   // ---- MFMA fragments: wave -> ci rows 16 tg .. +15, co columns 32 nh .. +31 ----
   const int tg = wave & 3, nh = wave >> 2;
   const int fm = lane & 15, fk = lane >> 4;
-  const int a_off = fk * 128 + (((16 * tg + fm) * 2) ^ (32 * (fk & 1)));
-  const int b_off = fk * 128 + (((32 * nh + fm) * 2) ^ (32 * (fk & 1)));
-  const int b_off1 = fk * 128 + (((32 * nh + 16 + fm) * 2) ^ (32 * (fk & 1)));
+  const unsigned va = lds_addr(Vs + fk * 128 + (((16 * tg + fm) * 2) ^ (32 * (fk & 1))));
+  const unsigned eb0 = lds_addr(Es + fk * 128 + (((32 * nh + fm) * 2) ^ (32 * (fk & 1))));
+  const unsigned eb1 = lds_addr(Es + fk * 128 + (((32 * nh + 16 + fm) * 2) ^ (32 * (fk & 1))));
   f32x4 acc[16][2];
 #pragma unroll
   for (int x = 0; x < 16; ++x)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fragments of one xi; the next xi's are read right behind its MFMAs (measured: reading them
-  // one stage ahead into a second register set, fenced or not, is 2-4 % slower in this kernel,
-  // whose stages carry 16-byte LDS stores)
-  f32x2v fa, fb0, fb1;
-  auto frag = [&](const float* Vb, const float* Eb, int x) {
-    fa = *reinterpret_cast<const f32x2v*>(Vb + x * 512 + a_off);
-    fb0 = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off);
-    fb1 = *reinterpret_cast<const f32x2v*>(Eb + x * 512 + b_off1);
+  // two fragment sets: the reads of xi + 1 are issued ahead of the MFMAs of xi
+  f32x2v fa[2], fb0[2], fb1[2];
+  auto frag = [&](auto bc, auto xc) {
+    constexpr int x = decltype(xc)::value, B = decltype(bc)::value, sl = x & 1;
+    fa[sl] = lds_rd64<(B * WW_BUF + x * 512) * 4>(va);
+    fb0[sl] = lds_rd64<(B * WW_BUF + x * 512) * 4>(eb0);
+    fb1[sl] = lds_rd64<(B * WW_BUF + x * 512) * 4>(eb1);
   };
   auto mm = [&](auto xc) {
-    constexpr int x = decltype(xc)::value;
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb0[0], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb1[0], acc[x][1], 0, 0, 0);
-    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb0[1], acc[x][0], 0, 0, 0);
-    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb1[1], acc[x][1], 0, 0, 0);
+    constexpr int x = decltype(xc)::value, sl = x & 1;
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb0[sl][0], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][0], fb1[sl][0], acc[x][1], 0, 0, 0);
+    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb0[sl][1], acc[x][0], 0, 0, 0);
+    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][1], fb1[sl][1], acc[x][1], 0, 0, 0);
   };
+  // reads a transform piece issues ahead of its stage (piece k of half h)
+  auto n_reads = [](int k, int h) { return k < 2 ? 6 : ((2 * h + k - 2) % 3 == 0 ? 2 : 4); };
 
-  if (g_begin < g_end) {
+  // One chunk on stage parity B by a wave of transform half HF: stage B is complete at the first
+  // barrier; xi 0..7 carry the raw stores of chunk g + 1 (loaded an iteration ago) and the loads
+  // of chunk g + 2; after the second barrier (raw chunk g + 1 complete) xi 8..11 carry its
+  // transform into stage B ^ 1.
+  auto chunk_body = [&](auto bc, auto hc) {
+    constexpr int B = decltype(bc)::value, HF = decltype(hc)::value;
+    using NB = template_ic<B ^ 1>;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    reg_anchor(ca, cb);
+    frag(bc, template_ic<0>{});
+    for_range<0, 16>([&](auto xc) {
+      constexpr int x = decltype(xc)::value;
+      constexpr bool T = x >= 8 && x < 12;
+      constexpr int NR = T ? n_reads(T ? x - 8 : 0, HF) : 0;
+      if constexpr (x == 8) {      // raw chunk g + 1 complete (LDS only; the fragments of xi 8 in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (T) t_reads(template_ic<(T ? x - 8 : 0)>{}, hc);
+      if constexpr (x + 1 < 16) frag(bc, template_ic<x + 1>{});
+      lds_wait<(x + 1 < 16 ? 3 : 0) + NR>(fa[x & 1], fb0[x & 1], fb1[x & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(xc);
+      if constexpr (T) {
+        lds_wait6<3>(tq[0], tq[1], tq[2], tq[3], tq[4], tq[5]);   // (only fragment reads in flight)
+        t_writes(template_ic<(T ? x - 8 : 0)>{}, hc, NB{});
+      }
+      if constexpr (x < 3) store_x(template_ic<(x < 3 ? x : 0)>{});   // chunk g + 1
+      if constexpr (x == 3) store_d();
+      if constexpr (x == 4) load_raw();
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  auto k_loop = [&](auto hc) {
     // prologue: chunk 0 transformed into stage 0, chunk 1 in the registers
-    load_raw(g_begin);
+    load_raw();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    reg_anchor(ca, cb);
     for_range<0, 3>(store_x);
     store_d();
-    load_raw(g_begin + 1 < g_end ? g_begin + 1 : g_begin);
+    load_raw();
     __syncthreads();
-    for_range<0, 4>([&](auto kc) { t_piece(kc, Vs, Es); });
-    for (int g = g_begin; g < g_end; ++g) {
-      const int buf = (g - g_begin) & 1;
-      const float* Vb = Vs + buf * WW_BUF;
-      const float* Eb = Es + buf * WW_BUF;
-      float* Vn = Vs + (buf ^ 1) * WW_BUF;
-      float* En = Es + (buf ^ 1) * WW_BUF;
-      const int g2 = g + 2 < g_end ? g + 2 : g_end - 1;   // branch-free tail: re-stage the last chunk
-      // stage buf is complete, every wave is done with stage buf ^ 1 and with the raw buffers
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      frag(Vb, Eb, 0);
-      for_range<0, 8>([&](auto xc) {
-        constexpr int x = decltype(xc)::value;
-        mm(xc);
-        frag(Vb, Eb, x + 1);
-        if constexpr (x < 3) store_x(template_ic<x>{});   // chunk g + 1 (loaded an iteration ago)
-        if constexpr (x == 3) store_d();
-        if constexpr (x == 4) load_raw(g2);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw chunk g + 1 complete (LDS only)
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      for_range<8, 16>([&](auto xc) {
-        constexpr int x = decltype(xc)::value;
-        mm(xc);
-        if constexpr (x + 1 < 16) frag(Vb, Eb, x + 1);
-        if constexpr (x < 12) t_piece(template_ic<x - 8>{}, Vn, En);
-        __builtin_amdgcn_sched_barrier(0);
-      });
+    for_range<0, 4>([&](auto kc) {
+      t_reads(kc, hc);
+      lds_wait6<0>(tq[0], tq[1], tq[2], tq[3], tq[4], tq[5]);
+      t_writes(kc, hc, template_ic<0>{});
+    });
+    for (int g = g_begin; g < g_end; g += 2) {
+      chunk_body(template_ic<0>{}, hc);
+      if (g + 1 < g_end) chunk_body(template_ic<1>{}, hc);
     }
+  };
+  if (g_begin < g_end) {
+    if (t_half == 0) k_loop(template_ic<0>{}); else k_loop(template_ic<1>{});   // (scalar branch)
   }
 
   // ---- epilogue: dW = A^T M A per (ci, co), register-local; lane holds ci = 16 tg + 4 fk + r,
-  //      co = 32 nh + 16 b + fm ----
+  //      co = 32 nh + 16 b + fm.  M_xi first gets the factors of G e G^T the transform left out:
+  //      1/2 per xi row / column 1 or 2 ----
+#pragma unroll
+  for (int x = 0; x < 16; ++x) {
+    const float sc = (((x >> 2) == 1 || (x >> 2) == 2) ? 0.5f : 1.f) * (((x & 3) == 1 || (x & 3) == 2) ? 0.5f : 1.f);
+    if (sc != 1.f) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[x][b] *= sc;
+    }
+  }
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll

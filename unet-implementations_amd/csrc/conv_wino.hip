@@ -31,12 +31,12 @@
 // (Our_UNet/models/unet.py:106-115), reached through unet_conv_in_fwd_wino /
 // unet_conv3x3_bwd_data_bs_wino.
 #include "conv_params.h"
+#include "lds_asm.h"
 #include <utility>
 
 namespace unet_conv {
 namespace {
 
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <int I> using wn_ic = std::integral_constant<int, I>;
 template <int B, int... I, typename F>
 __device__ __forceinline__ void wn_for_impl(std::integer_sequence<int, I...>, F&& f) {
@@ -45,47 +45,6 @@ __device__ __forceinline__ void wn_for_impl(std::integer_sequence<int, I...>, F&
 template <int B, int E, typename F>   // compile-time loop: f(integral_constant<int, I>), I in [B, E)
 __device__ __forceinline__ void wn_for(F&& f) {
   wn_for_impl<B>(std::make_integer_sequence<int, E - B>{}, f);
-}
-
-// Plain ds_read_b64 by hand.  hipcc fuses neighbouring 8-byte LDS reads into ds_read2(st64)_b64,
-// which the LDS serves at HALF the rate (8 array cycles per wave-instruction for 1 KB against
-// 2 for the 512 B of a ds_read_b64: MI355X guide, LDS table) - and these kernels keep the LDS
-// array busy for two thirds of their matrix time.  The compiler does not track the counter of
-// an asm read: lds_wait() is the s_waitcnt, tied to the registers it guards so that their uses
-// stay behind it.  (Its own waits stay valid: LDS returns in order, more reads in flight only
-// make a counted wait longer.)
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
-}
-template <int OFF>
-__device__ __forceinline__ f32x2v lds_rd64(unsigned a) {
-  f32x2v v;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(f32x2v& a, f32x2v& b, f32x2v& c) {
-  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(f32x2v& a, f32x2v& b, f32x2v& c, f32x2v& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
-}
-
-// 16 bytes from (scalar base + 32-bit lane offset), untracked like the LDS reads above (hipcc
-// builds a 64-bit VALU address per load instead); the consumer sits behind an s_waitcnt vmcnt(0)
-__device__ __forceinline__ void gld4_sbase(f32x4& v, unsigned lane_off, const float* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(lane_off), "s"(sbase) : "memory");
-}
-// global -> LDS DMA of 16 bytes per lane: LDS base of the piece in M0, scalar base + lane offset
-// (M0 has no other user in these kernels: gfx9 LDS instructions do not read it)
-template <int OFF>
-__device__ __forceinline__ void dma16_sbase(unsigned m0v, unsigned lane_off, const float* sbase) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
-               :: "s"(m0v), "v"(lane_off), "s"(sbase), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ void reg_anchor(f32x4& a, f32x4& b) {
-  asm volatile("" : "+v"(a), "+v"(b) :: "memory");
 }
 
 constexpr int WN_TH = 8, WN_TW = 32;        // output pixels of a workgroup
