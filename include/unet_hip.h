@@ -529,6 +529,18 @@ int unet_conv_in_fwd_b16(const unet_act_src* s0, const unet_act_src* s1, float s
                          const float* w, const float* bias, int ksize, int stride, uint16_t* y,
                          void* workspace, size_t workspace_bytes, int* stats_px_out, int N, int H,
                          int W, int Cout, unet_stream_t stream);
+/* unet_conv_in_fwd_b16 with the weights also given pre-rounded to bf16 (wb = [9][Cout][Cin],
+ * plane 0 of unet_pack_conv3x3_weights_batched's wf3; may be null): the stride-1 patch kernel
+ * stages its weight panels without the conversion, at half the L2 traffic; bit-identical. */
+int unet_conv_in_fwd_b16_wb(const unet_act_src* s0, const unet_act_src* s1, float slope,
+                            const float* w, const uint16_t* wb, const float* bias, int ksize,
+                            int stride, uint16_t* y, void* workspace, size_t workspace_bytes,
+                            int* stats_px_out, int N, int H, int W, int Cout, unet_stream_t stream);
+/* unet_conv3x3_bwd_data_bs_b16 likewise (wdb = [9][Cin_total][Cout] bf16, plane 0 of wd3). */
+int unet_conv3x3_bwd_data_bs_b16_wb(const uint16_t* dy, const float* wd, const uint16_t* wdb,
+                                    int Cin_total, int ci_offset, uint16_t* dx, int N, int H,
+                                    int W, int Cout, int Ccols, int stride, int accumulate,
+                                    unet_bwd_stats* bs, unet_stream_t stream);
 int unet_conv_in_stats_finalize_b16(const uint16_t* y, void* workspace, size_t workspace_bytes,
                                     int stats_px, const float* gamma, const float* beta, float eps,
                                     const float* mask, float* mean, float* rstd, float* alpha_out,

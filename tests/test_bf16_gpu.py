@@ -200,7 +200,8 @@ def test_instnorm_bwd_upsample_head_b16(ua):
     check(dw.cpu(), wr.grad, 1e-4, "head dw")
 
 
-@pytest.mark.parametrize("case", [(2, 8, 16, 64, 64), (1, 16, 16, 32, 64), (3, 2, 2, 64, 64)])
+@pytest.mark.parametrize("case", [(2, 8, 16, 64, 64), (1, 16, 16, 32, 64), (3, 2, 2, 64, 64),
+                                  (2, 32, 32, 128, 64), (1, 24, 40, 64, 128)])
 def test_up_backward_b16(ua, case):
     N, h, w, Cx, Cout = case
     x, coef = r16(rnd(N, Cx, h, w, seed=1)), coeffs(N, Cx, 60)

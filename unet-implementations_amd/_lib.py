@@ -117,6 +117,8 @@ SIGNATURES = {
                                       _i, _i, _p]),
     "unet_conv3x3_bwd_data_bs_wino": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv3x3_bwd_data_bs_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
+    "unet_conv3x3_bwd_data_bs_b16_wb": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs,
+                                             _p]),
     "unet_conv3x3_bwd_data_bs_bf16x3": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs,
                                              _p]),
     "unet_conv3x3_up_bwd_data_bs": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _pbs, _p]),
@@ -126,6 +128,8 @@ SIGNATURES = {
                                                        _p, _i, _p, _sz, _i, _i, _i, _p]),
     "unet_conv_in_fwd_b16": (_i, [_ps, _ps, _f, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i), _i, _i,
                                   _i, _i, _p]),
+    "unet_conv_in_fwd_b16_wb": (_i, [_ps, _ps, _f, _p, _p, _p, _i, _i, _p, _p, _sz, _c.POINTER(_i),
+                                     _i, _i, _i, _i, _p]),
     "unet_conv_in_stats_finalize_b16": (_i, [_p, _p, _sz, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i,
                                              _i, _p]),
     "unet_conv_in_bwd_weight_b16": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i,

@@ -1332,7 +1332,7 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   p.Ncols = Ccols;
   p.w3 = reinterpret_cast<const __bf16*>(wd3);
   p.w3_plane = 9 * Cout * Cin_total;
-  p.w3_bytes = (unsigned)((long long)3 * p.w3_plane * 2);
+  p.w3_bytes = (unsigned)((long long)(b16 ? 1 : 3) * p.w3_plane * 2);
   p.sin = 1;
   int bs_px = 0;
   if (use_bs) {
@@ -1458,6 +1458,18 @@ extern "C" int unet_conv3x3_bwd_data_bs_b16(const uint16_t* dy, const float* wd,
   return conv3x3_bwd_data_impl(reinterpret_cast<const float*>(dy), wd, Cin_total, ci_offset,
                                reinterpret_cast<float*>(dx), N, H, W, Cout, Ccols, stride,
                                accumulate, 1, (hipStream_t)stream, nullptr, 1, bs);
+}
+
+// ... with the weights also pre-rounded to bf16 (wdb = [9][Cin_total][Cout] bf16: plane 0 of
+// the pack's wd3; may be null), as unet_conv_in_fwd_b16_wb
+extern "C" int unet_conv3x3_bwd_data_bs_b16_wb(const uint16_t* dy, const float* wd,
+                                               const uint16_t* wdb, int Cin_total, int ci_offset,
+                                               uint16_t* dx, int N, int H, int W, int Cout,
+                                               int Ccols, int stride, int accumulate,
+                                               unet_bwd_stats* bs, unet_stream_t stream) {
+  return conv3x3_bwd_data_impl(reinterpret_cast<const float*>(dy), wd, Cin_total, ci_offset,
+                               reinterpret_cast<float*>(dx), N, H, W, Cout, Ccols, stride,
+                               accumulate, 1, (hipStream_t)stream, wdb, 1, bs);
 }
 
 // Split-bf16 mode of the fused pipeline (wd3 = pre-split planes, data-gradient layout); bs may
@@ -1683,6 +1695,11 @@ static int conv_in_fwd_impl(const unet_act_src* s0, const unet_act_src* s1, floa
         rc = b16 ? dispatch_igemm_b16(p, stream, &px) : dispatch_igemm(p, stream, &px);
       } else if (b16) {
         fill_fwd_taps(p, stride);
+        if (w3) {   // plane 0 of the pre-split weights = the bf16-rounded weights (patch kernel)
+          p.w3 = reinterpret_cast<const __bf16*>(w3);
+          p.w3_plane = 9 * Cout * Cin;
+          p.w3_bytes = (unsigned)((long long)p.w3_plane * 2);
+        }
         rc = dispatch_igemm_b16(p, stream, &px);
       } else {
         fill_fwd_taps(p, stride);
@@ -1744,6 +1761,20 @@ extern "C" int unet_conv_in_fwd_b16(const unet_act_src* s0, const unet_act_src* 
   return conv_in_fwd_impl(s0, s1, slope, w, bias, ksize, stride, reinterpret_cast<float*>(y),
                           workspace, workspace_bytes, stats_px_out, N, H, W, Cout,
                           (hipStream_t)stream, 1);
+}
+
+// The same with the weights also given pre-rounded to bf16 (wb = [9][Cout][Cin] bf16: plane 0 of
+// unet_pack_conv3x3_weights_batched's wf3, refreshed once per step): the patch kernel then
+// stages its weight panels without the fp32 -> bf16 conversion and at half the L2 traffic.
+// Results are bit-identical (the kernel rounds the same way).  wb may be null.
+extern "C" int unet_conv_in_fwd_b16_wb(const unet_act_src* s0, const unet_act_src* s1,
+                                       float slope, const float* w, const uint16_t* wb,
+                                       const float* bias, int ksize, int stride, uint16_t* y,
+                                       void* workspace, size_t workspace_bytes, int* stats_px_out,
+                                       int N, int H, int W, int Cout, unet_stream_t stream) {
+  return conv_in_fwd_impl(s0, s1, slope, w, bias, ksize, stride, reinterpret_cast<float*>(y),
+                          workspace, workspace_bytes, stats_px_out, N, H, W, Cout,
+                          (hipStream_t)stream, 1, ksize == 3 ? wb : nullptr);
 }
 
 static int conv_in_stats_finalize_impl(const float* y, void* workspace, size_t workspace_bytes,

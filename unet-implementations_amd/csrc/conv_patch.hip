@@ -561,14 +561,18 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 // MFMAs per wave between barriers at 128 columns.  Weights stay fp32 in HBM (master copy) and
 // are rounded while staged.  LDS 16 KB patch + 61 KB weights at 128 columns (two per CU).
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false>
+template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false,
+          bool WB = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParams p) {
   constexpr int BK = 32, LDA = BK + 8;       // bf16 elements per LDS row
   constexpr int TW = 32, PW = TW + 2;
   constexpr int PPIX = (TH + 2) * PW;
   constexpr int P_SLOTS = PPIX * 8;          // 4-channel slots: 32 channels per pixel
   constexpr int P_PASSES = (P_SLOTS + 255) / 256;
-  constexpr int B_SLOTS = 3 * BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  // weight slots of a K step (three taps x BN rows x 32 channels): 4 fp32 channels per slot, or
+  // (WB: the weights pre-rounded to bf16, p.w3) 8 bf16 channels - half the slots, no conversion
+  constexpr int B_SEGS = WB ? 4 : 8;
+  constexpr int B_SLOTS = 3 * BN * B_SEGS, B_PASSES = (B_SLOTS + 255) / 256;
   constexpr int B_TILE = 3 * BN * LDA;       // three taps of one kernel row
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -595,7 +599,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
       const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+  const __amdgpu_buffer_rsrc_t rsw = WB ? __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(p.w3), 0, (int)p.w3_bytes, 0x00020000)
+                                        : __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
   int pp_lin[P_PASSES], pp_lds[P_PASSES];
@@ -618,14 +624,18 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
     const int slot = (tid + 256 * j) % B_SLOTS;
-    const int tr = slot / (BN * 8), rem = slot - tr * BN * 8;
-    const int row = rem >> 3, seg = rem & 7;
+    const int tr = slot / (BN * B_SEGS), rem = slot - tr * BN * B_SEGS;
+    const int row = rem / B_SEGS, seg = rem % B_SEGS;
     wslot_tap[j] = tr;
-    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
-    wslot_lds[j] = (tr * BN + row) * LDA + seg * 4;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * (32 / B_SEGS)) * (WB ? 2u : 4u);
+    wslot_lds[j] = (tr * BN + row) * LDA + seg * (32 / B_SEGS);
   }
 
-  f32x4 pr[P_PASSES], rb[B_PASSES];
+  // WB: two register sets - the panel of step s + 2 is loaded while that of s + 1 waits for its
+  // LDS stage (a full step of flight; with one set the loads of s + 1 were stored at the end of
+  // the step that issued them)
+  constexpr int B_SETS = WB ? 2 : 1;
+  f32x4 pr[P_PASSES], rb[B_SETS][B_PASSES];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -677,7 +687,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
       *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(pr[i]);
     }
   };
-  auto load_b = [&](int row, int chunk) {   // the three taps 3*row .. 3*row+2
+  auto load_b = [&](int row, int chunk, auto setc) {   // the three taps 3*row .. 3*row+2
+    constexpr int SET = decltype(setc)::value;
     int oy, ox, wt0, wt1, wt2;
     tap_of(3 * row, oy, ox, wt0);
     tap_of(3 * row + 1, oy, ox, wt1);
@@ -685,37 +696,53 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const int wt = wslot_tap[j] == 0 ? wt0 : (wslot_tap[j] == 1 ? wt1 : wt2);
-      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rsw, wslot_off[j] + woff, 0, 0));
+      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * (WB ? 2u : 4u);
+      rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rsw, wslot_off[j] + woff, 0, 0));
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, auto setc) {
+    constexpr int SET = decltype(setc)::value;
     __bf16* Bb = Bs + buf * B_TILE;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j)
-      if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS)
-        *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[j]);
+      if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS) {
+        if constexpr (WB) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[SET][j];   // 8 bf16
+        else *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[SET][j]);
+      }
   };
 
   const int chunks = Ktot / BK;
   const int steps = chunks * 3;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, B_SETS - 1>;
   load_patch(0);
-  load_b(0, 0);
+  load_b(0, 0, S0{});
+  if constexpr (WB) load_b(steps > 1 ? 1 : 0, 0, S1{});   // (chunks >= 1: step 1 = row 1 of chunk 0)
   store_patch();
-  store_b(0);
+  store_b(0, S0{});
   __syncthreads();
 
   // lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of its row
   const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
   int row = 0, chunk = 0;
-  for (int s = 0; s < steps; ++s) {
+  // one K step on LDS stage `buf` (SET: the register set that receives this step's load)
+  auto k_step = [&](int s, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    using OTHER = std::integral_constant<int, (B_SETS - 1) - SET>;
     const int buf = s & 1;
     const int row1 = (row == 2) ? 0 : row + 1;
     const int chunk1 = (row == 2) ? chunk + 1 : chunk;
-    const bool more = s + 1 < steps;
-    load_b(more ? row1 : row, more ? chunk1 : chunk);
+    if constexpr (WB) {          // the panel of step s + 2 (the tail re-loads the last one)
+      const int row2 = (row1 == 2) ? 0 : row1 + 1;
+      const int chunk2 = (row1 == 2) ? chunk1 + 1 : chunk1;
+      const bool more2 = s + 2 < steps;
+      load_b(more2 ? row2 : row, more2 ? chunk2 : chunk, setc);
+    } else {
+      const bool more = s + 1 < steps;
+      load_b(more ? row1 : row, more ? chunk1 : chunk, setc);
+    }
     if (row == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
 
 #pragma unroll
@@ -740,7 +767,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
             acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[m][nb], 0, 0, 0);
       }
     }
-    store_b(buf ^ 1);
+    if constexpr (WB) store_b(buf ^ 1, OTHER{});   // step s + 1's panel, loaded a step ago
+    else store_b(buf ^ 1, setc);
     if (row == 2) {            // every wave is done with this chunk's patch
       __syncthreads();
       store_patch();
@@ -748,6 +776,53 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
     __syncthreads();
     row = row1;
     chunk = chunk1;
+  };
+  if constexpr (WB) {
+    for (int s = 0; s < steps; s += 2) {
+      k_step(s, S0{});
+      if (s + 1 < steps) k_step(s + 1, S1{});
+    }
+  } else {
+    // (the one-set form spelled out as before: through k_step the 128-column fused
+    // instantiation needed one register too many)
+    for (int s = 0; s < steps; ++s) {
+      const int buf = s & 1;
+      const int row1 = (row == 2) ? 0 : row + 1;
+      const int chunk1 = (row == 2) ? chunk + 1 : chunk;
+      const bool more = s + 1 < steps;
+      load_b(more ? row1 : row, more ? chunk1 : chunk, S0{});
+      if (row == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        int oy, ox, wt;
+        tap_of(3 * row + j, oy, ox, wt);
+        const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
+        const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 a[TM], b[TN];
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+            a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
+#pragma unroll
+          for (int nb = 0; nb < TN; ++nb)
+            b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int nb = 0; nb < TN; ++nb)
+              acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[m][nb], 0, 0, 0);
+        }
+      }
+      store_b(buf ^ 1, S0{});
+      if (row == 2) {            // every wave is done with this chunk's patch
+        __syncthreads();
+        store_patch();
+      }
+      __syncthreads();
+      row = row1;
+      chunk = chunk1;
+    }
   }
 
   __bf16* outp = reinterpret_cast<__bf16*>(p.out);
@@ -1855,10 +1930,16 @@ bool patch_s2_applicable(const IgemmParams& p) {
 template <int BN, int WM, int WN, int TH, bool ACT, bool STATS, bool BSTATS = false>
 int launch_patch_b16_t(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = ((size_t)((TH + 2) * 34) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16);
-  auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS>;
-  UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  if (p.w3) {     // the weights pre-rounded to bf16: panels staged without conversion
+    auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS, true>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  } else {
+    auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS, false>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  }
   UNET_CHECK_LAUNCH("conv_patch_b16");
   return UNET_OK;
 }

@@ -463,6 +463,155 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wgrad_taps_kernel(const Wgrad
 }
 
 // ---------------------------------------------------------------------------
+// conv_wgrad_taps_kernel on the bf16 matrix cores (mixed-precision pipeline: x and D are bf16
+// tensors): dW[tap][ci][co] = sum_q act(x)[q][ci] * D[q][tap*Cout + co] with
+// v_mfma_f32_32x32x16_bf16.  Operands are staged as [32-channel sub-tile][pixel][32] (64-byte
+// rows) and read with the transposing LDS read, as in conv_wgrad_bf16_kernel below: per
+// 16-pixel k-group one A fragment and nine D fragments.  D is copied raw (16 bytes = 8 channels
+// per slot: no bf16 -> fp32 -> bf16 round trip); x is activated in fp32 and rounded.
+// 64 x 64 tiles: wave w owns sub-block w for all nine taps (one pixel part).
+// ---------------------------------------------------------------------------
+template <int CI_T, int CO_T, int S, bool ACT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const WgradParams p) {
+  constexpr int TI = CI_T / 32, TJ = CO_T / 32;
+  constexpr int NSB = TI * TJ, NPP = 4 / NSB;
+  static_assert(NSB == 2 || NSB == 4, "tile must have 2 or 4 sub-blocks");
+  constexpr int NT = 256;
+  constexpr int SUB = S * 32;                  // elements of one 32-channel sub-tile
+  constexpr int ATILE = TI * SUB, DTILE = 9 * TJ * SUB, STAGE = ATILE + DTILE;
+  constexpr int NA = S * CI_T / 4;             // 4-channel slots of the x segment
+  constexpr int ND = S * 9 * CO_T / 8;         // 8-channel (16-byte) slots of the D segment
+  constexpr int NLA = (NA + NT - 1) / NT, NLD = (ND + NT - 1) / NT;
+  constexpr int NG = (S / 16) / NPP;           // 16-pixel k-groups per wave per segment
+  static_assert((S / 16) % NPP == 0 && NG >= 1, "segment must split into whole k-groups");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sb = wave % NSB, pp = wave / NSB;
+  const int wi = sb / TJ, wj = sb - wi * TJ;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);   // the tiles of one pixel range share D in one L2
+  const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+  const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+  const int sp = bid;
+  const int ci0 = ci_t * CI_T, co0 = co_t * CO_T;
+  const int g_begin = sp * p.segs_per_block;
+  const int g_end = min(g_begin + p.segs_per_block, p.total_segs);
+  const int HW = p.H * p.W;
+  const int Q = p.N * HW;
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+  // x slot k: pixel a_px of the segment, channels a_ch .. +3 -> LDS [sub][pixel][32]
+  // D slot k: byte offset from the segment's first pixel (a pixel past the end of the tensor is
+  //           beyond the descriptor's range and reads 0 by itself) -> LDS [tap][sub][pixel][32]
+  int a_px[NLA], a_lds[NLA];
+  const int a_seg = tid % (CI_T / 4);
+  const int a_ch = ci0 + a_seg * 4;
+#pragma unroll
+  for (int k = 0; k < NLA; ++k) {
+    a_px[k] = (tid + NT * k) / (CI_T / 4);
+    a_lds[k] = (a_seg >> 3) * SUB + a_px[k] * 32 + (a_seg & 7) * 4;
+  }
+  unsigned d_off[NLD];
+  int d_lds[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int idx = tid + NT * k;
+    const int px = idx / (9 * CO_T / 8), rem = idx - px * (9 * CO_T / 8);
+    const int t = rem / (CO_T / 8), c8 = rem - t * (CO_T / 8);
+    d_off[k] = (unsigned)(px * (9 * p.Cout) + t * p.Cout + co0 + 8 * c8) * 2u;
+    d_lds[k] = ATILE + (t * TJ + (c8 >> 2)) * SUB + px * 32 + (c8 & 3) * 8;
+  }
+
+  f32x4 ra[NLA], rdv[NLD];
+  f32x4 ca[NLA], cb[NLA];
+  unsigned okm = 0;
+  int lq0 = 0;   // first pixel of the segment being loaded
+  auto load_stage = [&]() {
+    okm = 0;
+#pragma unroll
+    for (int k = 0; k < NLA; ++k) {
+      const int q = lq0 + a_px[k];
+      const bool ok = q < Q && (NA % NT == 0 || tid + NT * k < NA);
+      ra[k] = buf_ld4<__bf16>(rsx, (unsigned)(q * p.Cx + a_ch), ok ? 0u : 0x80000000u);
+      if (ACT) {
+        const int n = ok ? q / HW : 0;
+        ca[k] = *reinterpret_cast<const f32x4*>(p.alpha + (size_t)n * p.Cx + a_ch);
+        cb[k] = *reinterpret_cast<const f32x4*>(p.beta + (size_t)n * p.Cx + a_ch);
+        okm |= (ok ? 1u : 0u) << k;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      rdv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsd, d_off[k] + (unsigned)(lq0 * (9 * p.Cout)) * 2u, 0, 0));
+  };
+  auto store_stage = [&](int buf) {
+    __bf16* base = smem_h + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < NLA; ++k) {
+      f32x4 v = ra[k];
+      if (ACT) v = act4(v, ca[k], cb[k], p.slope, (okm >> k) & 1u);
+      bf16x4 h;
+      h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+      if (NA % NT == 0 || tid + NT * k < NA) *reinterpret_cast<bf16x4*>(base + a_lds[k]) = h;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (NT * (k + 1) <= ND || tid + NT * k < ND)
+        *reinterpret_cast<f32x4*>(base + d_lds[k]) = rdv[k];
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (g_begin < g_end) {
+    lq0 = g_begin * S;
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+    const int tg = lane >> 4, th = tg >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tcol = 16 * (tg & 1) + 4 * tp;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    auto frag = [&](const __bf16* q) {   // rows r0..r0+3 and r0+4..r0+7 of this lane's group
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    for (int g = g_begin; g < g_end; ++g) {
+      const int buf = (g - g_begin) & 1;
+      if (g + 1 < g_end) lq0 += S;   // the last iteration re-stages the final segment
+      load_stage();
+      const __bf16* A = smem_h + buf * STAGE + wi * SUB;
+      const __bf16* D = smem_h + buf * STAGE + ATILE + wj * SUB;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const int r0 = 16 * (pp + NPP * gq) + 8 * th + tq;
+        const bf16x8 a = frag(A + r0 * 32 + tcol);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              a, frag(D + t * TJ * SUB + r0 * 32 + tcol), acc[t], 0, 0, 0);
+      }
+      store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  wgrad_epilogue<NSB, NPP, TJ, NT>(reinterpret_cast<float*>(smem_h), p, sp, ci0, co0, sb, pp,
+                                   [&](auto tc) -> const f32x16& {
+    return acc[decltype(tc)::value];
+  });
+}
+
+// ---------------------------------------------------------------------------
 // bf16 mixed-precision weight gradient (stride 1): same blocking, slabs and loader as
 // conv_wgrad_kernel; operands are rounded to bf16 while staged into LDS as
 // [32-channel sub-tile][pixel][32] (64-B rows) and read as MFMA fragments with the gfx950
@@ -1548,6 +1697,25 @@ int launch_wgrad_taps8(const WgradParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+// bf16 tensors, bf16 matrix cores (64 x 64 tiles)
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_taps_b16(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t stages = 2 * (size_t)S * (CI_T + 9 * CO_T) * sizeof(__bf16);
+  constexpr size_t lds = stages > kWgradMergeLds4 ? stages : kWgradMergeLds4;
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_taps_b16_kernel<CI_T, CO_T, S, true>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    auto kern = conv_wgrad_taps_b16_kernel<CI_T, CO_T, S, false>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_taps_b16");
+  return UNET_OK;
+}
+
 template <int CI_T, int CO_T, int S>
 int launch_wgrad_taps(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)S * (CI_T + 9 * CO_T) * sizeof(float);
@@ -2066,7 +2234,8 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
       else if (pl.co_t == 64) rc = launch_wgrad_taps8<32, 64, 32>(p, stream);
       else rc = launch_wgrad_taps8<32, 32, 64>(p, stream);
     } else {
-      if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
+      if (pl.ci_t == 64 && b16) rc = launch_wgrad_taps_b16<64, 64, 16>(p, stream);
+      else if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
       else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
       else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
     }

@@ -283,13 +283,15 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
         dx = out if out is not None else _b16((N, H, W, ccols), dy)
         assert dx.shape == (N, H, W, ccols) and _is_b16(dx)
         t0 = _timer.begin("conv") if _timer is not None else None
-        if nxt is not None:
-            bs = nxt.c_struct()
-            check(lib().unet_conv3x3_bwd_data_bs_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset,
-                                                     _ptr(dx), N, H, W, Cout, ccols, stride,
-                                                     1 if accumulate else 0, ctypes.byref(bs),
-                                                     _stream()))
-            nxt.tiles = bs.tiles_out
+        if nxt is not None or wd3 is not None:
+            # (wd3: the weights also pre-rounded to bf16 - plane 0 of the pack's planes)
+            bs = nxt.c_struct() if nxt is not None else None
+            check(lib().unet_conv3x3_bwd_data_bs_b16_wb(
+                _ptr(dy), _ptr(wd), _ptr(wd3), cin_total, ci_offset, _ptr(dx), N, H, W, Cout, ccols,
+                stride, 1 if accumulate else 0, ctypes.byref(bs) if bs is not None else None,
+                _stream()))
+            if nxt is not None:
+                nxt.tiles = bs.tiles_out
         else:
             check(lib().unet_conv3x3_bwd_data_b16(_ptr(dy), _ptr(wd), cin_total, ci_offset, _ptr(dx),
                                                   N, H, W, Cout, ccols, stride,
@@ -555,6 +557,11 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
         # Winograd F(2x2, 3x3) form (the caller checked conv_wino_supported)
         check(lib().unet_conv_in_fwd_wino(r0, r1, slope, _ptr(wu), _ptr(bias), _ptr(y), _ptr(ws),
                                           ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
+    elif w3 is not None and b16 and ksize == 3 and C0 != 3:
+        # mixed precision with the weights also pre-rounded to bf16 (plane 0 of the planes)
+        check(lib().unet_conv_in_fwd_b16_wb(r0, r1, slope, _ptr(w), _ptr(w3), _ptr(bias), ksize,
+                                            stride, _ptr(y), _ptr(ws), ws.numel(),
+                                            ctypes.byref(px), N, H, W, Cout, _stream()))
     elif w3 is not None and not b16 and C0 != 3:
         check(lib().unet_conv_in_fwd_bf16x3(r0, r1, slope, _ptr(w), _ptr(w3), _ptr(bias), ksize,
                                             stride, _ptr(y), _ptr(ws), ws.numel(),

@@ -466,8 +466,11 @@ class _UNetFunction(torch.autograd.Function):
                 wino.append((s1 and co % 64 == 0 and ci % 8 == 0,
                              s1 and ci % 64 == 0 and co % 8 == 0))
         table = model.__dict__.get("_pack_table")
-        if table is None or not table.matches(convs, bf16 == "bf16x3", wino):
-            table = model.__dict__["_pack_table"] = ops.PackTable(convs, bf16 == "bf16x3", wino)
+        # (the bf16 planes: all three terms in the split mode; in the mixed-precision mode their
+        # first plane is the bf16-rounded weight the patch kernels stage without a conversion)
+        planes = bf16 == "bf16x3" or (bf16 == "bf16" and model.fused_pipeline)
+        if table is None or not table.matches(convs, planes, wino):
+            table = model.__dict__["_pack_table"] = ops.PackTable(convs, planes, wino)
         table.run()
         packed = {id(w): k for k, w in enumerate(convs)}
 
@@ -515,7 +518,7 @@ class _UNetFunction(torch.autograd.Function):
             else:
                 k = packed[id(w)]
                 wk, wd = table.wf[k], table.wd[k]
-            w3 = table.wf3[k] if (x3 and l.ksize == 3) else None
+            w3 = table.wf3[k] if ((x3 or b16) and l.ksize == 3) else None
             m = mask_of[id(l)]
             wu = ud = None
             if l.ksize == 3 and not b16 and not x3:
