@@ -474,6 +474,18 @@ int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
 size_t unet_wino_weight_floats(int Cout, int Cin);
 int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin,
                            unet_stream_t stream);
+/* The same for several layers in one launch.  Entry k owns the blocks [block_begin,
+ * block_begin + ceil(Cout * Cin / 8 / 256)); uf / ud may be null per entry (form not wanted);
+ * the shape rules of unet_pack_wino_weights apply per entry (checked by the caller). */
+typedef struct unet_wino_pack_entry {
+  const float* w;   /* OIHW source [Cout][Cin][3][3] */
+  float* uf;        /* forward form or null */
+  float* ud;        /* data-gradient form or null */
+  int Cout, Cin;
+  int block_begin, reserved;
+} unet_wino_pack_entry;
+int unet_pack_wino_weights_batched(const unet_wino_pack_entry* table_device, int n,
+                                   int total_blocks, unet_stream_t stream);
 /* unet_conv_in_fwd (ksize 3, stride 1) on the Winograd kernel: y = conv3x3(cat(act(s0),
  * act(s1))) + bias and the per-tile statistics of y (256 pixels per tile). */
 int unet_conv_in_fwd_wino(const unet_act_src* s0, const unet_act_src* s1, float slope,

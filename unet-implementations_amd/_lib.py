@@ -109,6 +109,7 @@ SIGNATURES = {
     "unet_conv_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_wino_weight_floats": (_sz, [_i, _i]),
     "unet_pack_wino_weights": (_i, [_p, _p, _p, _i, _i, _p]),
+    "unet_pack_wino_weights_batched": (_i, [_p, _i, _i, _p]),
     "unet_conv_in_fwd_wino": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,
                                    _i, _p]),
     "unet_conv3x3_bwd_weight_is_winograd": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -159,6 +159,17 @@ class PackTable:
             self.ud.append(ud)
             if uf is not None or ud is not None:
                 self._wino_jobs.append((w, uf, ud, cout, cin))
+        # device table of unet_pack_wino_weights_batched: one launch for every Winograd form
+        self._wino_table, self._wino_blocks = None, 0
+        if self._wino_jobs:
+            rawu = b""
+            for w, uf, ud, cout, cin in self._wino_jobs:
+                rawu += struct.pack("<3Q4i", w.data_ptr(), 0 if uf is None else uf.data_ptr(),
+                                    0 if ud is None else ud.data_ptr(), cout, cin,
+                                    self._wino_blocks, 0)
+                self._wino_blocks += (cout * cin // 8 + 255) // 256
+            self._wino_table = torch.frombuffer(bytearray(rawu), dtype=torch.uint8).to(
+                weights[0].device)
         raw = b""
         tiles = 0
         for w in weights:
@@ -187,9 +198,10 @@ class PackTable:
     def run(self):
         check(lib().unet_pack_conv3x3_weights_batched(self.table.data_ptr(), self.n, self.tiles,
                                                       _stream()))
-        for w, uf, ud, cout, cin in self._wino_jobs:
-            check(lib().unet_pack_wino_weights(_ptr(w.detach()), _ptr(uf), _ptr(ud), cout, cin,
-                                               _stream()))
+        if self._wino_table is not None:
+            check(lib().unet_pack_wino_weights_batched(self._wino_table.data_ptr(),
+                                                       len(self._wino_jobs), self._wino_blocks,
+                                                       _stream()))
 
 
 # ---- convolution ---------------------------------------------------------------
