@@ -90,18 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.Hin, W = p.Win;
   const int tiles_n = p.Ncols / WN_BN, tiles_x = W / WN_TW, tiles_y = H / WN_TH;
-  // PERSISTENT workgroups: one per CU (the launch grid), each walks `per_wg` consecutive tiles.
-  // Measured with cycle-counter stamps on the 64-channel 256 x 256 layer (2048 tiles): 52 k
-  // cycles inside a tile's workgroup but 67 k cycles per tile of kernel time - a workgroup that
-  // owns all of a CU's LDS is re-dispatched only ~6 us after its predecessor ended.  The XCD
-  // remap makes the tiles of one XCD a contiguous range (halo rows and U panels in its L2).
-  const int ntiles = p.N * tiles_y * tiles_x * tiles_n;
-  const int per_wg = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int tile0 = xcd_remap(blockIdx.x, gridDim.x) * per_wg;
-  for (int tile_j = 0; tile_j < per_wg; ++tile_j) {
-  int bid = tile0 + tile_j;
-  if (bid >= ntiles) break;           // uniform
-  if (tile_j) __syncthreads();        // every wave is done with the previous tile's LDS
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % tiles_n; bid /= tiles_n;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
@@ -514,7 +503,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     if (block_col_sums<WN_BN, 4>(red, out))
       p.bs_partial[((size_t)n * p.bs_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
   }
-  }   // tiles of this workgroup
 }
 
 // U = G g G^T in the kernel's LDS image order.  One thread = one output column n and one chunk of
@@ -598,17 +586,7 @@ int launch_wino(const WinoParams& wp, hipStream_t stream) {
   const IgemmParams& p = wp.g;
   const long long tiles =
       (long long)p.N * (p.Hin / WN_TH) * (p.Win / WN_TW) * (p.Ncols / WN_BN);
-  // one persistent workgroup per CU (it takes the whole LDS), each walking tiles / CUs tiles
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-    else
-      cus = 256;
-  }
-  const long long blocks = tiles < cus ? tiles : cus;
+  const long long blocks = tiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), WN_LDS, stream, wp);
   UNET_CHECK_LAUNCH("conv_wino");
   return UNET_OK;
