@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 3
+#define UNET_ABI_VERSION 4
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */

@@ -376,3 +376,32 @@ def test_data_gradient_b16_emits_next_norm_reductions(ua, case):
     check(outs[0][0], outs[1][0], 8e-3, "dy")
     check(outs[0][1], outs[1][1], 3e-3, "dgamma")
     check(outs[0][2], outs[1][2], 3e-3, "dbeta")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 0, 128), (1, 128, 128, 64, 64, 64),
+                                  (1, 64, 64, 32, 0, 32)])
+def test_prerounded_bf16_weights_are_bit_identical(ua, case):
+    """unet_conv_in_fwd_b16_wb / unet_conv3x3_bwd_data_bs_b16_wb: the patch kernels stage weight
+    panels that were rounded to bf16 once per step (plane 0 of the pack's planes) instead of
+    converting the fp32 weights per tile - the same rounding, so the results must be EQUAL."""
+    N, H, W, C0, C1, Cout = case
+    x0, c0 = r16(rnd(N, C0, H, W, seed=1)), coeffs(N, C0, 10)
+    x1 = r16(rnd(N, C1, H, W, seed=2)) if C1 else None
+    c1 = coeffs(N, C1, 20) if C1 else None
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=0.1).to(DEV)
+    b = rnd(Cout, seed=4, scale=0.3).to(DEV)
+    g1, b1 = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+    table = ua.ops.PackTable([w], True)
+    table.run()
+    wf, wd, wf3, wd3 = table.wf[0], table.wd[0], table.wf3[0], table.wd3[0]
+    assert torch.equal(wf3[0].float(), wf.to(BF).float())   # plane 0 = the rounded weight
+    s0 = src(ua, x0, c0)
+    s1 = src(ua, x1, c1) if C1 else None
+    args = (s0, s1, SLOPE, wf, b, 3, 1, g1, b1, 1e-5, None)
+    y_a, st_a = ua.ops.conv_in_fwd(*args, b16=True)
+    y_b, st_b = ua.ops.conv_in_fwd(*args, b16=True, w3=wf3)
+    assert torch.equal(y_a, y_b) and torch.equal(st_a, st_b)
+    dy = to_nhwc_b16(r16(rnd(N, Cout, H, W, seed=5)))
+    dx_a = ua.ops.conv3x3_bwd_data(dy, wd, 0, C0, H, W, 1, bf16="bf16")
+    dx_b = ua.ops.conv3x3_bwd_data(dy, wd, 0, C0, H, W, 1, bf16="bf16", wd3=wd3)
+    assert torch.equal(dx_a, dx_b)

@@ -706,3 +706,23 @@ def test_low_resolution_gradient_emits_reductions(ua):
     g = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx, nxt=nn)
     assert torch.equal(g, ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx)) and nn.tiles > 0
     _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
+
+
+def test_winograd_weight_packing_in_one_launch(ua):
+    """unet_pack_wino_weights_batched (PackTable.run: every layer's U = G g G^T in one launch)
+    against the per-layer entry point, forward and data-gradient forms, incl. a layer that only
+    takes one of the two forms."""
+    ws = [rnd(64, 64, 3, 3, seed=1).to(DEV), rnd(128, 192, 3, 3, seed=2).to(DEV),
+          rnd(64, 40, 3, 3, seed=3).to(DEV), rnd(32, 32, 3, 3, seed=4).to(DEV)]
+    flags = [(True, True), (True, True), (True, False), (False, False)]
+    table = ua.ops.PackTable(ws, False, flags)
+    table.run()
+    for w, (ff, fd), uf, ud in zip(ws, flags, table.uf, table.ud):
+        assert (uf is not None) == ff and (ud is not None) == fd
+        if not (ff or fd):
+            continue
+        rf, rd = ua.ops.pack_wino_weights(w, want_f=ff, want_d=fd)
+        if ff:
+            assert torch.equal(uf, rf.view(-1))
+        if fd:
+            assert torch.equal(ud, rd.view(-1))

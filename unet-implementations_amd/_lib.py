@@ -188,7 +188,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.unet_abi_version() != 3:
+    if handle.unet_abi_version() != 4:
         raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib
