@@ -507,6 +507,25 @@ int unet_conv_up_in_fwd_wino(const unet_act_src* low, const unet_act_src* skip, 
 int unet_conv3x3_bwd_data_bs_wino(const float* dy, const float* ud, int Cin_total, int ci_offset,
                                   float* dx, int N, int H, int W, int Cout, int Ccols,
                                   unet_bwd_stats* bs, unet_stream_t stream);
+/* Apply-on-load InstanceNorm backward (round 3).  unet_instnorm_bwd_coefs turns the per-tile
+ * reductions a data-gradient epilogue left (unet_bwd_stats.partial, `tiles` per image) into the
+ * coefficient planes coef5 = [5][N][C] (a1, b1, P, Q, R) of
+ *   dz = (z > 0 ? P : P slope) g + (Q y + R),  z = y a1 + b1,
+ * and sums = [N][C][2] (S1, S2).  unet_conv3x3_bwd_data_dz_wino is unet_conv3x3_bwd_data_bs_wino
+ * whose loader forms dz from (g, y) with them - the elementwise unet_instnorm_lrelu_drop_bwd
+ * pass of the layer is not run - and which also writes dz (dz_out, must not alias g) for the
+ * layer's weight gradient and the layer's dgamma / dbeta / dbias (each may be null).
+ * Replaces the InstanceNorm2d / LeakyReLU / dropout backward of ConvBlock
+ * (Our_UNet/models/unet.py:118-123 under autograd). */
+int unet_instnorm_bwd_coefs(const void* partial, int tiles, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, const float* mask,
+                            float* coef5, float* sums, int N, int HW, int C, unet_stream_t stream);
+int unet_conv3x3_bwd_data_dz_wino(const float* g, const float* y, const float* coef5,
+                                  const float* sums, const float* gamma, const float* rstd,
+                                  float slope, float* dz_out, float* dgamma, float* dbeta,
+                                  float* dbias, const float* ud, int Cin_total, int ci_offset,
+                                  float* dx, int N, int H, int W, int Cout, int Ccols,
+                                  unet_bwd_stats* bs, unet_stream_t stream);
 /* unet_instnorm_lrelu_drop_bwd with the reductions already summarised per tile
  * (partial[(n * tiles + t) * C + c] = (S1, S2)). */
 int unet_instnorm_lrelu_drop_bwd_partials(const float* ga, const float* y, const float* mean,

@@ -726,3 +726,40 @@ def test_winograd_weight_packing_in_one_launch(ua):
             assert torch.equal(uf, rf.view(-1))
         if fd:
             assert torch.equal(ud, rd.view(-1))
+
+
+@pytest.mark.parametrize("case", [(4, 128, 128, 128, 128, 0), (2, 256, 256, 64, 64, 0),
+                                  (4, 128, 128, 256, 64, 128)])
+def test_instnorm_backward_applied_on_load_by_the_winograd_data_gradient(ua, case):
+    """unet_instnorm_bwd_coefs + unet_conv3x3_bwd_data_dz_wino (the loader forms dL/dy from
+    (g, y) and five coefficient planes, writes it for the weight gradient, emits the layer's
+    parameter gradients) against the elementwise pass + the plain Winograd data gradient.
+    Third case: a column slice of a wider weight (the skip half of a decoder stage's first
+    convolution: ci_offset > 0)."""
+    N, H, W, C, Ccols, ci_off = case
+    cin_total = ci_off + Ccols
+    y, st, gamma, beta, mask = _next_norm(ua, N, C, H, W, 30)
+    # g = dL/da of that layer with its reductions, as a producing data gradient leaves them
+    dyn = to_nhwc(rnd(N, 64, H, W, seed=1))
+    _, wdn = ua.ops.pack_conv3x3_weights(rnd(64, C, 3, 3, seed=2, scale=0.1).to(DEV))
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.conv3x3_bwd_data(dyn, wdn, 0, C, H, W, 1, nxt=nn)
+    assert nn.tiles > 0
+    w = rnd(C, cin_total, 3, 3, seed=3, scale=0.1).to(DEV)
+    _, wd = ua.ops.pack_conv3x3_weights(w)
+    _, ud = ua.ops.pack_wino_weights(w, want_f=False)
+    # the two-pass way
+    dg0, db0, dbi0 = (torch.empty(C, device=DEV) for _ in range(3))
+    dz0 = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), y, st[0], st[1], gamma, beta, mask, SLOPE, dg0,
+                                         db0, dbi0, partials=(nn.partial, nn.tiles))
+    dx0 = ua.ops.conv3x3_bwd_data(dz0, wd, ci_off, Ccols, H, W, 1, ud=ud)
+    # applied on load
+    coef5, sums = ua.ops.instnorm_bwd_coefs(y, st[0], st[1], gamma, beta, mask,
+                                            (nn.partial, nn.tiles))
+    dg1, db1, dbi1 = (torch.empty(C, device=DEV) for _ in range(3))
+    dx1, dz1 = ua.ops.conv3x3_bwd_data_dz(g, y, coef5, sums, gamma, st[1], SLOPE, dg1, db1, dbi1,
+                                          ud, cin_total, ci_off, Ccols)
+    check(dz1, dz0, 1e-5, "dz written by the data gradient")
+    check(dx1, dx0, 2e-5, "dx")
+    assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    assert (dbi1 - dbi0).abs().max() <= 1e-6 * (dz0.abs().max() * H * W)

@@ -446,6 +446,38 @@ def test_shape_sweep_fused_vs_standalone_pipeline(ua, shape):
     assert not bad, "\n".join(bad)
 
 
+def test_instnorm_backward_applied_on_load_matches_the_elementwise_pass(ua):
+    """`UNet.fold_instnorm_backward` (off by default: measured slower): the Winograd
+    data gradients of the stride-1 layers form dL/dy from (g, y) in their loaders and write it
+    for the weight gradients - no in_bwd_apply launch for those layers.  At 2 x 512 x 512 the 64-
+    and 128-channel layers and the skip halves of the last two decoder stages take that route;
+    every gradient element must agree with the elementwise pass to 1e-4 of the tensor's max
+    (same LeakyReLU branch expression, so no tie can flip between the two)."""
+    sd0 = O.fill_state_dict(23)
+    img, tgt = O.synthetic_batch(4, 2, 512, 512)
+    masks = O.draw_dropout_masks(6, 2)
+    outs = []
+    for fold in (False, True):
+        model = ua.UNet()
+        model.load_state_dict(sd0)
+        model = model.to(DEV).train()
+        model.fold_instnorm_backward = fold
+        model.dropout_mask_override = masks
+        loss = ua.get_loss_function()(model(img.to(DEV)), tgt.to(DEV))
+        loss.backward()
+        outs.append({k: p.grad.detach().cpu() for k, p in model.named_parameters()})
+        del model
+    bad = []
+    for k in outs[0]:
+        scale = outs[0][k].abs().max().item()
+        if scale < 1e-6:
+            continue
+        e = (outs[1][k] - outs[0][k]).abs().max().item() / scale
+        if e > 1e-4:
+            bad.append(f"{k}: {e:.2e}")
+    assert not bad, "\n".join(bad)
+
+
 def test_net_vs_oracle_random_init(ua):
     """Reference-style random init (Kaiming weights, zero biases, unit gamma), 96x64 input,
     train mode with oracle-drawn masks: logits, loss and every gradient against the oracle."""

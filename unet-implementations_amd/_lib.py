@@ -117,6 +117,9 @@ SIGNATURES = {
     "unet_conv_up_in_fwd_wino": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i,
                                       _i, _i, _p]),
     "unet_conv3x3_bwd_data_bs_wino": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _pbs, _p]),
+    "unet_instnorm_bwd_coefs": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "unet_conv3x3_bwd_data_dz_wino": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i,
+                                           _p, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv3x3_bwd_data_bs_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv3x3_bwd_data_bs_b16_wb": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs,
                                              _p]),

@@ -37,6 +37,7 @@
 namespace unet_conv {
 namespace {
 
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 template <int I> using wn_ic = std::integral_constant<int, I>;
 template <int B, int... I, typename F>
 __device__ __forceinline__ void wn_for_impl(std::integer_sequence<int, I...>, F&& f) {
@@ -72,6 +73,20 @@ __host__ __device__ __forceinline__ int wn_swz(int row, int k) {
 struct WinoParams {
   IgemmParams g;       // sources / activation coefficients / output / epilogue descriptors
   const float* wu;     // packed U: [n tile of 64][K chunk of 8][xi 16][n 64][k 8 swizzled]
+  // DZ (data gradient only): source 0 is the gradient g = dL/da of the layer's ACTIVATED output;
+  // the loader forms dz = dL/dy (InstanceNorm + LeakyReLU + dropout backward) from (g, y) and
+  // the coefficient planes of in_bwd_coef_kernel while it stages the patch - the elementwise
+  // in_bwd_apply pass of that layer is gone - and the workgroups of column tile 0 also WRITE dz
+  // (interior pixels of their tile) for the layer's weight gradient; workgroup 0 emits the
+  // layer's dgamma / dbeta / dbias from the per-image sums, as in_bwd_apply did.
+  const float* dz_y;       // raw conv output y, shape of source 0
+  const float* dz_coef;    // [5][N][C0]: a1, b1, P, Q, R
+  float* dz_out;           // dz, shape of source 0 (must not alias g: halos are re-read)
+  const float2* dz_sums;   // [N][C0] (S1, S2)
+  const float* dz_gamma;   // [C0]
+  const float* dz_rstd;    // [N][C0]
+  float* dz_dgamma; float* dz_dbeta; float* dz_dbias;   // [C0] each (may be null)
+  float dz_slope;
 };
 
 // UP: source 0 is the LOW-resolution tensor [N][H/2][W/2][C0] of a decoder stage's first
@@ -79,8 +94,9 @@ struct WinoParams {
 // bilinearly (align_corners=False at exactly 2x: taps {0.75, 0.25}, edge clamped; activation on
 // the four taps, PyTorch's blend order, zero padding after the blend - as conv_patch_up_kernel)
 // on their way into the raw patch, so the up-sampled tensor never exists.
-template <bool ACT, bool STATS, bool BSTATS, bool UP = false>
+template <bool ACT, bool STATS, bool BSTATS, bool UP = false, bool DZ = false>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) {
+  static_assert(!DZ || (!ACT && !UP && !STATS), "DZ is a data-gradient loader");
   const IgemmParams& p = wp.g;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                    // [buf][xi][tile 64][8]
@@ -103,6 +119,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.src1 ? p.src1 : p.src0), 0, (int)p.src1_bytes, 0x00020000);
+  // DZ: y and dz have the shape (and the slot offsets) of source 0
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(DZ ? wp.dz_y : p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+      DZ ? wp.dz_out : const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  if (DZ && blockIdx.x == 0) {   // parameter gradients of the layer (N x C0 sums to read)
+    const float hw = (float)(H * W), inv = 1.f / hw;
+    for (int c = tid; c < p.C0; c += 512) {
+      float dg = 0.f, db = 0.f, dbi = 0.f;
+      for (int q = 0; q < p.N; ++q) {
+        const float2 v = wp.dz_sums[(size_t)q * p.C0 + c];
+        db += v.x;
+        dg += v.y;
+        dbi += wp.dz_gamma[c] * wp.dz_rstd[(size_t)q * p.C0 + c] * (v.x - hw * (v.x * inv));
+      }
+      if (wp.dz_dgamma) wp.dz_dgamma[c] = dg;
+      if (wp.dz_dbeta) wp.dz_dbeta[c] = db;
+      if (wp.dz_dbias) wp.dz_dbias[c] = dbi;
+    }
+  }
 
   // ---- raw patch slots: 340 pixels x 2 channel halves; thread -> slots tid, tid + 512 ----
   // Everything the K loop needs per slot is loop-invariant and lives in a register or an
@@ -114,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   // unrolled over the two stage parities), DMA / coefficient loads are scalar base + lane offset.
   const int half = tid & 1;
   unsigned voff0[UP ? 1 : 2], voff1[2];   // byte offsets into source 0 / 1, bit 31 = outside the image
-  bool okslot[2];
+  bool okslot[2], wrslot[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = tid + 512 * i;
@@ -124,6 +160,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     const bool ok = slot < 2 * WN_PPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     const unsigned lin = (unsigned)((n * H + iy) * W + ix);
     okslot[i] = ok;
+    // (DZ: the pixels a workgroup of column tile 0 writes dz for: the interior of its patch)
+    wrslot[i] = DZ && ok && tn == 0 && prow >= 1 && prow <= WN_TH && pcol >= 1 && pcol <= WN_TW;
     if (!UP) voff0[i] = ok ? (lin * (unsigned)p.C0 + half * 4) * 4u : 0x80000000u;
     voff1[i] = ok ? (lin * (unsigned)p.C1 + half * 4) * 4u : 0x80000000u;
   }
@@ -152,6 +190,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   f32x4 pt[UP ? 2 : 1][3];   // UP: the other three taps of a slot
   bool pup = false;           // the chunk in the registers is a low-resolution (gathered) one
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  f32x4 py[DZ ? 2 : 1];            // DZ: the y values of the two slots
+  f32x4 cz[DZ ? 5 : 1];            // DZ: a1, b1, P, Q, R of this lane's four channels
   const unsigned hoff = (unsigned)half * 16u;   // this lane's 16 bytes of a chunk's coefficients
   // G: global -> registers, one slot per call.  Slot 1's call also fetches the chunk's coefficients
   // and source kind: it runs AFTER both slots of the previous chunk were stored
@@ -178,6 +218,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       unsigned vo = voff1[i];
       if constexpr (!UP) vo = first ? voff0[i] : voff1[i];
       pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cc * 4, 0));
+      if constexpr (DZ)
+        py[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, vo, cc * 4, 0));
+    }
+    if constexpr (DZ) {
+      if (i == 1) {   // the chunk's coefficient planes (looked at when the patch is stored)
+        const float* cf = wp.dz_coef + ((size_t)n * p.C0 + cc);
+        const size_t plane = (size_t)p.N * p.C0;
+        gld4_sbase(cz[0], hoff, cf);
+        gld4_sbase(cz[1], hoff, cf + plane);
+        gld4_sbase(cz[2], hoff, cf + 2 * plane);
+        gld4_sbase(cz[3], hoff, cf + 3 * plane);
+        gld4_sbase(cz[4], hoff, cf + 4 * plane);
+      }
     }
     if (ACT && i == 1) {   // (ACT: every source is an activated tensor - the entry points check)
       const float* al = (first ? p.act0_alpha : p.act1_alpha) + ((size_t)n * Cs + cc);
@@ -203,10 +256,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k * WN_RP] = d[RB + k * WN_RP] = 0.f;
     }
-  auto store_raw = [&](auto ic, auto bc) {   // R: activate, registers -> LDS raw patch (buffer bc)
+  // (DZ: `cst` = the chunk in the registers, or -1 when it is a re-staged tail chunk - its dz
+  // was written already)
+  auto store_raw = [&](auto ic, auto bc, int cst = -1) {   // R: activate, registers -> LDS raw patch (buffer bc)
     constexpr int i = decltype(ic)::value;
     constexpr int B = decltype(bc)::value;
     f32x4 v = pr[i];
+    if constexpr (DZ) {
+      // dz = (z > 0 ? P : P slope) g + (Q y + R),  z = y a1 + b1
+      const f32x4 yv = py[i];
+      const f32x4 z = yv * cz[0] + cz[1];
+      const f32x4 ps = cz[2] * wp.dz_slope;
+      f32x4 sel;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sel[k] = z[k] > 0.f ? cz[2][k] : ps[k];
+      v = sel * v + (cz[3] * yv + cz[4]);
+      if (wrslot[i] && cst >= 0)    // (uniform in cst; EXEC-masked in wrslot)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v, v), rso, voff0[i],
+                                               cst * WN_KC * 4, 0);
+    }
     if (ACT) {
       const f32x4 a1 = ca, b1 = cb;
       const float sl = p.slope;
@@ -338,13 +406,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   auto vm_done = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     reg_anchor(ca, cb);
+    if constexpr (DZ) { reg_anchor(cz[0], cz[1]); reg_anchor(cz[2], cz[3]); reg_anchor(cz[4]); }
   };
   load_raw(0, wn_ic<0>{});
   load_raw(0, wn_ic<1>{});
   wn_for<0, 4>([&](auto ic) { dma_u(0, wn_ic<0>{}, ic); });
   vm_done();
-  store_raw(wn_ic<0>{}, wn_ic<0>{});
-  store_raw(wn_ic<1>{}, wn_ic<0>{});
+  store_raw(wn_ic<0>{}, wn_ic<0>{}, 0);
+  store_raw(wn_ic<1>{}, wn_ic<0>{}, 0);
   load_raw(cl(1), wn_ic<0>{});
   load_raw(cl(1), wn_ic<1>{});
   __syncthreads();
@@ -354,8 +423,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     t_wr(ac, wn_ic<0>{});
   });
   vm_done();
-  store_raw(wn_ic<0>{}, wn_ic<1>{});
-  store_raw(wn_ic<1>{}, wn_ic<1>{});
+  store_raw(wn_ic<0>{}, wn_ic<1>{}, 1 < chunks ? 1 : -1);
+  store_raw(wn_ic<1>{}, wn_ic<1>{}, 1 < chunks ? 1 : -1);
   load_raw(cl(2), wn_ic<0>{});
   load_raw(cl(2), wn_ic<1>{});
   // One chunk, stages of parity B (compile time: every LDS offset of the body is an immediate).
@@ -373,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     reg_anchor(ca, cb);   // (the coefficients are behind the wait)
+    if constexpr (DZ) { reg_anchor(cz[0], cz[1]); reg_anchor(cz[2], cz[3]); reg_anchor(cz[4]); }
     frag(bc, wn_ic<0>{});
     wn_for<0, 16>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
@@ -393,9 +463,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
         if constexpr (x >= 8 && x < 12) t_wr(wn_ic<(x >= 8 && x < 12 ? x - 8 : 0)>{}, NB{});
         if constexpr (x >= 7 && x < 11) t_rd(wn_ic<(x >= 7 && x < 11 ? x - 7 : 0)>{}, NB{});
       }
-      if constexpr (x == 0) store_raw(wn_ic<0>{}, bc);        // chunk c + 2 (loaded an iteration ago)
+      if constexpr (x == 0) store_raw(wn_ic<0>{}, bc, c + 2 < chunks ? c + 2 : -1);   // chunk c + 2 (loaded an iteration ago)
       if constexpr (x == 1) load_raw(cl(c + 3), wn_ic<0>{});
-      if constexpr (x == 2) store_raw(wn_ic<1>{}, bc);
+      if constexpr (x == 2) store_raw(wn_ic<1>{}, bc, c + 2 < chunks ? c + 2 : -1);
       if constexpr (x == 3) load_raw(cl(c + 3), wn_ic<1>{});
       if constexpr (x >= 4 && x < 8) dma_u(cl(c + 1), NB{}, wn_ic<x - 4>{});
       __builtin_amdgcn_sched_barrier(0);
@@ -579,9 +649,9 @@ __global__ __launch_bounds__(256) void wino_pack_batched_kernel(
   wino_pack_items(e.w, e.uf, e.ud, e.Cout, e.Cin, blockIdx.y, (long long)blockIdx.x - e.block_begin);
 }
 
-template <bool ACT, bool STATS, bool BSTATS, bool UP = false>
+template <bool ACT, bool STATS, bool BSTATS, bool UP = false, bool DZ = false>
 int launch_wino(const WinoParams& wp, hipStream_t stream) {
-  auto kern = conv_wino_kernel<ACT, STATS, BSTATS, UP>;
+  auto kern = conv_wino_kernel<ACT, STATS, BSTATS, UP, DZ>;
   UNET_SET_DYN_LDS(kern, WN_LDS);
   const IgemmParams& p = wp.g;
   const long long tiles =
@@ -742,4 +812,51 @@ extern "C" int unet_conv3x3_bwd_data_bs_wino(const float* dy, const float* ud, i
     return launch_wino<false, false, true>(wp, (hipStream_t)stream);
   }
   return launch_wino<false, false, false>(wp, (hipStream_t)stream);
+}
+
+// unet_conv3x3_bwd_data_bs_wino with the InstanceNorm + LeakyReLU + dropout backward of the
+// layer applied ON LOAD (DZ mode of the kernel): g = dL/da (the gradient of the layer's activated
+// output), y = its raw convolution output, coef5 / sums from unet_instnorm_bwd_coefs.  Computes
+// dx as the data gradient of dz = dL/dy, WRITES dz (dz_out: [N][H][W][Cout], must not alias g)
+// for the layer's weight gradient, and the layer's dgamma / dbeta / dbias (each may be null).
+extern "C" int unet_conv3x3_bwd_data_dz_wino(const float* g, const float* y, const float* coef5,
+                                             const float* sums, const float* gamma,
+                                             const float* rstd, float slope, float* dz_out,
+                                             float* dgamma, float* dbeta, float* dbias,
+                                             const float* ud, int Cin_total, int ci_offset,
+                                             float* dx, int N, int H, int W, int Cout, int Ccols,
+                                             unet_bwd_stats* bs, unet_stream_t stream) {
+  UNET_REQUIRE(g && y && coef5 && sums && gamma && rstd && dz_out && ud && dx,
+               "conv3x3_bwd_data_dz_wino: null pointer");
+  UNET_REQUIRE(dz_out != g, "conv3x3_bwd_data_dz_wino: dz must not alias g (halo pixels are re-read)");
+  UNET_REQUIRE(ci_offset >= 0 && ci_offset + Ccols <= Cin_total && Cin_total % WN_BN == 0,
+               "conv3x3_bwd_data_dz_wino: bad channel slice");
+  UNET_REQUIRE(wino_shape_ok(N, H, W, Cout, 0, Ccols, ci_offset),
+               "conv3x3_bwd_data_dz_wino: shape N=%d %dx%d %d->%d not tiled by the Winograd kernel",
+               N, H, W, Cout, Ccols);
+  WinoParams wp{};
+  IgemmParams& p = wp.g;
+  p.src0 = g; p.C0 = Cout; p.C1 = 0;
+  p.src0_bytes = (unsigned)((long long)N * H * W * Cout * 4);
+  p.n_off = ci_offset;
+  p.out = dx; p.ldo = Ccols; p.N = N; p.Hin = p.Hl = p.Hout = H; p.Win = p.Wl = p.Wout = W;
+  p.Ncols = Ccols;
+  wp.wu = ud;
+  wp.dz_y = y; wp.dz_coef = coef5; wp.dz_out = dz_out;
+  wp.dz_sums = reinterpret_cast<const float2*>(sums);
+  wp.dz_gamma = gamma; wp.dz_rstd = rstd; wp.dz_slope = slope;
+  wp.dz_dgamma = dgamma; wp.dz_dbeta = dbeta; wp.dz_dbias = dbias;
+  const bool use_bs = bs && bs->y && bs->mean && bs->rstd && bs->gamma && bs->beta &&
+                      bs->partial &&
+                      bs->partial_bytes >= (size_t)N * (H * W / 256) * Ccols * sizeof(float2);
+  if (bs) bs->tiles_out = 0;
+  if (use_bs) {
+    p.bs_y = bs->y; p.bs_mean = bs->mean; p.bs_rstd = bs->rstd; p.bs_gamma = bs->gamma;
+    p.bs_beta = bs->beta; p.bs_mask = bs->mask; p.slope = bs->slope;
+    p.bs_partial = reinterpret_cast<float2*>(bs->partial);
+    p.bs_tiles = H * W / 256; p.bs_tile0 = 0;
+    bs->tiles_out = p.bs_tiles;
+    return launch_wino<false, false, true, false, true>(wp, (hipStream_t)stream);
+  }
+  return launch_wino<false, false, false, false, true>(wp, (hipStream_t)stream);
 }

@@ -380,6 +380,49 @@ __global__ __launch_bounds__(32 * FL) void in_bwd_finalize1_kernel(const float2*
   }
 }
 
+// Apply-on-load form of pass 2 (round 3): instead of writing dy, emit per (n, c) the five
+// coefficients a consumer needs to form it from (g, y) while it stages them,
+//   dy = (z > 0 ? P : P * slope) * g + (Q * y + R),   z = y * a1 + b1   (the forward's z),
+//   a1 = gamma rstd,  b1 = beta - mean a1,  P = gamma rstd mask,  Q = -gamma rstd^2 c2,
+//   R = -gamma rstd c1 - Q mean      (c1 = S1 / HW, c2 = S2 / HW),
+// as planes coef5[k][n][c], plus sums[n][c] = (S1, S2) for the parameter gradients.
+// Same grid / reduction as in_bwd_finalize1_kernel (which it replaces for such a layer).
+__global__ __launch_bounds__(32 * FL) void in_bwd_coef_kernel(
+    const float2* __restrict__ partial, float* __restrict__ coef5, float2* __restrict__ sums,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mask, int HW, int C, int split, int NC) {
+  __shared__ float sa[FL][33], sb[FL][33];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (int s = l; s < split; s += FL) {
+      const float2 v = partial[((size_t)n * split + s) * C + c];
+      a += v.x;
+      b += v.y;
+    }
+  sa[l][cl] = a; sb[l][cl] = b;
+  __syncthreads();
+  if (l == 0 && c < C) {
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int k = 0; k < FL; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+    const float inv = 1.f / (float)HW;
+    const float c1 = a * inv, c2 = b * inv;
+    const size_t i = (size_t)n * C + c;
+    const float rs = rstd[i], mu = mean[i], g = gamma[c];
+    const float al = g * rs;
+    const float q = -(al * rs) * c2;
+    coef5[i] = al;
+    coef5[(size_t)NC + i] = beta[c] - mu * al;      // same expression as the forward / in_bwd kernels
+    coef5[2 * (size_t)NC + i] = al * (mask ? mask[i] : 1.f);
+    coef5[3 * (size_t)NC + i] = q;
+    coef5[4 * (size_t)NC + i] = -(al * c1) - q * mu;
+    sums[i] = float2{a, b};
+  }
+}
+
 // pass 2: dy = gamma*rstd*(gz - c1 - xhat*c2); per-block column sums of dy -> dbias slabs
 template <typename TS>
 __global__ __launch_bounds__(kThreads) void in_bwd_apply_kernel(
@@ -662,5 +705,23 @@ static int instnorm_bwd_impl(const TS* ga, const TS* y, const float* mean, const
                      dgamma, dbeta, dbias);
   UNET_CHECK_LAUNCH("in_bwd_apply");
   (void)dbp; (void)dbstage;
+  return UNET_OK;
+}
+
+// Coefficients of the apply-on-load InstanceNorm backward (in_bwd_coef_kernel above) from the
+// per-tile reductions a data-gradient epilogue left (unet_bwd_stats): coef5 = [5][N][C] floats,
+// sums = [N][C][2] floats.  Consumed by unet_conv3x3_bwd_data_dz_wino.
+extern "C" int unet_instnorm_bwd_coefs(const void* partial, int tiles, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta,
+                                       const float* mask, float* coef5, float* sums, int N, int HW,
+                                       int C, unet_stream_t stream) {
+  UNET_REQUIRE(partial && tiles > 0 && mean && rstd && gamma && beta && coef5 && sums && N > 0 &&
+                   HW > 0 && C > 0,
+               "instnorm_bwd_coefs: bad argument");
+  hipLaunchKernelGGL(in_bwd_coef_kernel, dim3(ceil_div(C, 32), N), dim3(32 * FL), 0,
+                     (hipStream_t)stream, reinterpret_cast<const float2*>(partial), coef5,
+                     reinterpret_cast<float2*>(sums), mean, rstd, gamma, beta, mask, HW, C, tiles,
+                     N * C);
+  UNET_CHECK_LAUNCH("in_bwd_coef");
   return UNET_OK;
 }

@@ -48,6 +48,7 @@ __device__ __forceinline__ void dma16_sbase(unsigned m0v, unsigned lane_off, con
 __device__ __forceinline__ void reg_anchor(f32x4& a, f32x4& b) {
   asm volatile("" : "+v"(a), "+v"(b) :: "memory");
 }
+__device__ __forceinline__ void reg_anchor(f32x4& a) { asm volatile("" : "+v"(a) :: "memory"); }
 
 
 // ds_read2st64_b32: two floats 256-byte units apart (offsets in units of 256 B from `a`)

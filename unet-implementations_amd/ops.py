@@ -460,6 +460,41 @@ def instnorm_lrelu_drop_bwd(ga, y, mean, rstd, gamma, beta, mask, slope, dgamma,
     return dy
 
 
+def instnorm_bwd_coefs(y, mean, rstd, gamma, beta, mask, partials):
+    """Apply-on-load form of the InstanceNorm + LeakyReLU + dropout backward: from the per-tile
+    reductions `partials` = (buffer, tiles) the coefficient planes coef5 [5, N, C] and the sums
+    [N, C, 2] that `conv3x3_bwd_data_dz` consumes (no elementwise pass over the layer tensor)."""
+    N, H, W, C = y.shape
+    coef5 = _f32((5, N, C), y)
+    sums = _f32((N, C, 2), y)
+    check(lib().unet_instnorm_bwd_coefs(_ptr(partials[0]), partials[1], _ptr(mean), _ptr(rstd),
+                                        _ptr(gamma), _ptr(beta), _ptr(mask), _ptr(coef5),
+                                        _ptr(sums), N, H * W, C, _stream()))
+    return coef5, sums
+
+
+def conv3x3_bwd_data_dz(g, y, coef5, sums, gamma, rstd, slope, dgamma, dbeta, dbias, ud,
+                        cin_total, ci_offset, ccols, nxt=None):
+    """Winograd data gradient whose loader applies the InstanceNorm backward of the layer to
+    (g, y) on the fly (unet_conv3x3_bwd_data_dz_wino).  Returns (dx, dz): dz = dL/dy of the
+    layer, written as a by-product for its weight gradient; dgamma / dbeta / dbias are filled."""
+    N, H, W, Cout = g.shape
+    dx = _f32((N, H, W, ccols), g)
+    dz = _f32((N, H, W, Cout), g)
+    bs = nxt.c_struct() if nxt is not None else None
+    t0 = _timer.begin("conv") if _timer is not None else None
+    check(lib().unet_conv3x3_bwd_data_dz_wino(
+        _ptr(g), _ptr(y), _ptr(coef5), _ptr(sums), _ptr(gamma), _ptr(rstd), slope, _ptr(dz),
+        _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ud), cin_total, ci_offset, _ptr(dx), N, H, W,
+        Cout, ccols, ctypes.byref(bs) if bs is not None else None, _stream()))
+    if nxt is not None:
+        nxt.tiles = bs.tiles_out
+    if t0 is not None:
+        alg = 2.0 * N * H * W * 9 * ccols * Cout
+        _timer.end("conv_igemm", alg, 1, t0, executed=alg * 16.0 / 36.0)
+    return dx, dz
+
+
 # ---- fused layer pipeline (include/unet_hip.h) ---------------------------------------------
 class Act:
     """An operand that is activated on load: `x` is the RAW output of a convolution (NHWC)

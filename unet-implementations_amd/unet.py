@@ -213,6 +213,12 @@ class UNet(nn.Module):
         # fp32 fused pipeline: run the stride-1 3x3 layers the Winograd F(2x2,3x3) kernel tiles
         # on it (2.25x fewer matrix-core FLOPs, a few extra fp32 roundings: csrc/conv_wino.hip)
         self.winograd = True
+        # fp32 fused pipeline, OFF by default: where a layer's gradient dL/dy is consumed by a
+        # Winograd data gradient, apply the InstanceNorm + LeakyReLU + dropout backward in that
+        # kernel's loader (which also writes dL/dy for the weight gradient) instead of the
+        # elementwise pass.  Measured: 12 of the 22 elementwise passes go (-0.38
+        # ms) but the second operand in the loader costs the data gradients +0.43 ms.
+        self.fold_instnorm_backward = False
         # normalisation constants of forward(..., input_layout="nhwc_u8") (ImageNet, as the
         # reference's dataset: Our_UNet/src/train.py:303-308)
         self.input_mean, self.input_std = ops.IMAGENET_MEAN, ops.IMAGENET_STD
@@ -693,11 +699,6 @@ class _UNetFunction(torch.autograd.Function):
             if dbg is not None:
                 dbg.append((l.name, "ga", g_a.clone()))
             nn_ = rec.pop("nxt", None)     # reductions left by the kernel that produced g_a
-            dy = ops.instnorm_lrelu_drop_bwd(g_a, rec["y"], st[0], st[1], l.norm.weight.detach(),
-                                             l.norm.bias.detach(), rec["mask"], l.slope,
-                                             gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias),
-                                             partials=(nn_.partial, nn_.tiles)
-                                             if nn_ is not None and nn_.tiles > 0 else None)
             # dx0 of this layer is the final gradient of the previous layer's output (the skip
             # halves dx1 are accumulated into later, by the encoder): its producer also emits
             # that layer's InstanceNorm-backward reductions
@@ -707,12 +708,39 @@ class _UNetFunction(torch.autograd.Function):
                 pl_ = pr_["layer"]
                 nxt = ops.NextNorm(pr_["y"], pr_["st"], pl_.norm.weight.detach(),
                                    pl_.norm.bias.detach(), pr_["mask"], pl_.slope)
+            x0, x1 = rec["x0"], rec["x1"]
+            low = rec.get("x0_low")
+            # InstanceNorm backward applied ON LOAD by the layer's Winograd data gradient (which
+            # also writes dy for the weight gradient): no elementwise pass over the layer tensor.
+            # Needs the reductions from the producer of g_a and a Winograd data gradient of this dy.
+            dx_fold = None
+            fold_ud = rec.get("ud1") if low is not None else rec.get("ud")
+            if model.fold_instnorm_backward and nn_ is not None and nn_.tiles > 0 and \
+                    fold_ud is not None and not dx0_acc and dx0_out is None and \
+                    (need_dx1 if low is not None else (need_dx and x1 is None)):
+                coef5, sums = ops.instnorm_bwd_coefs(rec["y"], st[0], st[1], l.norm.weight.detach(),
+                                                     l.norm.bias.detach(), rec["mask"],
+                                                     (nn_.partial, nn_.tiles))
+                w_ = l.conv.weight
+                c0_ = low.shape[3] if low is not None else 0
+                cc_ = x1.shape[3] if low is not None else x0.shape[3]
+                dx_fold, dy = ops.conv3x3_bwd_data_dz(
+                    g_a, rec["y"], coef5, sums, l.norm.weight.detach(), st[1], l.slope,
+                    gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias), fold_ud, w_.shape[1], c0_,
+                    cc_, nxt=None if low is not None else nxt)
+                if nxt is not None and low is None:
+                    saved[i - 1]["nxt"] = nxt
+            else:
+                dy = ops.instnorm_lrelu_drop_bwd(g_a, rec["y"], st[0], st[1],
+                                                 l.norm.weight.detach(), l.norm.bias.detach(),
+                                                 rec["mask"], l.slope, gv(l.norm.weight),
+                                                 gv(l.norm.bias), gv(l.conv.bias),
+                                                 partials=(nn_.partial, nn_.tiles)
+                                                 if nn_ is not None and nn_.tiles > 0 else None)
             if dbg is not None:
                 dbg.append((l.name, "dy", dy.clone()))
-            x0, x1 = rec["x0"], rec["x1"]
             dw = gv(l.conv.weight)
             want_dw = l.conv.weight.requires_grad
-            low = rec.get("x0_low")
             if low is not None:
                 # conv3x3(upsample2x(act(low))): both gradients of the up-sampled operand are
                 # GEMMs over the LOW-resolution pixels once dy is reduced to its nine D_tap
@@ -724,8 +752,8 @@ class _UNetFunction(torch.autograd.Function):
                 g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0, nxt=nxt) if need_dx else None
                 if nxt is not None:
                     saved[i - 1]["nxt"] = nxt
-                dx1 = None
-                if need_dx1:
+                dx1 = dx_fold
+                if need_dx1 and dx1 is None:
                     dx1 = ops.conv3x3_bwd_data(dy, rec["wd"], C0, x1.shape[3], x1.shape[1],
                                                x1.shape[2], 1, wd3=rec["wd3"],
                                                bf16="bf16x3" if rec["wd3"] is not None else False,
@@ -751,7 +779,9 @@ class _UNetFunction(torch.autograd.Function):
                     ops.conv3x3_bwd_weight(x1, dy, dw, x0.shape[3], l.stride, bf16=ctx.bf16)
             dx0 = dx1 = None
             N, H, W, C0 = x0.shape
-            if need_dx:
+            if dx_fold is not None:
+                dx0 = dx_fold
+            elif need_dx:
                 dx0 = ops.conv3x3_bwd_data(dy, rec["wd"], 0, C0, H, W, l.stride, out=dx0_out,
                                            accumulate=dx0_acc, bf16=ctx.bf16, wd3=rec["wd3"],
                                            nxt=nxt, ud=rec.get("ud"))
