@@ -186,17 +186,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       l_meta[i] = (gx1 - gx0) | ((gy1 - gy0) << 1) | ((pcol & 1) << 2) | ((prow & 1) << 3);
     }
   }
-  f32x4 pr[2];
+  // Register sets of the loader.  Plain variants: TWO sets, used alternately by chunk parity -
+  // the loads of chunk c + 4 are issued in iteration c, behind its DMA pieces, and may stay in
+  // flight across the next barrier (the loop top waits only for everything OLDER than them: the
+  // DMA): two whole iterations before they are stored.  With one set (up-sampling and DZ
+  // variants: no registers left) the loads of chunk c + 3 precede the DMA and the barrier waits
+  // for them.
+  constexpr int NSET = (UP || DZ) ? 1 : 2;
+  f32x4 pr[NSET][2];
   f32x4 pt[UP ? 2 : 1][3];   // UP: the other three taps of a slot
   bool pup = false;           // the chunk in the registers is a low-resolution (gathered) one
-  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ca[NSET], cb[NSET];
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) { ca[q] = f32x4{1.f, 1.f, 1.f, 1.f}; cb[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   f32x4 py[DZ ? 2 : 1];            // DZ: the y values of the two slots
   f32x4 cz[DZ ? 5 : 1];            // DZ: a1, b1, P, Q, R of this lane's four channels
   const unsigned hoff = (unsigned)half * 16u;   // this lane's 16 bytes of a chunk's coefficients
   // G: global -> registers, one slot per call.  Slot 1's call also fetches the chunk's coefficients
   // and source kind: it runs AFTER both slots of the previous chunk were stored
-  auto load_raw = [&](int chunk, auto ic) {
+  auto load_raw = [&](int chunk, auto ic, auto setc) {
     constexpr int i = decltype(ic)::value;
+    constexpr int Q = decltype(setc)::value;
     const int c = chunk * WN_KC;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       const unsigned o = (unsigned)(l_lin[i] * Cs + cc + half * 4);
       const unsigned dx = (l_meta[i] & 1) ? (unsigned)Cs : 0u;
       const unsigned dy = (l_meta[i] & 2) ? (unsigned)(lw * Cs) : 0u;
-      pr[i] = buf_ld4<float>(rs, o, 0u);
+      pr[Q][i] = buf_ld4<float>(rs, o, 0u);
       if constexpr (UP) {
         pt[i][0] = buf_ld4<float>(rs, o + dx, 0u);
         pt[i][1] = buf_ld4<float>(rs, o + dy, 0u);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       if (UP && i == 1) pup = false;
       unsigned vo = voff1[i];
       if constexpr (!UP) vo = first ? voff0[i] : voff1[i];
-      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cc * 4, 0));
+      pr[Q][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cc * 4, 0));
       if constexpr (DZ)
         py[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, vo, cc * 4, 0));
     }
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       // the loaded coefficients are only looked at when the patch is stored, an iteration later
       // (scalar base + 32-bit lane offset by hand: hipcc builds a 64-bit VALU address; the
       // chunk_body's s_waitcnt vmcnt(0) + anchor stand in for the compiler's tracking)
-      gld4_sbase(ca, hoff, al);
-      gld4_sbase(cb, hoff, be);
+      gld4_sbase(ca[Q], hoff, al);
+      gld4_sbase(cb[Q], hoff, be);
     }
   };
   // raw patch position of slot i (slots past the patch: never stored)
@@ -258,10 +268,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     }
   // (DZ: `cst` = the chunk in the registers, or -1 when it is a re-staged tail chunk - its dz
   // was written already)
-  auto store_raw = [&](auto ic, auto bc, int cst = -1) {   // R: activate, registers -> LDS raw patch (buffer bc)
+  auto store_raw = [&](auto ic, auto bc, auto setc, int cst = -1) {   // R: activate, registers -> LDS raw patch (buffer bc)
     constexpr int i = decltype(ic)::value;
     constexpr int B = decltype(bc)::value;
-    f32x4 v = pr[i];
+    constexpr int Q = decltype(setc)::value;
+    f32x4 v = pr[Q][i];
     if constexpr (DZ) {
       // dz = (z > 0 ? P : P slope) g + (Q y + R),  z = y a1 + b1
       const f32x4 yv = py[i];
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
                                                cst * WN_KC * 4, 0);
     }
     if (ACT) {
-      const f32x4 a1 = ca, b1 = cb;
+      const f32x4 a1 = ca[Q], b1 = cb[Q];
       const float sl = p.slope;
       bool done = false;
       if constexpr (UP) {
@@ -400,37 +411,64 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
     }
   };
 
-  // ---- prologue: chunk 0 transformed, chunk 1 raw in LDS, chunk 2 in the registers ----
+  // ---- prologue: chunk 0 transformed, chunk 1 raw in LDS, chunk 2 (and, with two register
+  //      sets, chunk 3) in the registers ----
+  using S0 = wn_ic<0>;
+  using S1 = wn_ic<NSET - 1>;
   auto cl = [&](int c) { return c < chunks ? c : chunks - 1; };   // the tail re-stages the last chunk
   // (the coefficient loads and the DMA are not tracked by the compiler: explicit waits)
   auto vm_done = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    reg_anchor(ca, cb);
+#pragma unroll
+    for (int q = 0; q < NSET; ++q) reg_anchor(ca[q], cb[q]);
     if constexpr (DZ) { reg_anchor(cz[0], cz[1]); reg_anchor(cz[2], cz[3]); reg_anchor(cz[4]); }
   };
-  load_raw(0, wn_ic<0>{});
-  load_raw(0, wn_ic<1>{});
-  wn_for<0, 4>([&](auto ic) { dma_u(0, wn_ic<0>{}, ic); });
-  vm_done();
-  store_raw(wn_ic<0>{}, wn_ic<0>{}, 0);
-  store_raw(wn_ic<1>{}, wn_ic<0>{}, 0);
-  load_raw(cl(1), wn_ic<0>{});
-  load_raw(cl(1), wn_ic<1>{});
-  __syncthreads();
-  wn_for<0, 4>([&](auto ac) {
-    t_rd(ac, wn_ic<0>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    t_wr(ac, wn_ic<0>{});
-  });
-  vm_done();
-  store_raw(wn_ic<0>{}, wn_ic<1>{}, 1 < chunks ? 1 : -1);
-  store_raw(wn_ic<1>{}, wn_ic<1>{}, 1 < chunks ? 1 : -1);
-  load_raw(cl(2), wn_ic<0>{});
-  load_raw(cl(2), wn_ic<1>{});
+  if constexpr (NSET == 2) {
+    load_raw(0, wn_ic<0>{}, S0{});
+    load_raw(0, wn_ic<1>{}, S0{});
+    load_raw(cl(1), wn_ic<0>{}, S1{});
+    load_raw(cl(1), wn_ic<1>{}, S1{});
+    wn_for<0, 4>([&](auto ic) { dma_u(0, wn_ic<0>{}, ic); });
+    vm_done();
+    store_raw(wn_ic<0>{}, wn_ic<0>{}, S0{}, 0);
+    store_raw(wn_ic<1>{}, wn_ic<0>{}, S0{}, 0);
+    store_raw(wn_ic<0>{}, wn_ic<1>{}, S1{}, 1 < chunks ? 1 : -1);
+    store_raw(wn_ic<1>{}, wn_ic<1>{}, S1{}, 1 < chunks ? 1 : -1);
+    load_raw(cl(2), wn_ic<0>{}, S0{});
+    load_raw(cl(2), wn_ic<1>{}, S0{});
+    load_raw(cl(3), wn_ic<0>{}, S1{});
+    load_raw(cl(3), wn_ic<1>{}, S1{});
+    __syncthreads();
+    wn_for<0, 4>([&](auto ac) {
+      t_rd(ac, wn_ic<0>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t_wr(ac, wn_ic<0>{});
+    });
+  } else {
+    load_raw(0, wn_ic<0>{}, S0{});
+    load_raw(0, wn_ic<1>{}, S0{});
+    wn_for<0, 4>([&](auto ic) { dma_u(0, wn_ic<0>{}, ic); });
+    vm_done();
+    store_raw(wn_ic<0>{}, wn_ic<0>{}, S0{}, 0);
+    store_raw(wn_ic<1>{}, wn_ic<0>{}, S0{}, 0);
+    load_raw(cl(1), wn_ic<0>{}, S0{});
+    load_raw(cl(1), wn_ic<1>{}, S0{});
+    __syncthreads();
+    wn_for<0, 4>([&](auto ac) {
+      t_rd(ac, wn_ic<0>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t_wr(ac, wn_ic<0>{});
+    });
+    vm_done();
+    store_raw(wn_ic<0>{}, wn_ic<1>{}, S0{}, 1 < chunks ? 1 : -1);
+    store_raw(wn_ic<1>{}, wn_ic<1>{}, S0{}, 1 < chunks ? 1 : -1);
+    load_raw(cl(2), wn_ic<0>{}, S0{});
+    load_raw(cl(2), wn_ic<1>{}, S0{});
+  }
   // One chunk, stages of parity B (compile time: every LDS offset of the body is an immediate).
   // Branch-free, ONE barrier.  One stage per xi: its 4 MFMAs, the fragment reads of the next xi,
-  // and one piece of the staging pipeline, three chunks deep: the raw patch of chunk c + 2 from
-  // the registers to LDS, the loads of chunk c + 3, U of chunk c + 1 by DMA, the input
+  // and one piece of the staging pipeline: the raw patch of chunk c + 2 from the registers to
+  // LDS, the loads of chunk c + 3 (two register sets: c + 4), U of chunk c + 1 by DMA, the input
   // transform of chunk c + 1 (raw patch double-buffered, so it needs no barrier of its own) -
   // each stage fenced so nothing bunches up.
   // At the barrier: every DMA of this wave has landed, every wave is done with stage B ^ 1, with
@@ -439,9 +477,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
   auto chunk_body = [&](int c, auto bc) {
     constexpr int B = decltype(bc)::value;
     using NB = wn_ic<B ^ 1>;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    using SB = wn_ic<(NSET == 2 ? B : 0)>;        // the register set this iteration stores / reloads
+    if constexpr (NSET == 2) {
+      // everything older than the previous iteration's loads (its DMA pieces): those loads - two
+      // buffer loads and, ACT, two coefficient loads - may stay in flight
+      if constexpr (ACT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    reg_anchor(ca, cb);   // (the coefficients are behind the wait)
+    reg_anchor(ca[SB::value], cb[SB::value]);   // (the coefficients are behind the wait)
     if constexpr (DZ) { reg_anchor(cz[0], cz[1]); reg_anchor(cz[2], cz[3]); reg_anchor(cz[4]); }
     frag(bc, wn_ic<0>{});
     wn_for<0, 16>([&](auto xc) {
@@ -463,11 +509,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
         if constexpr (x >= 8 && x < 12) t_wr(wn_ic<(x >= 8 && x < 12 ? x - 8 : 0)>{}, NB{});
         if constexpr (x >= 7 && x < 11) t_rd(wn_ic<(x >= 7 && x < 11 ? x - 7 : 0)>{}, NB{});
       }
-      if constexpr (x == 0) store_raw(wn_ic<0>{}, bc, c + 2 < chunks ? c + 2 : -1);   // chunk c + 2 (loaded an iteration ago)
-      if constexpr (x == 1) load_raw(cl(c + 3), wn_ic<0>{});
-      if constexpr (x == 2) store_raw(wn_ic<1>{}, bc, c + 2 < chunks ? c + 2 : -1);
-      if constexpr (x == 3) load_raw(cl(c + 3), wn_ic<1>{});
-      if constexpr (x >= 4 && x < 8) dma_u(cl(c + 1), NB{}, wn_ic<x - 4>{});
+      if constexpr (NSET == 2) {
+        // chunk c + 2 (loaded two iterations ago) to LDS, the DMA, then the loads of chunk c + 4
+        if constexpr (x == 0) store_raw(wn_ic<0>{}, bc, SB{}, c + 2 < chunks ? c + 2 : -1);
+        if constexpr (x == 1) store_raw(wn_ic<1>{}, bc, SB{}, c + 2 < chunks ? c + 2 : -1);
+        if constexpr (x >= 2 && x < 6) dma_u(cl(c + 1), NB{}, wn_ic<(x >= 2 && x < 6 ? x - 2 : 0)>{});
+        if constexpr (x == 6) load_raw(cl(c + 4), wn_ic<0>{}, SB{});
+        if constexpr (x == 7) load_raw(cl(c + 4), wn_ic<1>{}, SB{});
+      } else {
+        if constexpr (x == 0) store_raw(wn_ic<0>{}, bc, SB{}, c + 2 < chunks ? c + 2 : -1);   // chunk c + 2 (loaded an iteration ago)
+        if constexpr (x == 1) load_raw(cl(c + 3), wn_ic<0>{}, SB{});
+        if constexpr (x == 2) store_raw(wn_ic<1>{}, bc, SB{}, c + 2 < chunks ? c + 2 : -1);
+        if constexpr (x == 3) load_raw(cl(c + 3), wn_ic<1>{}, SB{});
+        if constexpr (x >= 4 && x < 8) dma_u(cl(c + 1), NB{}, wn_ic<(x >= 4 && x < 8 ? x - 4 : 0)>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
