@@ -416,6 +416,14 @@ int unet_upsample2x_in_fwd(const unet_act_src* x, float slope, float* up, int N,
  */
 int unet_upsample2x_bwd_taps(const float* dy, float* D, int N, int h, int w, int C,
                              unet_stream_t stream);
+/* General bilinear resize of NCHW planes, align_corners = False (x: [planes][h][w] ->
+ * y: [planes][H][W]) and its adjoint (gather form, deterministic): the F.interpolate of
+ * SimpleLoss for logits whose size differs from the target's (Our_UNet/models/losses.py:66-68)
+ * and of CLIP_UNet's bottleneck features (CLIP_UNet/models/unet.py:444-450). */
+int unet_resize_bilinear_fwd(const float* x, float* y, int planes, int h, int w, int H, int W,
+                             unet_stream_t stream);
+int unet_resize_bilinear_bwd(const float* gy, float* gx, int planes, int h, int w, int H, int W,
+                             unet_stream_t stream);
 size_t unet_conv3x3_up_bwd_weight_workspace_bytes(int N, int h, int w, int Cx, int Cout);
 int unet_conv3x3_up_bwd_weight(const unet_act_src* x, float slope, const float* D, float* dw_oihw,
                                int ci_offset, int Cin_total, void* workspace,

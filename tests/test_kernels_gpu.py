@@ -765,3 +765,26 @@ def test_conv3x3_bench_size_layer(ua, mode):
     ua.ops.conv3x3_bwd_data(to_nhwc(gy), wd, 0, C, H, H, 1, out=acc, accumulate=True, bf16=mode,
                             **kw_d)
     check(from_nhwc(acc), gx + 1.0, 2e-5, f"{mode} dgrad accumulate")
+
+
+@pytest.mark.parametrize("case", [(2, 3, 64, 64, 128, 128), (1, 3, 48, 80, 96, 200),
+                                  (2, 5, 20, 12, 16, 16), (1, 4, 33, 17, 16, 40)])
+def test_resize_bilinear_matches_torch_interpolate(ua, case):
+    """unet_resize_bilinear_fwd / _bwd (the logits resize of SimpleLoss, losses.py:66-68, and the
+    CLIP feature resize, CLIP_UNet/models/unet.py:444-450) against F.interpolate(bilinear,
+    align_corners=False) and its autograd, up- and down-scaling, non-integer ratios."""
+    import torch.nn.functional as F
+    N, C, h, w, H, W = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, h, w, generator=g)
+    gy = torch.randn(N, C, H, W, generator=g)
+    # (the reference is the fp32 CPU op: source indices and weights are computed in fp32 there
+    # too; an fp64 evaluation differs from either by the rounding of the weights, ~1e-5)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(H, W), mode="bilinear", align_corners=False)
+    yr.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = ua.ops.resize_bilinear(xd, (H, W))
+    y.backward(gy.to(DEV))
+    assert (y.detach().cpu() - yr.detach()).abs().max() <= 2e-6 * yr.abs().max()
+    assert (xd.grad.cpu() - xr.grad).abs().max() <= 5e-6 * xr.grad.abs().max()

@@ -978,3 +978,41 @@ def test_uint8_batch_through_the_fused_stem(ua):
         a = model(x96, input_layout="nhwc_u8")
         b = model(ua.ops.preprocess_u8(x96)[0], input_layout="nhwc")
     assert torch.equal(a, b)
+
+
+def test_loss_resizes_logits_to_the_target_like_the_reference(ua):
+    """SimpleLoss.forward with logits at half the target's resolution
+    (Our_UNet/models/losses.py:66-68): loss and the gradient w.r.t. the low-resolution logits
+    against the oracle's loss on F.interpolate'd logits."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(8)
+    logits = torch.randn(2, 3, 32, 48, generator=g)
+    _, tgt = O.synthetic_batch(4, 2, 64, 96)
+    lr = logits.clone().requires_grad_(True)
+    ref = O.simple_loss(F.interpolate(lr, size=(64, 96), mode="bilinear", align_corners=False), tgt)
+    ref.backward()
+    ld = logits.to(DEV).requires_grad_(True)
+    loss = ua.get_loss_function()(ld, tgt.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    assert (ld.grad.cpu() - lr.grad).abs().max() <= 5e-5 * lr.grad.abs().max()
+
+
+def test_clip_features_of_another_size_are_resized_to_the_bottleneck_grid(ua, golden):
+    """CLIP_UNet/models/unet.py:444-450: features whose spatial size differs from the bottleneck's
+    are resized bilinearly first.  Features given at twice the grid must produce the logits of
+    their F.interpolate'd version passed directly."""
+    import torch.nn.functional as F
+    g = golden("clip64")
+    n, hw, clip_dim = int(g["n"]), int(g["hw"]), int(g["clip_dim"])
+    model = ua.CLIPUNet(with_clip_features=True, clip_dim=clip_dim)
+    model.load_state_dict(O.fill_state_dict(int(g["seed_w"]), clip_dim=clip_dim))
+    model = model.to(DEV).eval()
+    img, _ = O.synthetic_batch(int(g["seed_x"]), n, hw, hw)
+    big = torch.randn(n, clip_dim, 2 * (hw // 32), 2 * (hw // 32),
+                      generator=torch.Generator().manual_seed(1))
+    small = F.interpolate(big, size=(hw // 32, hw // 32), mode="bilinear", align_corners=False)
+    with torch.no_grad():
+        a = model(img.to(DEV), big.to(DEV))
+        b = model(img.to(DEV), small.to(DEV))
+    assert relerr(a, b) <= 1e-5

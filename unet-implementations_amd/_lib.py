@@ -72,6 +72,8 @@ SIGNATURES = {
     "unet_instnorm_lrelu_drop_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _sz,
                                           _i, _i, _i, _p]),
     "unet_upsample2x_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "unet_resize_bilinear_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "unet_resize_bilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "unet_upsample2x_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "unet_head1x1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "unet_head1x1_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -56,4 +56,11 @@ class CLIPUNet(UNet):
                              "built, CLIP_UNet/models/unet.py:459-474; pass clip_dim instead)")
         if not clip_features.is_cuda:
             raise RuntimeError("clip_features must live on the ROCm device (no CPU fallback exists)")
-        return ops.nchw_to_nhwc(clip_features.detach().contiguous().float())
+        f = clip_features.detach().contiguous().float()
+        n_down = self.n_stages - 1
+        grid = (x.shape[2] >> n_down, x.shape[3] >> n_down)
+        if tuple(f.shape[2:]) != grid:
+            # the reference resizes the features to the bottleneck grid
+            # (CLIP_UNet/models/unet.py:444-450: bilinear, align_corners=False)
+            f = ops.resize_bilinear(f, grid)
+        return ops.nchw_to_nhwc(f)

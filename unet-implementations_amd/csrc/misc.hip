@@ -386,6 +386,90 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const TS* __re
   }
 }
 
+// ---- general bilinear resize of NCHW planes (align_corners = False) -------------------------
+// F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False) as SimpleLoss applies it
+// to logits whose size differs from the target's (Our_UNet/models/losses.py:66-68) and CLIP_UNet
+// to the bottleneck features (CLIP_UNet/models/unet.py:444-450).  PyTorch's source index:
+// src = max((dst + 0.5) * (in / out) - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, in - 1),
+// weights (1 - l, l) with l = src - i0; blend order w0y (w0x p00 + w1x p01) + w1y (...).
+__device__ __forceinline__ void bil_src(int dst, float scale, int in, int& i0, int& i1, float& l) {
+  float src = ((float)dst + 0.5f) * scale - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 > in - 1 ? in - 1 : i0;
+  i1 = i0 + 1 > in - 1 ? in - 1 : i0 + 1;
+  l = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const float* __restrict__ x,
+                                                                  float* __restrict__ y, int h,
+                                                                  int w, int H, int W,
+                                                                  long long total) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int X = (int)(i % W);
+    const long long r = i / W;
+    const int Y = (int)(r % H);
+    const long long pl = r / H;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_src(Y, sy, h, y0, y1, ly);
+    bil_src(X, sx, w, x0, x1, lx);
+    const float* p = x + pl * (long long)h * w;
+    const float top = (1.f - lx) * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1];
+    const float bot = (1.f - lx) * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1];
+    y[i] = (1.f - ly) * top + ly * bot;
+  }
+}
+// Adjoint, gather form (deterministic: no float atomics): input pixel (iy, ix) sums the output
+// pixels whose stencil touches it.  Output rows that can reference input row iy have
+// src in (iy - 1, iy + 1), i.e. dst in ((iy - 0.5) / scale - 0.5, (iy + 1.5) / scale - 0.5).
+__device__ __forceinline__ void bil_range(int i, float scale, int out, int& lo, int& hi) {
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out - 1 ? out - 1 : hi;
+}
+__device__ __forceinline__ float bil_coef(int dst, float scale, int in, int i) {
+  int i0, i1;
+  float l;
+  bil_src(dst, scale, in, i0, i1, l);
+  float c = 0.f;
+  if (i0 == i) c += 1.f - l;
+  if (i1 == i) c += l;
+  return c;
+}
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* __restrict__ gy,
+                                                                  float* __restrict__ gx, int h,
+                                                                  int w, int H, int W,
+                                                                  long long total) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int ix = (int)(i % w);
+    const long long r = i / w;
+    const int iy = (int)(r % h);
+    const long long pl = r / h;
+    int ylo, yhi, xlo, xhi;
+    bil_range(iy, sy, H, ylo, yhi);
+    bil_range(ix, sx, W, xlo, xhi);
+    const float* g = gy + pl * (long long)H * W;
+    float acc = 0.f;
+    for (int Y = ylo; Y <= yhi; ++Y) {
+      const float cy = bil_coef(Y, sy, h, iy);
+      if (cy == 0.f) continue;
+      float row = 0.f;
+      for (int X = xlo; X <= xhi; ++X) {
+        const float cx = bil_coef(X, sx, w, ix);
+        if (cx != 0.f) row += cx * g[(size_t)Y * W + X];
+      }
+      acc += cy * row;
+    }
+    gx[i] = acc;
+  }
+}
+
 // ---- SGD with Nesterov momentum ------------------------------------------------
 // hyper != nullptr: {lr, mu, wd, gscale} are read from device memory (graph-captured steps)
 __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p,
@@ -615,5 +699,27 @@ extern "C" int unet_preprocess_u8(const uint8_t* image_hwc, const uint8_t* mask,
                      reinterpret_cast<long long*>(target), pixels, mean3[0], mean3[1], mean3[2],
                      std3[0], std3[1], std3[2]);
   UNET_CHECK_LAUNCH("preprocess_u8");
+  return UNET_OK;
+}
+
+extern "C" int unet_resize_bilinear_fwd(const float* x, float* y, int planes, int h, int w, int H,
+                                        int W, unet_stream_t stream) {
+  UNET_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0,
+               "resize_bilinear_fwd: bad argument");
+  const long long total = (long long)planes * H * W;
+  hipLaunchKernelGGL(resize_bilinear_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, h, w, H, W, total);
+  UNET_CHECK_LAUNCH("resize_bilinear_fwd");
+  return UNET_OK;
+}
+
+extern "C" int unet_resize_bilinear_bwd(const float* gy, float* gx, int planes, int h, int w, int H,
+                                        int W, unet_stream_t stream) {
+  UNET_REQUIRE(gy && gx && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0,
+               "resize_bilinear_bwd: bad argument");
+  const long long total = (long long)planes * h * w;
+  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, gy, gx, h, w, H, W, total);
+  UNET_CHECK_LAUNCH("resize_bilinear_bwd");
   return UNET_OK;
 }

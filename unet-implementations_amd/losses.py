@@ -78,7 +78,8 @@ class SimpleLoss(nn.Module):
             raise RuntimeError("unet-implementations_amd.SimpleLoss runs on MI355X only "
                                "(no CPU fallback exists)")
         if input.shape[-2:] != target.shape[-2:]:
-            raise NotImplementedError("logits and target must have the same H, W on the HIP path")
+            # the reference resizes the logits to the target (Our_UNet/models/losses.py:66-68)
+            input = ops.resize_bilinear(input, target.shape[-2:])
         if target.dtype != torch.int64:
             target = target.long()
         cw = None

@@ -495,6 +495,32 @@ def conv3x3_bwd_data_dz(g, y, coef5, sums, gamma, rstd, slope, dgamma, dbeta, db
     return dx, dz
 
 
+class _ResizeBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        n, c, h, w = x.shape
+        x = x.contiguous().float()
+        y = _f32((n, c, H, W), x)
+        check(lib().unet_resize_bilinear_fwd(_ptr(x), _ptr(y), n * c, h, w, H, W, _stream()))
+        ctx.hw = (h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, c, H, W = gy.shape
+        h, w = ctx.hw
+        gy = gy.contiguous().float()
+        gx = _f32((n, c, h, w), gy)
+        check(lib().unet_resize_bilinear_bwd(_ptr(gy), _ptr(gx), n * c, h, w, H, W, _stream()))
+        return gx, None, None
+
+
+def resize_bilinear(x, size):
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) of an NCHW fp32 tensor
+    on the HIP kernels (differentiable; the backward is the deterministic gather-form adjoint)."""
+    return _ResizeBilinear.apply(x, int(size[0]), int(size[1]))
+
+
 # ---- fused layer pipeline (include/unet_hip.h) ---------------------------------------------
 class Act:
     """An operand that is activated on load: `x` is the RAW output of a convolution (NHWC)
