@@ -257,6 +257,71 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const TS* __restric
   }
 }
 
+// The same for bf16 tensors (mixed-precision pipeline), organised by LOW-resolution pixel: one
+// thread = one input pixel x 8 channels (16-byte loads / stores): its 3 x 3 neighbourhood is
+// loaded and activated ONCE (9 loads for 4 outputs instead of 16, 9 activations instead of 16)
+// and the 2 x 2 output block is blended with PyTorch's weights and operation order:
+// output row 2i   = taps (i-1, i) x (0.25, 0.75)   [i = 0: the clamped source index is 0: (0, 1)]
+// output row 2i+1 = taps (i, i+1) x (0.75, 0.25)   [i = h-1: tap i+1 is clamped onto i]
+__global__ __launch_bounds__(256) void upsample2x_fwd_b16x8_kernel(
+    const __bf16* __restrict__ x, __bf16* __restrict__ y, int h, int w, int C, long long total8,
+    const float* __restrict__ alpha, const float* __restrict__ beta, float slope) {
+  const int lpp = C >> 3;
+  const int W2 = 2 * w;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total8; t += stride) {
+    const long long pix = t / lpp;
+    const int c = (int)(t - pix * lpp) * 8;
+    const int j = (int)(pix % w);
+    const long long r = pix / w;
+    const int i = (int)(r % h);
+    const long long n = r / h;
+    f32x4 al[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, be[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (alpha) {   // uniform
+      al[0] = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * C + c);
+      al[1] = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * C + c + 4);
+      be[0] = *reinterpret_cast<const f32x4*>(beta + (size_t)n * C + c);
+      be[1] = *reinterpret_cast<const f32x4*>(beta + (size_t)n * C + c + 4);
+    }
+    const __bf16* b = x + (size_t)n * h * w * C + c;
+    f32x4 v[3][3][2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      int yy = i - 1 + ky;
+      yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int xx = j - 1 + kx;
+        xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+        const bf16x8 q = *reinterpret_cast<const bf16x8*>(b + ((size_t)yy * w + xx) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[ky][kx][0][k] = (float)q[k]; v[ky][kx][1][k] = (float)q[4 + k]; }
+        if (alpha) {
+          v[ky][kx][0] = unet_conv::act4(v[ky][kx][0], al[0], be[0], slope, true);
+          v[ky][kx][1] = unet_conv::act4(v[ky][kx][1], al[1], be[1], slope, true);
+        }
+      }
+    }
+    const float wy[2][2] = {{i > 0 ? 0.25f : 0.f, i > 0 ? 0.75f : 1.f}, {0.75f, 0.25f}};
+    const float wx[2][2] = {{j > 0 ? 0.25f : 0.f, j > 0 ? 0.75f : 1.f}, {0.75f, 0.25f}};
+    __bf16* o = y + (((size_t)n * 2 * h + 2 * i) * W2 + 2 * j) * C + c;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        bf16x8 out;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 res = (v[a][bb][hf] * wx[bb][0] + v[a][bb + 1][hf] * wx[bb][1]) * wy[a][0] +
+                            (v[a + 1][bb][hf] * wx[bb][0] + v[a + 1][bb + 1][hf] * wx[bb][1]) * wy[a][1];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) out[4 * hf + k] = (__bf16)res[k];
+        }
+        *reinterpret_cast<bf16x8*>(o + ((size_t)a * W2 + bb) * C) = out;
+      }
+  }
+}
+
 // gather form of the transpose: input row i receives
 //   out[2i] * a(2i), out[2i+1] * a(2i+1), out[2i-1] * 0.25 (i>=1), out[2i+2] * 0.25 (i<=L-1)
 // where the self-weights are 0.75 except at the clamped ends (1.0).
@@ -310,16 +375,18 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 // tensor) once dy has been reduced to the nine tensors D_tap.  This kernel writes
 // D[n][i][j][tap * C + c] (9C channels per low-resolution pixel) from dy[n][2h][2w][C].
 // One thread = one low-resolution pixel x 4 channels: 6 x 6 dy pixels in, 9 x 4 sums out.
-template <typename TS>
+// V = float4 groups per thread: 1 (4 channels) or, for bf16 tensors, 2 (8 channels = 16-byte
+// loads and stores: half the memory instructions of this load-issue-bound kernel).
+template <typename TS, int V = 1>
 __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const TS* __restrict__ dy,
                                                                   TS* __restrict__ D, int h,
                                                                   int w, int C, long long total4) {
-  const int lpp = C >> 2;
+  const int lpp = C / (4 * V);
   const int H2 = 2 * h, W2 = 2 * w;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += stride) {
     const long long pix = i4 / lpp;
-    const int c = (int)(i4 - pix * lpp) * 4;
+    const int c = (int)(i4 - pix * lpp) * 4 * V;
     const int j = (int)(pix % w);
     const long long r = pix / w;
     const int i = (int)(r % h);
@@ -336,36 +403,48 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const TS* __re
     wx[2] = j == w - 1 ? 1.0f : 0.75f;
     wx[3] = j < w - 1 ? 0.25f : 0.f;
     const TS* b = dy + (size_t)n * H2 * W2 * C + c;
-    f32x4 acc[3][3];
+    f32x4 acc[3][3][V];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) acc[ky][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[ky][kx][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     // dy row R' = R - (ky - 1) for up row R = 2i - 1 + a: rows 2i-2 .. 2i+3, same for columns
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
       const int Ry = 2 * i - 2 + rr;
       if ((unsigned)Ry >= (unsigned)H2) continue;
-      f32x4 v[6];
+      f32x4 v[6][V];
 #pragma unroll
       for (int cc = 0; cc < 6; ++cc) {
         const int Rx = 2 * j - 2 + cc;
-        v[cc] = (unsigned)Rx < (unsigned)W2 ? ld4(b + ((size_t)Ry * W2 + Rx) * C)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool in = (unsigned)Rx < (unsigned)W2;
+        if constexpr (V == 2) {     // (bf16 only) one 16-byte load
+          bf16x8 q8 = {};
+          if (in) q8 = *reinterpret_cast<const bf16x8*>(b + ((size_t)Ry * W2 + Rx) * C);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[cc][0][k] = (float)q8[k]; v[cc][1][k] = (float)q8[4 + k]; }
+        } else {
+          v[cc][0] = in ? ld4(b + ((size_t)Ry * W2 + Rx) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
       // column stencil: for tap kx, up column S = 2j-1+bb reads dy column S-(kx-1) = index
       // cc = bb + 2 - kx of v
-      f32x4 colsum[3];
+      f32x4 colsum[3][V];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int S = 2 * j - 1 + bb;           // up column (must exist)
-          const float wgt = (unsigned)S < (unsigned)W2 ? wx[bb] : 0.f;
-          t += v[bb + 2 - kx] * wgt;
+        for (int q = 0; q < V; ++q) {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const int S = 2 * j - 1 + bb;           // up column (must exist)
+            const float wgt = (unsigned)S < (unsigned)W2 ? wx[bb] : 0.f;
+            t += v[bb + 2 - kx][q] * wgt;
+          }
+          colsum[kx][q] = t;
         }
-        colsum[kx] = t;
       }
       // row stencil: dy row Ry serves tap ky for up row R = Ry + ky - 1 = 2i-1+a, a = rr+ky-2
 #pragma unroll
@@ -375,14 +454,28 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_taps_kernel(const TS* __re
         const int R = 2 * i - 1 + a;
         const float wgt = (unsigned)R < (unsigned)H2 ? wy[a] : 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky][kx] += colsum[kx] * wgt;
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int q = 0; q < V; ++q) acc[ky][kx][q] += colsum[kx][q] * wgt;
       }
     }
     TS* o = D + (size_t)pix * 9 * C + c;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) st4(o + (size_t)(ky * 3 + kx) * C, acc[ky][kx]);
+      for (int kx = 0; kx < 3; ++kx) {
+        if constexpr (V == 2) {
+          bf16x8 out;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            out[k] = (__bf16)acc[ky][kx][0][k];
+            out[4 + k] = (__bf16)acc[ky][kx][1][k];
+          }
+          *reinterpret_cast<bf16x8*>(o + (size_t)(ky * 3 + kx) * C) = out;
+        } else {
+          st4(o + (size_t)(ky * 3 + kx) * C, acc[ky][kx][0]);
+        }
+      }
   }
 }
 
@@ -601,6 +694,14 @@ extern "C" int unet_upsample2x_in_fwd_b16(const unet_act_src* x, float slope, ui
   UNET_REQUIRE(x && x->x && up && N > 0 && h > 0 && w > 0 && x->C > 0 && x->C % 4 == 0 &&
                    (!x->alpha || x->beta),
                "upsample2x_in_fwd_b16: bad argument");
+  if (x->C % 8 == 0) {   // one thread per low-resolution pixel x 8 channels
+    const long long total8 = (long long)N * h * w * (x->C / 8);
+    hipLaunchKernelGGL(upsample2x_fwd_b16x8_kernel, dim3(stream_grid(total8)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const __bf16*>(x->x),
+                       reinterpret_cast<__bf16*>(up), h, w, x->C, total8, x->alpha, x->beta, slope);
+    UNET_CHECK_LAUNCH("upsample2x_fwd(b16 x8)");
+    return UNET_OK;
+  }
   const long long total4 = (long long)N * 4 * h * w * (x->C / 4);
   hipLaunchKernelGGL(upsample2x_fwd_kernel<__bf16>, dim3(stream_grid(total4)), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const __bf16*>(x->x),
@@ -635,6 +736,14 @@ extern "C" int unet_upsample2x_bwd_taps_b16(const uint16_t* dy, uint16_t* D, int
                                             int C, unet_stream_t stream) {
   UNET_REQUIRE(dy && D && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
                "upsample2x_bwd_taps_b16: bad argument");
+  if (C % 8 == 0) {   // 8 channels per thread: 16-byte loads and stores
+    const long long total8 = (long long)N * h * w * (C / 8);
+    hipLaunchKernelGGL((upsample2x_bwd_taps_kernel<__bf16, 2>), dim3(stream_grid(total8)), dim3(256),
+                       0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(dy),
+                       reinterpret_cast<__bf16*>(D), h, w, C, total8);
+    UNET_CHECK_LAUNCH("upsample2x_bwd_taps(b16 x8)");
+    return UNET_OK;
+  }
   const long long total4 = (long long)N * h * w * (C / 4);
   hipLaunchKernelGGL(upsample2x_bwd_taps_kernel<__bf16>, dim3(stream_grid(total4)), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const __bf16*>(dy),
