@@ -1016,3 +1016,53 @@ def test_clip_features_of_another_size_are_resized_to_the_bottleneck_grid(ua, go
         a = model(img.to(DEV), big.to(DEV))
         b = model(img.to(DEV), small.to(DEV))
     assert relerr(a, b) <= 1e-5
+
+
+def test_grad_cam_style_hooks_on_stage_modules(ua):
+    """The reference's Grad-CAM helper (Our_UNet/utils/visualize.py:392-412) registers a forward
+    hook and a (legacy) backward hook on a target layer.  The fused walk never calls sub-modules,
+    so stage-level modules get their hooks fired by the walk itself, with a materialised NCHW
+    output / grad_output.  Checked on the last decoder stage - the head is linear in it, so
+    logits = conv1x1(fmap) and d(logit[0, c].mean()) / d fmap = w_head[c] / (H W) for image 0 -
+    and on the first encoder stage against the oracle's two units."""
+    import torch.nn.functional as F
+    sd0 = O.fill_state_dict(31)
+    model = ua.UNet()
+    model.load_state_dict(sd0)
+    model = model.to(DEV).eval()
+    img, _ = O.synthetic_batch(2, 2, 64, 64)
+    got = {}
+    target = model.decoder_stages[-1]
+    h1 = target.register_forward_hook(lambda m, i, o: got.__setitem__("fmap", o.detach()))
+    h2 = target.register_backward_hook(lambda m, gi, go: got.__setitem__("grad", go[0].detach()))
+    h3 = model.encoder_stages[0].register_forward_hook(
+        lambda m, i, o: got.__setitem__("enc0", o.detach()))
+    h4 = model.encoder_stages[0].register_full_backward_hook(
+        lambda m, gi, go: got.__setitem__("genc0", go[0].detach()))
+    out = model(img.to(DEV))
+    cls = 1
+    model.zero_grad()
+    out[0, cls].mean().backward(retain_graph=True)
+    for h in (h1, h2, h3, h4):
+        h.remove()
+    fmap, grad = got["fmap"], got["grad"]
+    assert fmap.shape == (2, 32, 64, 64) and grad.shape == fmap.shape
+    head = model.segmentation_output
+    logits2 = F.conv2d(fmap, head.weight.detach(), head.bias.detach())
+    assert relerr(logits2, out.detach()) <= 1e-5
+    want = torch.zeros_like(grad)
+    want[0] = (head.weight.detach()[cls, :, 0, 0] / (64 * 64))[:, None, None]
+    assert (grad - want).abs().max() <= 1e-6 * want.abs().max()
+    # first encoder stage vs the oracle's two conv -> norm -> lrelu units (eval: no dropout)
+    osd = O.leaf_state_dict(sd0)
+    rows = O.layer_table()[:2]
+    cur = img
+    for prefix, ci, ni, _, _, stride, _, _ in rows:
+        cur = O.conv_in_lrelu_drop(cur, osd[f"{prefix}.{ci}.weight"].detach(),
+                                   osd[f"{prefix}.{ci}.bias"].detach(),
+                                   osd[f"{prefix}.{ni}.weight"].detach(),
+                                   osd[f"{prefix}.{ni}.bias"].detach(), stride)
+    assert relerr(got["enc0"], cur) <= 1e-4
+    assert got["genc0"].shape == got["enc0"].shape and torch.isfinite(got["genc0"]).all()
+    # without hooks nothing is materialised and the output is unchanged
+    assert torch.equal(model(img.to(DEV)).detach(), out.detach())

@@ -437,6 +437,40 @@ def _draw_masks(model, layers, n, device):
     return out
 
 
+def _hooked(mods, attr):
+    return [m for m in mods if getattr(m, attr, None)]
+
+
+def _fire_forward_hooks(mods, make_output):
+    """nn.Module forward hooks of stage-level sub-modules (encoder_stages[i], decoder_stages[i],
+    its conv_block, segmentation_output), which the fused walk never calls: the stage output is
+    materialised (NCHW fp32) only when such a hook exists and handed to it as `output` (the
+    reference's Grad-CAM helper, Our_UNet/utils/visualize.py:392-402).  Hooks observe: a hook
+    that returns a replacement output is not supported on this path."""
+    mods = _hooked(mods, "_forward_hooks")
+    if not mods:
+        return
+    out = make_output()
+    for m in mods:
+        for hook in list(m._forward_hooks.values()):
+            if hook(m, (None,), out) is not None:
+                raise NotImplementedError("forward hooks that replace the output of a sub-module "
+                                          "are not supported on the HIP path")
+
+
+def _fire_backward_hooks(mods, make_grad):
+    """register_backward_hook / register_full_backward_hook of the same sub-modules: called with
+    grad_output = (dL/d output,) when the backward walk reaches the stage (grad_input is not
+    materialised: (None,))."""
+    mods = _hooked(mods, "_backward_hooks")
+    if not mods:
+        return
+    g = make_grad()
+    for m in mods:
+        for hook in list(m._backward_hooks.values()):
+            hook(m, (None,), (g,))
+
+
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, extra, *params):
@@ -587,12 +621,23 @@ class _UNetFunction(torch.autograd.Function):
             cur = x if isinstance(x, ops.U8Image) else ops.Act(x)   # the image: a plain operand
         else:
             cur = x          # NHWC image
+        def stage_output(v):
+            """activated stage output as an NCHW fp32 tensor (only materialised for hooks)"""
+            if isinstance(v, ops.Act):
+                if v.x.dtype != torch.float32:
+                    raise NotImplementedError("sub-module hooks on the bf16 pipeline")
+                a = v.x if v.alpha is None else ops.instnorm_lrelu_drop_fwd(v.x, v.alpha, v.beta,
+                                                                            None, slope)
+                return ops.nhwc_to_nchw(a)
+            return ops.nhwc_to_nchw(v)
+
         skips = []
         for bi, blk in enumerate(enc):
             for l in blk:
                 cur = run_layer(l, cur, None)
             if bi < len(enc) - 1:
                 skips.append(cur)
+            _fire_forward_hooks([model.encoder_stages[bi]], lambda: stage_output(cur))
         if fusion is not None:
             if extra.shape[:3] != cur.shape[:3]:
                 raise NotImplementedError("bottleneck features must match the 1/32-resolution "
@@ -605,16 +650,19 @@ class _UNetFunction(torch.autograd.Function):
             if fused:
                 for li, l in enumerate(blk):
                     cur = run_up_layer_fused(l, cur, skip) if li == 0 else run_layer(l, cur, None)
-                continue
-            up = ops.upsample2x_fwd(cur)
-            for li, l in enumerate(blk):
-                cur = run_layer(l, up, skip) if li == 0 else run_layer(l, cur, None)
+            else:
+                up = ops.upsample2x_fwd(cur)
+                for li, l in enumerate(blk):
+                    cur = run_layer(l, up, skip) if li == 0 else run_layer(l, cur, None)
+            _fire_forward_hooks([model.decoder_stages[di], model.decoder_stages[di].conv_block],
+                                lambda: stage_output(cur))
         head = model.segmentation_output
         hw = head.weight.detach().view(head.out_channels, -1)
         if fused:
             logits = ops.head1x1_in_fwd(cur, slope, hw, head.bias.detach())
         else:
             logits = ops.head1x1_fwd(cur, hw, head.bias.detach())
+        _fire_forward_hooks([head], lambda: logits)
         if need_grad:
             ctx.model = model
             ctx.saved = saved
@@ -674,6 +722,12 @@ class _UNetFunction(torch.autograd.Function):
                 hook(model._offsets[model._param_index[id(first)]])
 
         ready(head)
+        _fire_backward_hooks([head], lambda: dlogits)
+
+        def grad_nchw(t):
+            if t.dtype != torch.float32:
+                raise NotImplementedError("sub-module hooks on the bf16 pipeline")
+            return ops.nhwc_to_nchw(t)
 
         def trainable(l):
             return any(q.requires_grad for q in (l.conv.weight, l.conv.bias, l.norm.weight,
@@ -799,6 +853,8 @@ class _UNetFunction(torch.autograd.Function):
             if done or idx < stop:
                 done = True
                 break
+            _fire_backward_hooks([model.decoder_stages[di], model.decoder_stages[di].conv_block],
+                                 lambda: grad_nchw(g))
             for li in range(len(blk) - 1, 0, -1):
                 if idx < stop:
                     done = True
@@ -825,6 +881,7 @@ class _UNetFunction(torch.autograd.Function):
             blk = enc[bi]
             if done or idx < stop:
                 break
+            _fire_backward_hooks([model.encoder_stages[bi]], lambda: grad_nchw(g))
             for li in range(len(blk) - 1, -1, -1):
                 if idx < stop:
                     done = True
