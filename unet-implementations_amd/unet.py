@@ -317,8 +317,11 @@ class UNet(nn.Module):
         return True
 
     # -- flat parameter / gradient arenas -------------------------------------------------------
-    def _ensure_arena(self):
-        params = list(self.parameters())
+    def _ensure_arena(self, params=None):
+        # (a walk of the module tree - 182 modules - costs ~70 us of host time: callers that
+        # already hold the parameter list pass it in)
+        if params is None:
+            params = list(self.parameters())
         dev = params[0].device
         ok = self._arena is not None and self._arena.device == dev
         if ok:
@@ -387,8 +390,8 @@ class UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of {1 << n_down} and >= {2 << n_down}")
         if self._plan is None:
             self._build_plan()
-        self._ensure_arena()
         params = list(self.parameters())
+        self._ensure_arena(params)
         self._param_index = {id(p): i for i, p in enumerate(params)}
         if u8 is not None:
             x_nhwc = u8
@@ -710,7 +713,7 @@ class _UNetFunction(torch.autograd.Function):
             g = ops.head1x1_bwd(saved[-1]["a"], dlogits, hw,
                                 gv(head.weight).view(head.out_channels, -1), gv(head.bias))
         ctx.last = None
-        touched.update(id(q) for q in head.parameters())
+        touched.update(id(q) for q in (head.weight, head.bias))
 
         idx = len(saved) - 1
         skip_grads = {}
@@ -718,7 +721,7 @@ class _UNetFunction(torch.autograd.Function):
 
         def ready(module):
             if hook is not None:
-                first = next(module.parameters())
+                first = next(module.parameters())     # (only with a data-parallel hook installed)
                 hook(model._offsets[model._param_index[id(first)]])
 
         ready(head)
