@@ -11,7 +11,16 @@ import ctypes
 from ._lib import ActSrc, BwdStats, check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  Every entry-point call needs
+    it (~330 per train step): the raw accessors cost ~0.3 us, `torch.cuda.current_stream()`
+    builds a Stream object for ~10 us (3 ms of host time per step)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
