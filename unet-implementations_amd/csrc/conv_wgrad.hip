@@ -1334,8 +1334,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
                                                                           pixbase * p.Cout * 4, 0));
     if (ACT) {   // the loaded coefficients are only looked at when the patch is stored
       const size_t o = (size_t)l_n * p.Cx + ci0;
-      gld4_sbase(ca, (unsigned)grp4 * 4u, p.alpha + o);
-      gld4_sbase(cb, (unsigned)grp4 * 4u, p.beta + o);
+      // (compiler-tracked loads on purpose: the values live across the loop's back edge, where
+      // the register allocator copies them between the chunk bodies - an untracked asm load
+      // still in flight at such a copy is copied stale and lands in a register that has been
+      // given to something else.  Seen as memory faults when two processes shared the GPU.)
+      ca = *reinterpret_cast<const f32x4*>(p.alpha + o + grp4);
+      cb = *reinterpret_cast<const f32x4*>(p.beta + o + grp4);
     }
     if (l_g + 1 < g_end) {     // uniform
       ++l_g;
@@ -1465,9 +1469,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
   auto chunk_body = [&](auto bc, auto hc) {
     constexpr int B = decltype(bc)::value, HF = decltype(hc)::value;
     using NB = template_ic<B ^ 1>;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    reg_anchor(ca, cb);
+    asm volatile("" ::: "memory");
     frag(bc, template_ic<0>{});
     for_range<0, 16>([&](auto xc) {
       constexpr int x = decltype(xc)::value;
@@ -1496,8 +1500,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
   auto k_loop = [&](auto hc) {
     // prologue: chunk 0 transformed into stage 0, chunk 1 in the registers
     load_raw();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    reg_anchor(ca, cb);
     for_range<0, 3>(store_x);
     store_d();
     load_raw();

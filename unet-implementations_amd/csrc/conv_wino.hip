@@ -235,21 +235,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams wp) 
       if (i == 1) {   // the chunk's coefficient planes (looked at when the patch is stored)
         const float* cf = wp.dz_coef + ((size_t)n * p.C0 + cc);
         const size_t plane = (size_t)p.N * p.C0;
-        gld4_sbase(cz[0], hoff, cf);
-        gld4_sbase(cz[1], hoff, cf + plane);
-        gld4_sbase(cz[2], hoff, cf + 2 * plane);
-        gld4_sbase(cz[3], hoff, cf + 3 * plane);
-        gld4_sbase(cz[4], hoff, cf + 4 * plane);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          cz[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(cf + k * plane) + hoff);
       }
     }
     if (ACT && i == 1) {   // (ACT: every source is an activated tensor - the entry points check)
       const float* al = (first ? p.act0_alpha : p.act1_alpha) + ((size_t)n * Cs + cc);
       const float* be = (first ? p.act0_beta : p.act1_beta) + ((size_t)n * Cs + cc);
       // the loaded coefficients are only looked at when the patch is stored, an iteration later
-      // (scalar base + 32-bit lane offset by hand: hipcc builds a 64-bit VALU address; the
-      // chunk_body's s_waitcnt vmcnt(0) + anchor stand in for the compiler's tracking)
-      gld4_sbase(ca[Q], hoff, al);
-      gld4_sbase(cb[Q], hoff, be);
+      // (compiler-tracked loads on purpose, although hipcc builds a 64-bit VALU address for
+      // them: the values live across the loop's back edge, where the register allocator copies
+      // them between the chunk bodies - an untracked asm load still in flight at such a copy
+      // is copied stale and lands in a register that has been given to something else)
+      ca[Q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(al) + hoff);
+      cb[Q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(be) + hoff);
     }
   };
   // raw patch position of slot i (slots past the patch: never stored)

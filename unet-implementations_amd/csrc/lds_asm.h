@@ -33,16 +33,22 @@ __device__ __forceinline__ void lds_wait(f32x2v& a, f32x2v& b, f32x2v& c, f32x2v
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
-// 16 bytes from (scalar base + 32-bit lane offset), untracked like the LDS reads above (hipcc
-// builds a 64-bit VALU address per load instead); the consumer sits behind an s_waitcnt vmcnt(0)
-__device__ __forceinline__ void gld4_sbase(f32x4& v, unsigned lane_off, const float* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(lane_off), "s"(sbase) : "memory");
-}
+// NOTHING whose value outlives the straight-line code between the asm and its wait may be loaded
+// this way.  An earlier version loaded the activation coefficients with an asm
+// `global_load_dwordx4 v, v_off, s[base]` (to save the 64-bit VALU address hipcc builds) a loop
+// iteration ahead of their use: the register allocator, which takes an asm's output for valid on
+// the spot, gave those registers to address arithmetic while the load was in flight, and with two
+// processes sharing the GPU (loads slower than the rest of the iteration) the late data landed in
+// an address - "Memory access fault by GPU".  tools/asm_hazard_check.py walks the disassembly for
+// exactly this (a register touched while a load into it is queued) and tests/test_build_cpu.py
+// runs it on every build.
 // global -> LDS DMA of 16 bytes per lane: LDS base of the piece in M0, scalar base + lane offset
-// (M0 has no other user in these kernels: gfx9 LDS instructions do not read it)
+// (M0 has no other user in these kernels: gfx9 LDS instructions do not read it; the s_nop is the
+// wait state between an SALU write of M0 and an LDS-DMA instruction, which nothing inserts inside
+// an asm block.  No register output: the DMA is behind the s_waitcnt vmcnt at the chunk barrier.)
 template <int OFF>
 __device__ __forceinline__ void dma16_sbase(unsigned m0v, unsigned lane_off, const float* sbase) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
                :: "s"(m0v), "v"(lane_off), "s"(sbase), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void reg_anchor(f32x4& a, f32x4& b) {
