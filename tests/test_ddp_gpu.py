@@ -194,6 +194,18 @@ def test_bench_gpus_2_without_a_launcher():
     assert r["config"]["global_batch"] == 4 and r["value"] > 0
 
 
+def test_two_ranks_at_full_size_share_one_gpu():
+    """The benchmark configuration itself (bs 8, 512 x 512: the Winograd kernels and every
+    hand-scheduled loop run) on two ranks time-slicing cuda:0.  Memory latencies under sharing are
+    several times the exclusive ones, which is what it takes to expose a register read or reused
+    before a hand-waited load has landed (one did: "Memory access fault by GPU", found by exactly
+    this rehearsal; tools/asm_hazard_check.py is the static side of the same check)."""
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-alt", "--no-cpu-baseline",
+                    "--no-graph"], dict(UNET_SHARE_GPU="1", UNET_DIST_BACKEND="gloo"))
+    assert r["n_gpus"] == 2 and r["config"]["world"] == 2 and r["config"]["global_batch"] == 16
+    assert r["value"] > 0
+
+
 def test_bench_single_gpu_through_a_one_rank_rccl_group():
     """UNET_BENCH_RCCL=1: the N=1 bench runs its fence barrier, the MAX all-reduce of the step
     time and the bucketed gradient all-reduces through RCCL (backend nccl, one rank)."""
