@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 4
+#define UNET_ABI_VERSION 5
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -479,6 +479,12 @@ int unet_conv3x3_up_bwd_data_bs(const float* D, const float* wd, int Cin_total, 
  * Same arithmetic as nn.Conv2d / its data gradient (Our_UNet/models/unet.py:106-115) up to
  * fp32 rounding of the transforms (<= 3e-6 of max |y| measured). */
 int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
+/* The 32 -> 32 channel stride-1 layers (enc0 / dec4 at full resolution) have a Winograd form of
+ * their own inside unet_conv_in_fwd / unet_conv3x3_bwd_data(_bs): it needs no extra weight form
+ * (U = G g G^T is built in the kernel's prologue from the packed weights), so it is a process-wide
+ * switch rather than an entry point: 1 (default) = Winograd, 0 = the direct kernel.  Returns the
+ * previous setting.  (csrc/conv_c32.hip) */
+int unet_set_c32_winograd(int on);
 size_t unet_wino_weight_floats(int Cout, int Cin);
 int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin,
                            unet_stream_t stream);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
     "unet_conv3x3_bwd_data_bs": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_conv_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_set_c32_winograd": (_i, [_i]),
     "unet_wino_weight_floats": (_sz, [_i, _i]),
     "unet_pack_wino_weights": (_i, [_p, _p, _p, _i, _i, _p]),
     "unet_pack_wino_weights_batched": (_i, [_p, _i, _i, _p]),
@@ -193,7 +194,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.unet_abi_version() != 4:
+    if handle.unet_abi_version() != 5:
         raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

@@ -267,7 +267,314 @@ __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, i
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// The same layers in the Winograd F(2x2, 3x3) form: 16 element-wise 32 x 32 products per
+// 2 x 2 output tile instead of 36 multiply-adds per output - 4/9 of the matrix-core work.
+//
+// K = 32 is ONE Winograd "chunk", so there is no K loop to pipeline: the kernel is a sequence
+// of phases per 8 x 32-pixel tile, separated by barriers, and loses nothing by it - on gfx950
+// VALU / LDS instructions do not overlap with fp32 MFMAs anyway.
+//   * persistent workgroup of eight waves and the activated (8+2) x 34 x 32 patch in LDS exactly
+//     as above (one buffer: the next tile's patch rides in registers through the whole tile);
+//   * the transformed weights U = G g G^T live in REGISTERS and are built in the prologue from
+//     the packed 3x3 weights the direct kernel reads (no extra weight form, no packing launch):
+//     wave (i, h) keeps row i of the 4 x 4 xi grid for output columns 16 h .. +15: 32 VGPRs;
+//   * per half tile (2 x 16 Winograd tiles): every thread transforms one (tile, channel pair)
+//     V = B^T d B from the patch into LDS; 64 MFMAs (16x16x4) per wave: M[xi] = V[xi] U[xi] for
+//     the wave's four xi; the column pass of A^T M A in registers (the wave holds a whole row of
+//     xi); the row pass across the four waves through a 32 KB LDS exchange, after which lane
+//     (column, half) owns 8 output pixels of one column - the epilogue layout of the direct
+//     kernel: bias, statistics / BSTATS, 128-byte store segments.
+// ---------------------------------------------------------------------------
+constexpr int W32_VP = 36;                         // V row pitch in floats (conflict-free b64 fragment reads)
+constexpr int W32_V = 16 * 32 * W32_VP;            // [xi][tile slot 32][channel 32 (+4)]
+constexpr int W32_Z = 4 * 2 * 2 * 4 * 2 * 64;      // [xi row][b][m block][r][column half][lane]
+constexpr size_t W32_LDS = ((size_t)C32_PPIX * C32_LDA + W32_V + W32_Z) * sizeof(float) +
+                           8 * 32 * sizeof(float2);
+
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+__device__ __forceinline__ float wino_g(int i, int u) {
+  if (i == 0) return u == 0 ? 1.f : 0.f;
+  if (i == 3) return u == 2 ? 1.f : 0.f;
+  if (i == 1) return 0.5f;
+  return u == 1 ? -0.5f : 0.5f;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p, int ntiles) {
+  constexpr int LDA = C32_LDA, PW = C32_PW, P_PASSES = C32_PASSES;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Pb = smem;
+  float* const Vs = smem + C32_PPIX * LDA;
+  float* const Zs = Vs + W32_V;
+  float2* const red = reinterpret_cast<float2*>(Zs + W32_Z);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = p.Hin, W = p.Win;
+  const int tiles_x = W / C32_TW, tiles_y = H / C32_TH;
+
+  const int G = gridDim.x;
+  int t_first, t_stride, t_end;
+  if ((ntiles & 7) == 0 && (G & 7) == 0) {
+    const int per = ntiles >> 3, xcd = blockIdx.x & 7;
+    t_first = xcd * per + (blockIdx.x >> 3);
+    t_stride = G >> 3;
+    t_end = (xcd + 1) * per;
+  } else {
+    t_first = blockIdx.x; t_stride = G; t_end = ntiles;
+  }
+  if (t_first >= t_end) return;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+
+  // ---- U = G g G^T, row wi of the xi grid, for this lane's B-fragment positions ----
+  // MFMA ks = 2 q + e of a xi multiplies input channel 8 q + 2 fk + e into output column
+  // 16 wh + fn (the A fragments below read channel PAIRS: 8 bytes per lane).
+  const int wi = wave & 3, wh = wave >> 2;
+  const int fn = lane & 15, fk = lane >> 4;
+  float ub[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ub[j][k] = 0.f;
+  for_range_c<0, 9>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int u = (int)(e & 3u), v = (int)((e >> 2) & 3u);   // = offset + 1: g[u][v]
+    const int wt = (int)(e >> 4);
+    const float gu = wino_g(wi, u);
+    const float* wp = p.w + (size_t)wt * p.tap_stride + (size_t)(p.n_off + 16 * wh + fn) * 32 + 2 * fk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2w w2 = *reinterpret_cast<const f32x2w*>(wp + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float c = gu * wino_g(j, v);
+        ub[j][2 * q] = fmaf(c, w2[0], ub[j][2 * q]);
+        ub[j][2 * q + 1] = fmaf(c, w2[1], ub[j][2 * q + 1]);
+      }
+    }
+  });
+
+  // ---- patch slots of this thread (constant across tiles) ----
+  int pp_rel[P_PASSES], pp_lds[P_PASSES], pp_rc[P_PASSES];
+#pragma unroll
+  for (int i = 0; i < P_PASSES; ++i) {
+    const int slot = tid + 512 * i;
+    const bool valid = slot < C32_SLOTS;
+    const int pix = valid ? slot >> 3 : 0, seg = slot & 7;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    pp_rel[i] = ((prow * W + pcol) * 32 + seg * 4) * 4;
+    pp_lds[i] = pix * LDA + seg * 4;
+    pp_rc[i] = valid ? (prow | (pcol << 8)) : (1 << 20);
+  }
+  f32x4 pr[P_PASSES];
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  float cs = 1.f;
+  unsigned okm = 0;
+  auto tile_pos = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % tiles_x;
+    const int r = tile / tiles_x;
+    const int ty = r % tiles_y;
+    n = r / tiles_y; y0 = ty * C32_TH; x0 = tx * C32_TW;
+  };
+  auto load_patch = [&](int tile) {
+    int n, y0, x0;
+    tile_pos(tile, n, y0, x0);
+    const int base = ((n * H + y0 - 1) * W + x0 - 1) * 128;
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const int prow = pp_rc[i] & 0xff, pcol = pp_rc[i] >> 8;
+      const bool ok = (unsigned)(y0 - 1 + prow) < (unsigned)H && (unsigned)(x0 - 1 + pcol) < (unsigned)W;
+      okm |= (ok ? 1u : 0u) << i;
+      const unsigned off = ok ? (unsigned)(base + pp_rel[i]) : 0x80000000u;
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+    }
+    if (FUSED) {
+      if (p.act0_alpha) {   // uniform
+        const size_t o = (size_t)n * 32 + (tid & 7) * 4;
+        ca = *reinterpret_cast<const f32x4*>(p.act0_alpha + o);
+        cb = *reinterpret_cast<const f32x4*>(p.act0_beta + o);
+        cs = p.slope;
+      }
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      if (FUSED) pr[i] = act4(pr[i], ca, cb, cs, (okm >> i) & 1u);
+      if (512 * (i + 1) <= C32_SLOTS || tid + 512 * i < C32_SLOTS)
+        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = pr[i];
+    }
+  };
+
+  // ---- input transform: thread -> (channel pair cp, tile slot tt of the half tile) ----
+  // slot tt = 4 wave + (lane >> 4) sits at tile row tt >> 4, tile column 4 (tt & 3) + ((tt >> 2) & 3):
+  // the four 16-lane groups of a wave read pixels 8 apart (conflict-free 8-byte reads)
+  const int cp = tid & 15, tt = tid >> 4;
+  const int t_ty = tt >> 4, t_tx = 4 * (tt & 3) + ((tt >> 2) & 3);
+  const float* const t_src = Pb + ((2 * t_ty) * PW + 2 * t_tx) * LDA + 2 * cp;
+  float* const t_dst = Vs + tt * W32_VP + 2 * cp;
+  auto transform = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    const float* src = t_src + s * (4 * PW * LDA);
+    f32x2w d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const f32x2w*>(src + (r * PW + c) * LDA);
+    // B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    f32x2w t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t[0][c] = d[0][c] - d[2][c];
+      t[1][c] = d[1][c] + d[2][c];
+      t[2][c] = d[2][c] - d[1][c];
+      t[3][c] = d[1][c] - d[3][c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float* dst = t_dst + (4 * a) * (32 * W32_VP);
+      *reinterpret_cast<f32x2w*>(dst) = t[a][0] - t[a][2];
+      *reinterpret_cast<f32x2w*>(dst + 32 * W32_VP) = t[a][1] + t[a][2];
+      *reinterpret_cast<f32x2w*>(dst + 2 * 32 * W32_VP) = t[a][2] - t[a][1];
+      *reinterpret_cast<f32x2w*>(dst + 3 * 32 * W32_VP) = t[a][1] - t[a][3];
+    }
+  };
+
+  // ---- products: wave (wi, wh): xi = 4 wi + j, tile slots 16 mb + fn, columns 16 wh + .. ----
+  const float* const a_src = Vs + (4 * wi * 32 + fn) * W32_VP + 2 * fk;
+  float* const z_dst = Zs + (wi * 2) * 1024 + wh * 64 + lane;     // + b * 1024 + (mb * 4 + r) * 128
+  // ---- row pass + epilogue: wave -> tile row (wave >> 2), tile columns 4 (wave & 3) .. +3 of the
+  //      half tile; lane (li, lh) -> column li, tile columns 4 (wave & 3) + 2 lh + e ----
+  const int o_mb = wave >> 2, o_r = wave & 3;
+  const float* const z_src = Zs + (o_mb * 4 + o_r) * 128 + (li >> 4) * 64 + 32 * lh + (li & 15);   // + e * 16 + (i * 2 + b) * 1024
+  const bool summaries = FUSED ? p.stats != nullptr : p.bs_partial != nullptr;   // uniform
+  const float bv = (FUSED && p.bias) ? p.bias[li] : 0.f;
+
+  load_patch(t_first);
+  store_patch();
+  __syncthreads();
+
+  for (int tile = t_first; tile < t_end; tile += t_stride) {
+    const int nxt = tile + t_stride;
+    const bool more = nxt < t_end;
+    if (more) load_patch(nxt);   // uniform
+    int n, y0, x0;
+    tile_pos(tile, n, y0, x0);
+    float outv[16], yv[16];
+    for_range_c<0, 2>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      transform(sc);
+      __syncthreads();
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          acc[j][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* ap = a_src + (j * 32 + 16 * mb) * W32_VP;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x2w a2 = *reinterpret_cast<const f32x2w*>(ap + 8 * q);
+            acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0], ub[j][2 * q], acc[j][mb], 0, 0, 0);
+            acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[1], ub[j][2 * q + 1], acc[j][mb], 0, 0, 0);
+          }
+        }
+      // column pass of A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]) over this wave's row of xi
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float m0 = acc[0][mb][r], m1 = acc[1][mb][r], m2 = acc[2][mb][r], m3 = acc[3][mb][r];
+          z_dst[(mb * 4 + r) * 128] = m0 + (m1 + m2);
+          z_dst[1024 + (mb * 4 + r) * 128] = (m1 - m2) - m3;
+        }
+      __syncthreads();
+      // row pass: Y[a][b] = sum_i A^T[a][i] Z[i][b]
+      const int yrow = y0 + 4 * s + 2 * o_mb;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int xcol = x0 + 2 * (4 * o_r + 2 * lh + e);
+        float z[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) z[i][b] = z_src[e * 16 + (i * 2 + b) * 1024];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          outv[8 * s + 4 * e + b] = z[0][b] + (z[1][b] + z[2][b]);
+          outv[8 * s + 4 * e + 2 + b] = (z[1][b] - z[2][b]) - z[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int k = 8 * s + 4 * e + 2 * a + b;
+            const size_t pix = ((size_t)n * H + yrow + a) * W + xcol + b;
+            float* o = p.out + pix * p.ldo + li;
+            if (FUSED) {
+              outv[k] += bv;
+            } else {
+              if (p.accumulate) outv[k] += *o;   // uniform
+              if (p.bs_partial) yv[k] = p.bs_y[pix * p.ldo + li];   // uniform
+            }
+            *o = outv[k];
+          }
+      }
+    });
+    if (FUSED) {
+      if (p.stats) {   // uniform
+        const float2 mine = wave_col_stats<1>([&](int, int r) { return outv[r]; });
+        if (lh == 0) red[wave * 32 + li] = mine;
+      }
+    } else if (p.bs_partial) {   // uniform
+      const BwdCoef cf = bwd_coef(p, n, li);
+      const float2 mine = wave_bwd_stats<1>(
+          cf, p.slope, [&](int, int r) { return outv[r]; }, [&](int, int r) { return yv[r]; });
+      if (lh == 0) red[wave * 32 + li] = mine;
+    }
+    if (more) store_patch();   // every transform of this tile lies two barriers back
+    __syncthreads();
+    if (summaries && tid < 32) {   // red is rewritten five barriers from now
+      const float2* rr = red + tid;
+      const size_t dst = ((size_t)n * (tiles_x * tiles_y) + (y0 / C32_TH) * tiles_x + (x0 >> 5)) * 32 + tid;
+      if (FUSED) {
+        float mean[4], m2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mean[k] = rr[(2 * k) * 32].x; m2[k] = rr[(2 * k) * 32].y;
+          wf_merge_eq(mean[k], m2[k], rr[(2 * k + 1) * 32].x, rr[(2 * k + 1) * 32].y, 32.f);
+        }
+        wf_merge_eq(mean[0], m2[0], mean[1], m2[1], 64.f);
+        wf_merge_eq(mean[2], m2[2], mean[3], m2[3], 64.f);
+        wf_merge_eq(mean[0], m2[0], mean[2], m2[2], 128.f);
+        p.stats[dst] = float2{mean[0], m2[0]};
+      } else {
+        float a = rr[0].x, b = rr[0].y;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += rr[k * 32].x; b += rr[k * 32].y; }
+        p.bs_partial[dst] = float2{a, b};
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// process-wide choice between the two forms of these layers (unet_set_c32_winograd)
+int& c32_winograd_flag() {
+  static int on = 1;
+  return on;
+}
 
 // 3x3 stride-1, 32 input and 32 output channels, image tiles as 8 x 32 pixels
 bool c32_applicable(const IgemmParams& p) {
@@ -295,6 +602,19 @@ int launch_c32(const IgemmParams& p0, int fused, hipStream_t stream, int* tile_p
   }
   const int ntiles = p.N * (p.Hin / C32_TH) * (p.Win / C32_TW);
   const int grid = ntiles < 256 ? ntiles : 256;
+  if (c32_winograd_flag()) {
+    if (fused) {
+      auto kern = conv_wino32_kernel<true>;
+      UNET_SET_DYN_LDS(kern, W32_LDS);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), W32_LDS, stream, p, ntiles);
+    } else {
+      auto kern = conv_wino32_kernel<false>;
+      UNET_SET_DYN_LDS(kern, W32_LDS);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), W32_LDS, stream, p, ntiles);
+    }
+    UNET_CHECK_LAUNCH("conv_wino32");
+    return UNET_OK;
+  }
   if (fused) {
     auto kern = conv_c32_kernel<true>;
     UNET_SET_DYN_LDS(kern, C32_LDS);
@@ -309,3 +629,11 @@ int launch_c32(const IgemmParams& p0, int fused, hipStream_t stream, int* tile_p
 }
 
 }  // namespace unet_conv
+
+// 1: the 32 -> 32 channel layers run the Winograd F(2x2, 3x3) kernel (default), 0: the direct
+// kernel.  Returns the previous setting.
+extern "C" int unet_set_c32_winograd(int on) {
+  const int prev = unet_conv::c32_winograd_flag();
+  unet_conv::c32_winograd_flag() = on ? 1 : 0;
+  return prev;
+}
