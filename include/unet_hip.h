@@ -485,6 +485,9 @@ int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
  * switch rather than an entry point: 1 (default) = Winograd, 0 = the direct kernel.  Returns the
  * previous setting.  (csrc/conv_c32.hip) */
 int unet_set_c32_winograd(int on);
+/* 1 when a 3x3 fused forward / data gradient of this shape runs that Winograd form (for FLOP
+ * accounting: it issues 16/36 of the direct kernel's matrix-core FLOPs). */
+int unet_conv_c32_is_winograd(int N, int H, int W, int Cin, int Cout, int stride);
 size_t unet_wino_weight_floats(int Cout, int Cin);
 int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin,
                            unet_stream_t stream);

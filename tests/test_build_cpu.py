@@ -43,16 +43,18 @@ def test_no_register_is_touched_while_an_untracked_load_into_it_is_in_flight():
     disassembly with the vmcnt / lgkmcnt queues and reports any such touch."""
     chk = os.path.join(ROOT, "tools", "asm_hazard_check.py")
     checked = 0
-    for obj in ("conv_wino.o", "conv_wgrad.o"):
+    # (conv_c32.o: the only hand-issued loads of its Winograd kernel are LDS reads; following the
+    # compiler-tracked vmcnt queue through its uniform branches too takes minutes)
+    for obj, opts in (("conv_wino.o", []), ("conv_wgrad.o", []), ("conv_c32.o", ["--lds-only"])):
         path = os.path.join(BUILD, obj)
         if not os.path.exists(path):
             pytest.skip("no built objects (run __graft_entry__.build() first)")
-        r = subprocess.run(["python3", chk, path, "wino"], capture_output=True, text=True)
+        r = subprocess.run(["python3", chk] + opts + [path, "wino"], capture_output=True, text=True)
         m = re.search(r"(\d+) kernels checked, (\d+) hazards, (\d+) incomplete", r.stdout)
         assert m, r.stdout + r.stderr
         assert int(m.group(2)) == 0 and int(m.group(3)) == 0 and r.returncode == 0, r.stdout[-4000:]
         checked += int(m.group(1))
-    assert checked >= 8, checked
+    assert checked >= 12, checked
 
 
 def test_hazard_checker_sees_a_touched_in_flight_register():

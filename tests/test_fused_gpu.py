@@ -216,6 +216,87 @@ def test_data_gradient_winograd(ua, case):
     _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
 
 
+C32_CASES = [(2, 64, 64, True), (1, 8, 32, True), (3, 40, 96, False), (2, 128, 160, True)]
+
+
+@pytest.mark.parametrize("case", C32_CASES)
+def test_c32_winograd_forward(ua, case):
+    """The 32 -> 32 channel layers' own Winograd form (csrc/conv_c32.hip: U built in the kernel
+    from the packed weights, one K chunk, phase per half tile) against the fp64 convolution of
+    the activated source and against the direct kernel behind the same entry point - shapes with
+    one tile, odd tile counts (a partial persistent walk) and H != W."""
+    N, H, W, act = case
+    C = 32
+    x0 = rnd(N, C, H, W, seed=1)
+    c0 = coeffs(N, C, 10) if act else None
+    w = rnd(C, C, 3, 3, seed=3, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(C, seed=4, scale=0.3)
+    gamma = rnd(C, seed=5) * 0.2 + 1.0
+    beta = rnd(C, seed=6) * 0.2
+    keep = torch.rand(N, C, generator=torch.Generator().manual_seed(7)) < 0.7
+    mask = keep.float() / 0.7
+    a0 = act_ref(x0, *c0) if c0 else x0.double()
+    y_ref = F.conv2d(a0, w.double(), b.double(), padding=1)
+    mean_ref = y_ref.mean(dim=(2, 3))
+    rstd_ref = 1.0 / torch.sqrt(y_ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+    wk, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    args = (make_src(ua, x0, c0), None, SLOPE, wk, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV),
+            1e-5, mask.to(DEV))
+    assert ua.ops._c32_winograd(N, H, W, C, C, 1)
+    y, st = ua.ops.conv_in_fwd(*args)
+    check(from_nhwc(y), y_ref, 2e-5, "y (Winograd, 32 channels)")
+    assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), rstd_ref, 5e-5, "rstd (Winograd, 32 channels)")
+    prev = ua.ops.set_c32_winograd(False)
+    try:
+        assert prev and not ua.ops._c32_winograd(N, H, W, C, C, 1)
+        y32, st32 = ua.ops.conv_in_fwd(*args)
+    finally:
+        ua.ops.set_c32_winograd(True)
+    check(y, y32, 2e-5, "Winograd vs direct")
+    check(st[2], st32[2], 5e-5, "alpha: Winograd vs direct")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 0), (1, 8, 32, 0), (3, 40, 96, 0), (2, 64, 96, 64)])
+def test_c32_winograd_data_gradient(ua, case):
+    """Its data-gradient side: with the BSTATS epilogue (reductions of the next InstanceNorm
+    backward on the same y), accumulating into an existing gradient, and as the skip half of the
+    last decoder stage's first convolution (32 columns at offset 64 of a 96-channel weight)."""
+    N, H, W, ci_off = case
+    C = 32
+    cin_total = ci_off + C
+    dy = to_nhwc(rnd(N, C, H, W, seed=1))
+    w = rnd(C, cin_total, 3, 3, seed=2, scale=0.1)
+    _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
+    y, st, gamma, beta, mask = _next_norm(ua, N, C, H, W, 10)
+    base = to_nhwc(rnd(N, C, H, W, seed=5))
+
+    def run():
+        out = {}
+        out["plain"] = ua.ops.conv3x3_bwd_data(dy, wd, ci_off, C, H, W, 1)
+        out["acc"] = ua.ops.conv3x3_bwd_data(dy, wd, ci_off, C, H, W, 1, out=base.clone(),
+                                             accumulate=True)
+        if not ci_off:
+            nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+            out["bs"] = ua.ops.conv3x3_bwd_data(dy, wd, 0, C, H, W, 1, nxt=nn)
+            out["nn"] = nn
+        return out
+
+    assert ua.ops._c32_winograd(N, H, W, C, C, 1)
+    wino = run()
+    ua.ops.set_c32_winograd(False)
+    try:
+        direct = run()
+    finally:
+        ua.ops.set_c32_winograd(True)
+    check(wino["plain"], direct["plain"], 2e-5, "Winograd data gradient vs direct")
+    check(wino["acc"], direct["acc"], 2e-5, "accumulating Winograd data gradient vs direct")
+    if not ci_off:
+        check(wino["bs"], direct["bs"], 2e-5, "Winograd data gradient (+BSTATS) vs direct")
+        assert wino["nn"].tiles == direct["nn"].tiles == H * W // 256
+        _in_bwd_both_ways(ua, wino["bs"], wino["nn"], y, st, gamma, beta, mask)
+
+
 X3_FUSED_CASES = [  # shapes the split patch kernel takes in the fused pipeline
     (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # 128 columns, two sources
     (2, 256, 256, 64, 0, 64, 1, 3, True, False),     # 64 columns, 8-row tiles

@@ -14,7 +14,7 @@ once (so a loop body is seen with the state its previous iteration leaves behind
 in-order queues behind vmcnt and lgkmcnt, and reports every instruction that reads or writes a
 VGPR that a queued load has yet to deliver.
 
-usage: tools/asm_hazard_check.py <obj-or-so> [kernel-name-substring ...]
+usage: tools/asm_hazard_check.py [--max-states=N] [--lds-only] <obj-or-so> [kernel-name-substring ...]
 exit code 1 when a hazard is found.
 """
 import re
@@ -121,7 +121,7 @@ def canon(q, cap):
     return q[-cap:] if len(q) > cap else q
 
 
-def check_kernel(name, body, max_states=20000):
+def check_kernel(name, body, max_states=20000, track_vm=True):
     """Walk every path of the kernel (both sides of each conditional branch; a (branch target,
     queue state) pair is expanded once).  The queues hold, per outstanding operation, the frozen
     set of VGPRs it will write (empty for stores / DMA; None for a scalar load)."""
@@ -157,7 +157,7 @@ def check_kernel(name, body, max_states=20000):
                         hazards.setdefault(key, "%s @%x: `%s %s` touches %s while a %s load into it is in flight (%d younger)"
                                            % (name, addr, mn, ops.strip(), ["%s%d" % r for r in sorted(t & d)[:4]],
                                               what, len(q) - 1 - age))
-            if vm:
+            if vm and track_vm:
                 dst = frozenset(first) if vm_load or ("atomic" in mn and re.search(r"\b(glc|sc0)\b", ops)) else frozenset()
                 vmq = vmq + (dst,)
             elif lds:
@@ -186,7 +186,17 @@ def check_kernel(name, body, max_states=20000):
 
 
 def main():
-    path, pats = sys.argv[1], sys.argv[2:]
+    args = sys.argv[1:]
+    limit, track_vm = 20000, True
+    while args and args[0].startswith("--"):
+        a = args.pop(0)
+        if a.startswith("--max-states="):
+            limit = int(a.split("=")[1])
+        elif a == "--lds-only":     # kernels whose only hand-issued loads are LDS reads: the
+            track_vm = False        # vmcnt queue (all compiler-tracked) multiplies the states
+        else:
+            raise SystemExit("unknown option " + a)
+    path, pats = args[0], args[1:]
     kernels = split_kernels(disassemble(path))
     bad = []
     n = 0
@@ -194,7 +204,7 @@ def main():
         if pats and not any(p in name for p in pats):
             continue
         n += 1
-        bad += check_kernel(name, body)
+        bad += check_kernel(name, body, limit, track_vm)
     seen = set()
     for h in bad:
         if h not in seen:

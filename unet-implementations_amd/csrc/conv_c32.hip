@@ -19,6 +19,7 @@
 // FUSED = the fused-layer forward (activation on load, bias, statistics); otherwise the data
 // gradient form (optional accumulate, optional BSTATS epilogue).
 #include "conv_params.h"
+#include "lds_asm.h"
 #include <stdlib.h>
 
 #include <utility>
@@ -423,16 +424,20 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
   const int t_ty = tt >> 4, t_tx = 4 * (tt & 3) + ((tt >> 2) & 3);
   const float* const t_src = Pb + ((2 * t_ty) * PW + 2 * t_tx) * LDA + 2 * cp;
   float* const t_dst = Vs + tt * W32_VP + 2 * cp;
+  const unsigned t_srca = lds_addr(t_src);
   auto transform = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    const float* src = t_src + s * (4 * PW * LDA);
-    f32x2w d[4][4];
+    // (plain ds_read_b64 by hand: hipcc pairs them into ds_read2_b64, which the LDS serves at
+    // half the rate - and this phase is nothing but LDS traffic; all 16 waited for at once)
+    f32x2v d[4][4];
+    for_range_c<0, 16>([&](auto ic) {
+      constexpr int r = decltype(ic)::value / 4, c = decltype(ic)::value % 4;
+      d[r][c] = lds_rd64<(s * 4 * PW * LDA + (r * PW + c) * LDA) * 4>(t_srca);
+    });
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const f32x2w*>(src + (r * PW + c) * LDA);
+    for (int r = 0; r < 4; ++r) lds_wait<0>(d[r][0], d[r][1], d[r][2], d[r][3]);
     // B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    f32x2w t[4][4];
+    f32x2v t[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       t[0][c] = d[0][c] - d[2][c];
@@ -443,10 +448,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       float* dst = t_dst + (4 * a) * (32 * W32_VP);
-      *reinterpret_cast<f32x2w*>(dst) = t[a][0] - t[a][2];
-      *reinterpret_cast<f32x2w*>(dst + 32 * W32_VP) = t[a][1] + t[a][2];
-      *reinterpret_cast<f32x2w*>(dst + 2 * 32 * W32_VP) = t[a][2] - t[a][1];
-      *reinterpret_cast<f32x2w*>(dst + 3 * 32 * W32_VP) = t[a][1] - t[a][3];
+      *reinterpret_cast<f32x2v*>(dst) = t[a][0] - t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 32 * W32_VP) = t[a][1] + t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 2 * 32 * W32_VP) = t[a][2] - t[a][1];
+      *reinterpret_cast<f32x2v*>(dst + 3 * 32 * W32_VP) = t[a][1] - t[a][3];
     }
   };
 
@@ -473,22 +478,51 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
     float outv[16], yv[16];
     for_range_c<0, 2>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
+      // BSTATS / accumulate operands of this half tile: loaded now, looked at in its epilogue
+      // (with the loads there, every wave sat out an HBM round trip per half tile)
+      float oldv[8];
+      if (!FUSED) {
+        if (p.bs_partial || p.accumulate) {   // uniform
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int e = k >> 2, a = (k >> 1) & 1, b = k & 1;
+            const size_t pix = ((size_t)n * H + y0 + 4 * s + 2 * o_mb + a) * W + x0 + 2 * (4 * o_r + 2 * lh + e) + b;
+            if (p.bs_partial) yv[8 * s + k] = p.bs_y[pix * p.ldo + li];
+            if (p.accumulate) oldv[k] = p.out[pix * p.ldo + li];
+          }
+        }
+      }
       transform(sc);
       __syncthreads();
+      // eight independent accumulators per k step (xi x m block), the A fragments of the next
+      // k-step pair read while this one multiplies
       f32x4 acc[4][2];
+      f32x2w af[2][4][2];
+      auto frag = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            af[q & 1][j][mb] = *reinterpret_cast<const f32x2w*>(a_src + (j * 32 + 16 * mb) * W32_VP + 8 * q);
+      };
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          acc[j][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* ap = a_src + (j * 32 + 16 * mb) * W32_VP;
+        for (int mb = 0; mb < 2; ++mb) acc[j][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      frag(std::integral_constant<int, 0>{});
+      for_range_c<0, 4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q + 1 < 4) frag(std::integral_constant<int, q + 1>{});
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x2w a2 = *reinterpret_cast<const f32x2w*>(ap + 8 * q);
-            acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0], ub[j][2 * q], acc[j][mb], 0, 0, 0);
-            acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[1], ub[j][2 * q + 1], acc[j][mb], 0, 0, 0);
-          }
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+              acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q & 1][j][mb][e], ub[j][2 * q + e],
+                                                                acc[j][mb], 0, 0, 0);
+      });
       // column pass of A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]) over this wave's row of xi
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
@@ -524,8 +558,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
             if (FUSED) {
               outv[k] += bv;
             } else {
-              if (p.accumulate) outv[k] += *o;   // uniform
-              if (p.bs_partial) yv[k] = p.bs_y[pix * p.ldo + li];   // uniform
+              if (p.accumulate) outv[k] += oldv[4 * e + 2 * a + b];   // uniform
             }
             *o = outv[k];
           }
@@ -636,4 +669,9 @@ extern "C" int unet_set_c32_winograd(int on) {
   const int prev = unet_conv::c32_winograd_flag();
   unet_conv::c32_winograd_flag() = on ? 1 : 0;
   return prev;
+}
+
+extern "C" int unet_conv_c32_is_winograd(int N, int H, int W, int Cin, int Cout, int stride) {
+  return unet_conv::c32_winograd_flag() && stride == 1 && Cin == 32 && Cout == 32 && N > 0 &&
+         H > 0 && W > 0 && H % 8 == 0 && W % 32 == 0 && (long long)N * H * W * 128 < (1LL << 31);
 }

@@ -276,6 +276,18 @@ class NextNorm:
                         _ptr(self.beta), _ptr(self.mask), self.slope, _ptr(self.partial), nbytes, 0)
 
 
+def _c32_winograd(N, H, W, Cin, Cout, stride):
+    """True when the fp32 32 -> 32 channel kernel of this shape runs in its Winograd form
+    (csrc/conv_c32.hip; `set_c32_winograd`): 16/36 of the direct kernel's MFMA FLOPs."""
+    return bool(lib().unet_conv_c32_is_winograd(N, H, W, Cin, Cout, stride))
+
+
+def set_c32_winograd(on):
+    """Process-wide: Winograd (default) or direct kernel for the 32 -> 32 channel stride-1 layers
+    on the fused fp32 pipeline.  Returns the previous setting."""
+    return bool(lib().unet_set_c32_winograd(1 if on else 0))
+
+
 def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False,
                      bf16=False, wd3=None, nxt=None, ud=None):
     """dx[N,H,W,ccols] (+)= transpose-conv of dy for input channels [ci_offset, ci_offset+ccols).
@@ -338,7 +350,10 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
                                                  _stream()))
         nxt.tiles = bs.tiles_out
         if t0 is not None:
-            _timer.end("conv_igemm" + _GROUP[pr], 2.0 * N * Ho * Wo * 9 * ccols * Cout, 1, t0)
+            alg = 2.0 * N * Ho * Wo * 9 * ccols * Cout
+            c32w = pr == 0 and _c32_winograd(N, H, W, ccols, Cout, stride)
+            _timer.end("conv_igemm" + _GROUP[pr], alg, 1, t0,
+                       executed=alg * 16.0 / 36.0 if c32w else None)
         return dx
     t0 = _timer.begin("conv") if _timer is not None else None
     fn = getattr(lib(), "unet_conv3x3_bwd_data" + _SUFFIX[pr])
@@ -355,8 +370,10 @@ def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulat
         if stride == 2:  # fp32: one launch when >= 512 tiles, else one per output parity class
             tiles = -(-(N * Ho * Wo) // 128) * (ccols // 32)
             launches = 1 if (pr == 0 and tiles >= 512) else 4
-        _timer.end("conv_igemm" + _GROUP[pr],
-                   2.0 * N * Ho * Wo * 9 * ccols * Cout, launches, t0)
+        alg = 2.0 * N * Ho * Wo * 9 * ccols * Cout
+        c32w = pr == 0 and _c32_winograd(N, H, W, ccols, Cout, stride)
+        _timer.end("conv_igemm" + _GROUP[pr], alg, launches, t0,
+                   executed=alg * 16.0 / 36.0 if c32w else None)
     return dx
 
 
@@ -654,6 +671,8 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
     if t0 is not None:   # the convolution launch alone (its epilogue includes the statistics)
         alg = 2.0 * N * Ho * Wo * ksize * ksize * (C0 + C1) * Cout
         wino = wu is not None and not b16 and ksize == 3 and stride == 1
+        if not wino and not b16 and w3 is None and u8 is None and ksize == 3 and s1 is None:
+            wino = _c32_winograd(N, H, W, C0, Cout, stride)
         _timer.end("conv_stem_fwd" if C0 == 3 else
                    ("conv_igemm_bf16" if b16 else ("conv_igemm_bf16x3" if w3 is not None else "conv_igemm")),
                    alg, 1, t0, executed=alg * 16.0 / 36.0 if wino else None)
