@@ -482,8 +482,10 @@ int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
 /* The 32 -> 32 channel stride-1 layers (enc0 / dec4 at full resolution) have a Winograd form of
  * their own inside unet_conv_in_fwd / unet_conv3x3_bwd_data(_bs): it needs no extra weight form
  * (U = G g G^T is built in the kernel's prologue from the packed weights), so it is a process-wide
- * switch rather than an entry point: 1 (default) = Winograd, 0 = the direct kernel.  Returns the
- * previous setting.  (csrc/conv_c32.hip) */
+ * switch rather than an entry point: 1 (default) = Winograd when the launch fills the chip (at
+ * least 512 tiles of 8 x 32 pixels: the persistent kernel runs two workgroups per CU), 2 =
+ * Winograd for every shape the kernel tiles, 0 = the direct kernel.  Returns the previous
+ * setting.  (csrc/conv_c32.hip) */
 int unet_set_c32_winograd(int on);
 /* 1 when a 3x3 fused forward / data gradient of this shape runs that Winograd form (for FLOP
  * accounting: it issues 16/36 of the direct kernel's matrix-core FLOPs). */

@@ -216,7 +216,8 @@ def test_data_gradient_winograd(ua, case):
     _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
 
 
-C32_CASES = [(2, 64, 64, True), (1, 8, 32, True), (3, 40, 96, False), (2, 128, 160, True)]
+C32_CASES = [(2, 64, 64, True), (1, 8, 32, True), (3, 40, 96, False), (2, 128, 160, True),
+             (2, 256, 256, True)]
 
 
 @pytest.mark.parametrize("case", C32_CASES)
@@ -242,17 +243,21 @@ def test_c32_winograd_forward(ua, case):
     wk, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
     args = (make_src(ua, x0, c0), None, SLOPE, wk, b.to(DEV), 3, 1, gamma.to(DEV), beta.to(DEV),
             1e-5, mask.to(DEV))
-    assert ua.ops._c32_winograd(N, H, W, C, C, 1)
-    y, st = ua.ops.conv_in_fwd(*args)
-    check(from_nhwc(y), y_ref, 2e-5, "y (Winograd, 32 channels)")
-    assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
-    check(st[1].cpu(), rstd_ref, 5e-5, "rstd (Winograd, 32 channels)")
-    prev = ua.ops.set_c32_winograd(False)
+    # (by default only launches of >= 512 tiles take this form: "always" for the small shapes)
+    assert ua.ops.set_c32_winograd("always") is True
     try:
-        assert prev and not ua.ops._c32_winograd(N, H, W, C, C, 1)
+        assert ua.ops._c32_winograd(N, H, W, C, C, 1)
+        y, st = ua.ops.conv_in_fwd(*args)
+        ua.ops.set_c32_winograd(False)
+        assert not ua.ops._c32_winograd(N, H, W, C, C, 1)
         y32, st32 = ua.ops.conv_in_fwd(*args)
     finally:
         ua.ops.set_c32_winograd(True)
+    assert ua.ops._c32_winograd(N, H, W, C, C, 1) == (N * (H // 8) * (W // 32) >= 512)
+    assert ua.ops._c32_winograd(8, 512, 512, C, C, 1) and not ua.ops._c32_winograd(8, 512, 512, C, 64, 1)
+    check(from_nhwc(y), y_ref, 2e-5, "y (Winograd, 32 channels)")
+    assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), rstd_ref, 5e-5, "rstd (Winograd, 32 channels)")
     check(y, y32, 2e-5, "Winograd vs direct")
     check(st[2], st32[2], 5e-5, "alpha: Winograd vs direct")
 
@@ -282,10 +287,11 @@ def test_c32_winograd_data_gradient(ua, case):
             out["nn"] = nn
         return out
 
-    assert ua.ops._c32_winograd(N, H, W, C, C, 1)
-    wino = run()
-    ua.ops.set_c32_winograd(False)
+    ua.ops.set_c32_winograd("always")
     try:
+        assert ua.ops._c32_winograd(N, H, W, C, C, 1)
+        wino = run()
+        ua.ops.set_c32_winograd(False)
         direct = run()
     finally:
         ua.ops.set_c32_winograd(True)

@@ -41,7 +41,7 @@ def fwd():
 
 
 res = {}
-for form in (0, 1):
+for form in (0, 2):
     lib().unet_set_c32_winograd(form)
     y, st = fwd()
     if form == 0:
@@ -58,14 +58,14 @@ for form in (0, 1):
     res[form] = (y.clone(), [s.clone() for s in st], dx0.clone(), dx1.clone(), part, tiles)
     print(f"{'winograd' if form else 'direct  '}: fwd {t_f * 1e6:7.1f} us {fl / t_f * 1e-12:6.1f} TF/s | dgrad "
           f"{t_d * 1e6:7.1f} us {fl / t_d * 1e-12:6.1f} | dgrad+bs {t_b * 1e6:7.1f} us {fl / t_b * 1e-12:6.1f}", flush=True)
-lib().unet_set_c32_winograd(1)
+lib().unet_set_c32_winograd(1)  # back to the default (size rule)
 
 
 def rel(a, bb):
     return ((a - bb).abs().max() / bb.abs().max()).item()
 
 
-d, wv = res[0], res[1]
+d, wv = res[0], res[2]
 print("y rel", rel(wv[0], d[0]), "stats rel", [rel(a, bb) for a, bb in zip(wv[1], d[1])])
 print("dx rel", rel(wv[2], d[2]), "dx(bs) rel", rel(wv[3], d[3]), "tiles", wv[5], d[5],
       "partial rel", rel(wv[4].view(torch.float32)[:wv[5] * N * C * 2], d[4].view(torch.float32)[:d[5] * N * C * 2]))

@@ -274,25 +274,30 @@ __global__ __launch_bounds__(512, 1) void conv_c32_kernel(const IgemmParams p, i
 // 2 x 2 output tile instead of 36 multiply-adds per output - 4/9 of the matrix-core work.
 //
 // K = 32 is ONE Winograd "chunk", so there is no K loop to pipeline: the kernel is a sequence
-// of phases per 8 x 32-pixel tile, separated by barriers, and loses nothing by it - on gfx950
-// VALU / LDS instructions do not overlap with fp32 MFMAs anyway.
-//   * persistent workgroup of eight waves and the activated (8+2) x 34 x 32 patch in LDS exactly
-//     as above (one buffer: the next tile's patch rides in registers through the whole tile);
+// of phases per unit of work, separated by barriers.
+//   * unit = 4 x 16 pixels = 2 x 8 Winograd tiles, its activated (4+2) x 18 x 32 patch in LDS
+//     (the next unit's patch rides in registers through the unit); a workgroup of FOUR waves
+//     walks whole 8 x 32-pixel tiles, four units each, so the statistics / BSTATS tiles stay
+//     256 pixels; two workgroups per CU (70 KB of LDS each);
 //   * the transformed weights U = G g G^T live in REGISTERS and are built in the prologue from
 //     the packed 3x3 weights the direct kernel reads (no extra weight form, no packing launch):
-//     wave (i, h) keeps row i of the 4 x 4 xi grid for output columns 16 h .. +15: 32 VGPRs;
-//   * per half tile (2 x 16 Winograd tiles): every thread transforms one (tile, channel pair)
-//     V = B^T d B from the patch into LDS; 64 MFMAs (16x16x4) per wave: M[xi] = V[xi] U[xi] for
-//     the wave's four xi; the column pass of A^T M A in registers (the wave holds a whole row of
-//     xi); the row pass across the four waves through a 32 KB LDS exchange, after which lane
-//     (column, half) owns 8 output pixels of one column - the epilogue layout of the direct
-//     kernel: bias, statistics / BSTATS, 128-byte store segments.
+//     wave w keeps row w of the 4 x 4 xi grid for all 32 output columns: 64 VGPRs;
+//   * per unit: every thread transforms one (tile, channel pair) V = B^T d B from the patch into
+//     LDS; 64 MFMAs (16x16x4) per wave: M[xi] = V[xi] U[xi] for the wave's four xi, every
+//     element of V read once; the column pass of A^T M A in registers (the wave holds a whole
+//     row of xi); the row pass across the four waves through a 16 KB LDS exchange, after which
+//     lane (column, half) owns 8 output pixels of one column - the epilogue layout of the direct
+//     kernel: bias, statistics / BSTATS (accumulated per unit), 128-byte store segments.
+// Measured (bs 8, 512 x 512; tools/bench_c32.py): 340 -> 240-270 us per launch.  The phases do
+// NOT overlap, and cannot be made to: an eight-wave version (one workgroup per CU, half-tile
+// units) took 128 us of products + 111 us of everything else, strictly in sequence; this one,
+// whose two workgroups per CU are free to drift apart, takes the same time with or without a
+// forced phase offset between them, and one workgroup per CU alone reaches 89 % of the rate of
+// two - the same behaviour as in DESIGN.md section 3g (an instruction of either wave of a SIMD
+// takes its issue time away from the fp32 matrix pipe), so what counts is the instruction and
+// LDS-byte count per unit, not the schedule.
 // ---------------------------------------------------------------------------
 constexpr int W32_VP = 36;                         // V row pitch in floats (conflict-free b64 fragment reads)
-constexpr int W32_V = 16 * 32 * W32_VP;            // [xi][tile slot 32][channel 32 (+4)]
-constexpr int W32_Z = 4 * 2 * 2 * 4 * 2 * 64;      // [xi row][b][m block][r][column half][lane]
-constexpr size_t W32_LDS = ((size_t)C32_PPIX * C32_LDA + W32_V + W32_Z) * sizeof(float) +
-                           8 * 32 * sizeof(float2);
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
 
@@ -304,17 +309,24 @@ __device__ __forceinline__ float wino_g(int i, int u) {
   return u == 1 ? -0.5f : 0.5f;
 }
 
+constexpr int Q_PW = 18, Q_PH = 6, Q_PPIX = Q_PW * Q_PH;   // 108 patch pixels
+constexpr int Q_SLOTS = Q_PPIX * 8;                        // f32x4 slots
+constexpr int Q_PASSES = (Q_SLOTS + 255) / 256;            // 4
+constexpr int Q_V = 16 * 16 * W32_VP;                      // [xi][tile slot 16][channel 32 (+4)]
+constexpr int Q_Z = 4 * 2 * 4 * 128;                       // [xi row][b][r][column half][lane]
+constexpr size_t Q_LDS = ((size_t)Q_PPIX * C32_LDA + Q_V + Q_Z) * sizeof(float) + 4 * 32 * sizeof(float2);
+
 template <bool FUSED>
-__global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p, int ntiles) {
-  constexpr int LDA = C32_LDA, PW = C32_PW, P_PASSES = C32_PASSES;
+__global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams p, int ntiles) {
+  constexpr int LDA = C32_LDA, PW = Q_PW, P_PASSES = Q_PASSES;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Pb = smem;
-  float* const Vs = smem + C32_PPIX * LDA;
-  float* const Zs = Vs + W32_V;
-  float2* const red = reinterpret_cast<float2*>(Zs + W32_Z);
+  float* const Vs = smem + Q_PPIX * LDA;
+  float* const Zs = Vs + Q_V;
+  float2* const red = reinterpret_cast<float2*>(Zs + Q_Z);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row of the xi grid
   const int li = lane & 31, lh = lane >> 5;
   const int H = p.Hin, W = p.Win;
   const int tiles_x = W / C32_TW, tiles_y = H / C32_TH;
@@ -334,42 +346,44 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
 
-  // ---- U = G g G^T, row wi of the xi grid, for this lane's B-fragment positions ----
-  // MFMA ks = 2 q + e of a xi multiplies input channel 8 q + 2 fk + e into output column
-  // 16 wh + fn (the A fragments below read channel PAIRS: 8 bytes per lane).
-  const int wi = wave & 3, wh = wave >> 2;
+  // ---- U = G g G^T, row `wave` of the xi grid, both column halves ----
   const int fn = lane & 15, fk = lane >> 4;
-  float ub[4][8];
+  float ub[4][2][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ub[j][k] = 0.f;
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ub[j][nb][k] = 0.f;
   for_range_c<0, 9>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
     const int u = (int)(e & 3u), v = (int)((e >> 2) & 3u);   // = offset + 1: g[u][v]
     const int wt = (int)(e >> 4);
-    const float gu = wino_g(wi, u);
-    const float* wp = p.w + (size_t)wt * p.tap_stride + (size_t)(p.n_off + 16 * wh + fn) * 32 + 2 * fk;
+    const float gu = wino_g(wave, u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x2w w2 = *reinterpret_cast<const f32x2w*>(wp + 8 * q);
+    for (int nb = 0; nb < 2; ++nb) {
+      const float* wp = p.w + (size_t)wt * p.tap_stride + (size_t)(p.n_off + 16 * nb + fn) * 32 + 2 * fk;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float c = gu * wino_g(j, v);
-        ub[j][2 * q] = fmaf(c, w2[0], ub[j][2 * q]);
-        ub[j][2 * q + 1] = fmaf(c, w2[1], ub[j][2 * q + 1]);
+      for (int q = 0; q < 4; ++q) {
+        const f32x2w w2 = *reinterpret_cast<const f32x2w*>(wp + 8 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float c = gu * wino_g(j, v);
+          ub[j][nb][2 * q] = fmaf(c, w2[0], ub[j][nb][2 * q]);
+          ub[j][nb][2 * q + 1] = fmaf(c, w2[1], ub[j][nb][2 * q + 1]);
+        }
       }
     }
   });
 
-  // ---- patch slots of this thread (constant across tiles) ----
+  // ---- patch slots of this thread (constant across units) ----
   int pp_rel[P_PASSES], pp_lds[P_PASSES], pp_rc[P_PASSES];
 #pragma unroll
   for (int i = 0; i < P_PASSES; ++i) {
-    const int slot = tid + 512 * i;
-    const bool valid = slot < C32_SLOTS;
+    const int slot = tid + 256 * i;
+    const bool valid = slot < Q_SLOTS;
     const int pix = valid ? slot >> 3 : 0, seg = slot & 7;
     const int prow = pix / PW, pcol = pix - prow * PW;
     pp_rel[i] = ((prow * W + pcol) * 32 + seg * 4) * 4;
@@ -380,25 +394,36 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
   float cs = 1.f;
   unsigned okm = 0;
+  int n_coef = -1;     // image whose activation / BSTATS coefficients are in the registers
   auto tile_pos = [&](int tile, int& n, int& y0, int& x0) {
     const int tx = tile % tiles_x;
     const int r = tile / tiles_x;
     const int ty = r % tiles_y;
     n = r / tiles_y; y0 = ty * C32_TH; x0 = tx * C32_TW;
   };
-  auto load_patch = [&](int tile) {
-    int n, y0, x0;
-    tile_pos(tile, n, y0, x0);
-    const int base = ((n * H + y0 - 1) * W + x0 - 1) * 128;
+  // unit u of a tile: rows 4 (u >> 1) .., columns 16 (u & 1) ..
+  auto load_patch = [&](int n, int yu, int xu) {
+    const int base = ((n * H + yu - 1) * W + xu - 1) * 128;
     okm = 0;
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i) {
       const int prow = pp_rc[i] & 0xff, pcol = pp_rc[i] >> 8;
-      const bool ok = (unsigned)(y0 - 1 + prow) < (unsigned)H && (unsigned)(x0 - 1 + pcol) < (unsigned)W;
+      const bool ok = (unsigned)(yu - 1 + prow) < (unsigned)H && (unsigned)(xu - 1 + pcol) < (unsigned)W;
       okm |= (ok ? 1u : 0u) << i;
       const unsigned off = ok ? (unsigned)(base + pp_rel[i]) : 0x80000000u;
       pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
     }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      if (FUSED) pr[i] = act4(pr[i], ca, cb, cs, (okm >> i) & 1u);
+      if (256 * (i + 1) <= Q_SLOTS || tid + 256 * i < Q_SLOTS)
+        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = pr[i];
+    }
+  };
+  // activation coefficients of image n (the patch in the registers is stored with them)
+  auto load_act = [&](int n) {
     if (FUSED) {
       if (p.act0_alpha) {   // uniform
         const size_t o = (size_t)n * 32 + (tid & 7) * 4;
@@ -408,35 +433,22 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
       }
     }
   };
-  auto store_patch = [&]() {
-#pragma unroll
-    for (int i = 0; i < P_PASSES; ++i) {
-      if (FUSED) pr[i] = act4(pr[i], ca, cb, cs, (okm >> i) & 1u);
-      if (512 * (i + 1) <= C32_SLOTS || tid + 512 * i < C32_SLOTS)
-        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = pr[i];
-    }
-  };
 
-  // ---- input transform: thread -> (channel pair cp, tile slot tt of the half tile) ----
-  // slot tt = 4 wave + (lane >> 4) sits at tile row tt >> 4, tile column 4 (tt & 3) + ((tt >> 2) & 3):
-  // the four 16-lane groups of a wave read pixels 8 apart (conflict-free 8-byte reads)
+  // ---- input transform: thread -> (channel pair cp, tile slot tt = 4 wave + (lane >> 4)) ----
+  // slot tt sits at tile row (tt & 3) >> 1, tile column 4 (tt & 1) + (tt >> 2): the 16-lane
+  // groups of a half wave read pixels 8 apart (conflict-free 8-byte reads)
   const int cp = tid & 15, tt = tid >> 4;
-  const int t_ty = tt >> 4, t_tx = 4 * (tt & 3) + ((tt >> 2) & 3);
-  const float* const t_src = Pb + ((2 * t_ty) * PW + 2 * t_tx) * LDA + 2 * cp;
+  const int t_ty = (tt & 3) >> 1, t_tx = 4 * (tt & 1) + (tt >> 2);
+  const unsigned t_srca = lds_addr(Pb + ((2 * t_ty) * PW + 2 * t_tx) * LDA + 2 * cp);
   float* const t_dst = Vs + tt * W32_VP + 2 * cp;
-  const unsigned t_srca = lds_addr(t_src);
-  auto transform = [&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    // (plain ds_read_b64 by hand: hipcc pairs them into ds_read2_b64, which the LDS serves at
-    // half the rate - and this phase is nothing but LDS traffic; all 16 waited for at once)
+  auto transform = [&]() {
     f32x2v d[4][4];
     for_range_c<0, 16>([&](auto ic) {
       constexpr int r = decltype(ic)::value / 4, c = decltype(ic)::value % 4;
-      d[r][c] = lds_rd64<(s * 4 * PW * LDA + (r * PW + c) * LDA) * 4>(t_srca);
+      d[r][c] = lds_rd64<((r * PW + c) * LDA) * 4>(t_srca);
     });
 #pragma unroll
     for (int r = 0; r < 4; ++r) lds_wait<0>(d[r][0], d[r][1], d[r][2], d[r][3]);
-    // B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
     f32x2v t[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -447,69 +459,84 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      float* dst = t_dst + (4 * a) * (32 * W32_VP);
+      float* dst = t_dst + (4 * a) * (16 * W32_VP);
       *reinterpret_cast<f32x2v*>(dst) = t[a][0] - t[a][2];
-      *reinterpret_cast<f32x2v*>(dst + 32 * W32_VP) = t[a][1] + t[a][2];
-      *reinterpret_cast<f32x2v*>(dst + 2 * 32 * W32_VP) = t[a][2] - t[a][1];
-      *reinterpret_cast<f32x2v*>(dst + 3 * 32 * W32_VP) = t[a][1] - t[a][3];
+      *reinterpret_cast<f32x2v*>(dst + 16 * W32_VP) = t[a][1] + t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 2 * 16 * W32_VP) = t[a][2] - t[a][1];
+      *reinterpret_cast<f32x2v*>(dst + 3 * 16 * W32_VP) = t[a][1] - t[a][3];
     }
   };
 
-  // ---- products: wave (wi, wh): xi = 4 wi + j, tile slots 16 mb + fn, columns 16 wh + .. ----
-  const float* const a_src = Vs + (4 * wi * 32 + fn) * W32_VP + 2 * fk;
-  float* const z_dst = Zs + (wi * 2) * 1024 + wh * 64 + lane;     // + b * 1024 + (mb * 4 + r) * 128
-  // ---- row pass + epilogue: wave -> tile row (wave >> 2), tile columns 4 (wave & 3) .. +3 of the
-  //      half tile; lane (li, lh) -> column li, tile columns 4 (wave & 3) + 2 lh + e ----
-  const int o_mb = wave >> 2, o_r = wave & 3;
-  const float* const z_src = Zs + (o_mb * 4 + o_r) * 128 + (li >> 4) * 64 + 32 * lh + (li & 15);   // + e * 16 + (i * 2 + b) * 1024
+  const float* const a_src = Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk;   // + j * 16 * VP + 8 q
+  float* const z_dst = Zs + (wave * 2) * 512 + lane;                         // + b * 512 + r * 128 + nb * 64
+  // row pass + epilogue: wave -> slots with r = wave; lane (li, lh) -> column li, k = 2 lh + e
+  const float* const z_src = Zs + wave * 128 + (li >> 4) * 64 + 32 * lh + (li & 15);   // + e * 16 + (i * 2 + b) * 512
+  const int o_ty = wave >> 1, o_tx0 = 4 * (wave & 1) + 2 * lh;
   const bool summaries = FUSED ? p.stats != nullptr : p.bs_partial != nullptr;   // uniform
   const float bv = (FUSED && p.bias) ? p.bias[li] : 0.f;
+  BwdCoef cf{};
 
-  load_patch(t_first);
-  store_patch();
+  {
+    int n, y0, x0;
+    tile_pos(t_first, n, y0, x0);
+    load_patch(n, y0, x0);
+    load_act(n);
+    n_coef = n;
+    if (!FUSED && p.bs_partial) cf = bwd_coef(p, n, li);
+    store_patch();
+  }
   __syncthreads();
 
   for (int tile = t_first; tile < t_end; tile += t_stride) {
     const int nxt = tile + t_stride;
     const bool more = nxt < t_end;
-    if (more) load_patch(nxt);   // uniform
     int n, y0, x0;
     tile_pos(tile, n, y0, x0);
-    float outv[16], yv[16];
-    for_range_c<0, 2>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      // BSTATS / accumulate operands of this half tile: loaded now, looked at in its epilogue
-      // (with the loads there, every wave sat out an HBM round trip per half tile)
-      float oldv[8];
+    // running (mean, M2) of the four units (FUSED) / (S1, S2) (BSTATS) of this lane's column
+    float um[4], uq[4];
+    float s1 = 0.f, s2 = 0.f;
+    for_range_c<0, 4>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int yu = y0 + 4 * (u >> 1), xu = x0 + 16 * (u & 1);
+      // the next unit's patch: into the registers now, to LDS after this unit's epilogue
+      bool have_next = true;
+      int nn = n;
+      if constexpr (u < 3) {
+        load_patch(n, y0 + 4 * ((u + 1) >> 1), x0 + 16 * ((u + 1) & 1));
+      } else {
+        have_next = more;
+        if (more) {   // uniform
+          int ny, nx;
+          tile_pos(nxt, nn, ny, nx);
+          load_patch(nn, ny, nx);
+        }
+      }
+      float yv[8], oldv[8];
       if (!FUSED) {
         if (p.bs_partial || p.accumulate) {   // uniform
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const int e = k >> 2, a = (k >> 1) & 1, b = k & 1;
-            const size_t pix = ((size_t)n * H + y0 + 4 * s + 2 * o_mb + a) * W + x0 + 2 * (4 * o_r + 2 * lh + e) + b;
-            if (p.bs_partial) yv[8 * s + k] = p.bs_y[pix * p.ldo + li];
+            const size_t pix = ((size_t)n * H + yu + 2 * o_ty + a) * W + xu + 2 * (o_tx0 + e) + b;
+            if (p.bs_partial) yv[k] = p.bs_y[pix * p.ldo + li];
             if (p.accumulate) oldv[k] = p.out[pix * p.ldo + li];
           }
         }
       }
-      transform(sc);
+      transform();
       __syncthreads();
-      // eight independent accumulators per k step (xi x m block), the A fragments of the next
-      // k-step pair read while this one multiplies
       f32x4 acc[4][2];
-      f32x2w af[2][4][2];
+      f32x2w af[2][4];
       auto frag = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-            af[q & 1][j][mb] = *reinterpret_cast<const f32x2w*>(a_src + (j * 32 + 16 * mb) * W32_VP + 8 * q);
+          af[q & 1][j] = *reinterpret_cast<const f32x2w*>(a_src + j * 16 * W32_VP + 8 * q);
       };
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) acc[j][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < 2; ++nb) acc[j][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       frag(std::integral_constant<int, 0>{});
       for_range_c<0, 4>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
@@ -519,82 +546,105 @@ __global__ __launch_bounds__(512, 1) void conv_wino32_kernel(const IgemmParams p
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-              acc[j][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q & 1][j][mb][e], ub[j][2 * q + e],
-                                                                acc[j][mb], 0, 0, 0);
+            for (int nb = 0; nb < 2; ++nb)
+              acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q & 1][j][e], ub[j][nb][2 * q + e],
+                                                                acc[j][nb], 0, 0, 0);
       });
-      // column pass of A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]) over this wave's row of xi
+      // column pass of A^T M A over this wave's row of xi
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float m0 = acc[0][mb][r], m1 = acc[1][mb][r], m2 = acc[2][mb][r], m3 = acc[3][mb][r];
-          z_dst[(mb * 4 + r) * 128] = m0 + (m1 + m2);
-          z_dst[1024 + (mb * 4 + r) * 128] = (m1 - m2) - m3;
+          const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
+          z_dst[r * 128 + nb * 64] = m0 + (m1 + m2);
+          z_dst[512 + r * 128 + nb * 64] = (m1 - m2) - m3;
         }
       __syncthreads();
       // row pass: Y[a][b] = sum_i A^T[a][i] Z[i][b]
-      const int yrow = y0 + 4 * s + 2 * o_mb;
+      float ov[8];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int xcol = x0 + 2 * (4 * o_r + 2 * lh + e);
         float z[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) z[i][b] = z_src[e * 16 + (i * 2 + b) * 1024];
+          for (int b = 0; b < 2; ++b) z[i][b] = z_src[e * 16 + (i * 2 + b) * 512];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          outv[8 * s + 4 * e + b] = z[0][b] + (z[1][b] + z[2][b]);
-          outv[8 * s + 4 * e + 2 + b] = (z[1][b] - z[2][b]) - z[3][b];
+          ov[4 * e + b] = z[0][b] + (z[1][b] + z[2][b]);
+          ov[4 * e + 2 + b] = (z[1][b] - z[2][b]) - z[3][b];
         }
+      }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+      for (int k = 0; k < 8; ++k) {
+        const int e = k >> 2, a = (k >> 1) & 1, b = k & 1;
+        const size_t pix = ((size_t)n * H + yu + 2 * o_ty + a) * W + xu + 2 * (o_tx0 + e) + b;
+        if (FUSED) ov[k] += bv;
+        else if (p.accumulate) ov[k] += oldv[k];   // uniform
+        p.out[pix * p.ldo + li] = ov[k];
+      }
+      if (FUSED) {
+        if (p.stats) {   // uniform: (mean, M2) of this unit's 8 values
+          float sm = 0.f;
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int k = 8 * s + 4 * e + 2 * a + b;
-            const size_t pix = ((size_t)n * H + yrow + a) * W + xcol + b;
-            float* o = p.out + pix * p.ldo + li;
-            if (FUSED) {
-              outv[k] += bv;
-            } else {
-              if (p.accumulate) outv[k] += oldv[4 * e + 2 * a + b];   // uniform
-            }
-            *o = outv[k];
+          for (int k = 0; k < 8; ++k) sm += ov[k];
+          const float mean = sm * 0.125f;
+          float m2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float dd = ov[k] - mean; m2 = fmaf(dd, dd, m2); }
+          um[u] = mean; uq[u] = m2;
+        }
+      } else if (p.bs_partial) {   // uniform
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float z = fmaf(yv[k], cf.A, cf.B0);
+          const float gz = ov[k] * cf.mk * (z > 0.f ? 1.f : p.slope);
+          s1 += gz;
+          s2 = fmaf(gz, (yv[k] - cf.mu) * cf.rs, s2);
+        }
+      }
+      if constexpr (u == 3) {
+        if (FUSED) {
+          if (p.stats) {   // uniform
+            wf_merge_eq(um[0], uq[0], um[1], uq[1], 8.f);
+            wf_merge_eq(um[2], uq[2], um[3], uq[3], 8.f);
+            wf_merge_eq(um[0], uq[0], um[2], uq[2], 16.f);
+            const float mb = __shfl_xor(um[0], 32, 64), qb = __shfl_xor(uq[0], 32, 64);
+            wf_merge_eq(um[0], uq[0], mb, qb, 32.f);
+            if (lh == 0) red[wave * 32 + li] = float2{um[0], uq[0]};
           }
+        } else if (p.bs_partial) {   // uniform
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (lh == 0) red[wave * 32 + li] = float2{s1, s2};
+        }
       }
+      if (have_next) {   // uniform
+        if (nn != n_coef) {   // uniform: a new image - its coefficients (rare: once per image)
+          load_act(nn);
+          if (!FUSED && p.bs_partial) cf = bwd_coef(p, nn, li);
+          n_coef = nn;
+        }
+        store_patch();   // this unit's transform lies two barriers back
+      }
+      __syncthreads();
     });
-    if (FUSED) {
-      if (p.stats) {   // uniform
-        const float2 mine = wave_col_stats<1>([&](int, int r) { return outv[r]; });
-        if (lh == 0) red[wave * 32 + li] = mine;
-      }
-    } else if (p.bs_partial) {   // uniform
-      const BwdCoef cf = bwd_coef(p, n, li);
-      const float2 mine = wave_bwd_stats<1>(
-          cf, p.slope, [&](int, int r) { return outv[r]; }, [&](int, int r) { return yv[r]; });
-      if (lh == 0) red[wave * 32 + li] = mine;
-    }
-    if (more) store_patch();   // every transform of this tile lies two barriers back
-    __syncthreads();
-    if (summaries && tid < 32) {   // red is rewritten five barriers from now
+    if (summaries && tid < 32) {   // red is rewritten eleven barriers from now
       const float2* rr = red + tid;
       const size_t dst = ((size_t)n * (tiles_x * tiles_y) + (y0 / C32_TH) * tiles_x + (x0 >> 5)) * 32 + tid;
       if (FUSED) {
-        float mean[4], m2[4];
+        float mean[2], m2[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
           mean[k] = rr[(2 * k) * 32].x; m2[k] = rr[(2 * k) * 32].y;
-          wf_merge_eq(mean[k], m2[k], rr[(2 * k + 1) * 32].x, rr[(2 * k + 1) * 32].y, 32.f);
+          wf_merge_eq(mean[k], m2[k], rr[(2 * k + 1) * 32].x, rr[(2 * k + 1) * 32].y, 64.f);
         }
-        wf_merge_eq(mean[0], m2[0], mean[1], m2[1], 64.f);
-        wf_merge_eq(mean[2], m2[2], mean[3], m2[3], 64.f);
-        wf_merge_eq(mean[0], m2[0], mean[2], m2[2], 128.f);
+        wf_merge_eq(mean[0], m2[0], mean[1], m2[1], 128.f);
         p.stats[dst] = float2{mean[0], m2[0]};
       } else {
         float a = rr[0].x, b = rr[0].y;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { a += rr[k * 32].x; b += rr[k * 32].y; }
+        for (int k = 1; k < 4; ++k) { a += rr[k * 32].x; b += rr[k * 32].y; }
         p.bs_partial[dst] = float2{a, b};
       }
     }
@@ -635,17 +685,20 @@ int launch_c32(const IgemmParams& p0, int fused, hipStream_t stream, int* tile_p
   }
   const int ntiles = p.N * (p.Hin / C32_TH) * (p.Win / C32_TW);
   const int grid = ntiles < 256 ? ntiles : 256;
-  if (c32_winograd_flag()) {
+  // Winograd form: when the launch fills the chip with its two workgroups per CU (the same kind
+  // of rule as for the wider layers' Winograd kernels), or always on request (tests)
+  if (c32_winograd_flag() == 2 || (c32_winograd_flag() == 1 && ntiles >= 512)) {
+    const int grid2 = ntiles < 512 ? ntiles : 512;
     if (fused) {
-      auto kern = conv_wino32_kernel<true>;
-      UNET_SET_DYN_LDS(kern, W32_LDS);
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), W32_LDS, stream, p, ntiles);
+      auto kern = conv_wino32q_kernel<true>;
+      UNET_SET_DYN_LDS(kern, Q_LDS);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid2), dim3(256), Q_LDS, stream, p, ntiles);
     } else {
-      auto kern = conv_wino32_kernel<false>;
-      UNET_SET_DYN_LDS(kern, W32_LDS);
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), W32_LDS, stream, p, ntiles);
+      auto kern = conv_wino32q_kernel<false>;
+      UNET_SET_DYN_LDS(kern, Q_LDS);
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid2), dim3(256), Q_LDS, stream, p, ntiles);
     }
-    UNET_CHECK_LAUNCH("conv_wino32");
+    UNET_CHECK_LAUNCH("conv_wino32q");
     return UNET_OK;
   }
   if (fused) {
@@ -663,15 +716,19 @@ int launch_c32(const IgemmParams& p0, int fused, hipStream_t stream, int* tile_p
 
 }  // namespace unet_conv
 
-// 1: the 32 -> 32 channel layers run the Winograd F(2x2, 3x3) kernel (default), 0: the direct
-// kernel.  Returns the previous setting.
+// 1 (default): the 32 -> 32 channel layers run the Winograd F(2x2, 3x3) kernel when the launch
+// has at least 512 tiles of 8 x 32 pixels (two workgroups per CU), 2: always, 0: never (the
+// direct kernel).  Returns the previous setting.
 extern "C" int unet_set_c32_winograd(int on) {
   const int prev = unet_conv::c32_winograd_flag();
-  unet_conv::c32_winograd_flag() = on ? 1 : 0;
+  unet_conv::c32_winograd_flag() = on < 0 ? 0 : (on > 2 ? 2 : on);
   return prev;
 }
 
 extern "C" int unet_conv_c32_is_winograd(int N, int H, int W, int Cin, int Cout, int stride) {
-  return unet_conv::c32_winograd_flag() && stride == 1 && Cin == 32 && Cout == 32 && N > 0 &&
-         H > 0 && W > 0 && H % 8 == 0 && W % 32 == 0 && (long long)N * H * W * 128 < (1LL << 31);
+  const int f = unet_conv::c32_winograd_flag();
+  if (!(f && stride == 1 && Cin == 32 && Cout == 32 && N > 0 && H > 0 && W > 0 && H % 8 == 0 &&
+        W % 32 == 0 && (long long)N * H * W * 128 < (1LL << 31)))
+    return 0;
+  return f == 2 || (long long)N * (H / 8) * (W / 32) >= 512;
 }

@@ -283,9 +283,13 @@ def _c32_winograd(N, H, W, Cin, Cout, stride):
 
 
 def set_c32_winograd(on):
-    """Process-wide: Winograd (default) or direct kernel for the 32 -> 32 channel stride-1 layers
-    on the fused fp32 pipeline.  Returns the previous setting."""
-    return bool(lib().unet_set_c32_winograd(1 if on else 0))
+    """Process-wide choice for the 32 -> 32 channel stride-1 layers on the fused fp32 pipeline:
+    True (default) = the Winograd kernel for launches that fill the chip (>= 512 tiles of 8 x 32
+    pixels), "always" = for every shape it tiles, False = the direct kernel.  Returns the previous
+    setting in the same terms."""
+    code = 2 if on == "always" else (1 if on else 0)
+    prev = lib().unet_set_c32_winograd(code)
+    return "always" if prev == 2 else bool(prev)
 
 
 def conv3x3_bwd_data(dy, wd, ci_offset, ccols, H, W, stride, out=None, accumulate=False,
