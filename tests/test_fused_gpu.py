@@ -303,6 +303,44 @@ def test_c32_winograd_data_gradient(ua, case):
         _in_bwd_both_ways(ua, wino["bs"], wino["nn"], y, st, gamma, beta, mask)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, True), (1, 8, 32, True), (3, 40, 96, False),
+                                  (2, 256, 256, True)])
+def test_c32_winograd_weight_gradient(ua, case):
+    """The 32 -> 32 channel layers' Winograd F(3x3,2x2) weight gradient (csrc/conv_wgrad.hip:
+    conv_wgrad_wino32_kernel - both operands transformed on chip, all 16 xi accumulated over a
+    persistent walk, A^T M A once per workgroup) against the fp64 gradient of the activated
+    operand and against the direct kernel behind the same entry point; written into a column
+    slice of a wider gradient (the skip half of dec4.0: 32 of 96 input channels)."""
+    N, H, W, act = case
+    C = 32
+    x = rnd(N, C, H, W, seed=1)
+    c0 = coeffs(N, C, 10) if act else None
+    dy = rnd(N, C, H, W, seed=2)
+    a = act_ref(x, *c0) if c0 else x.double()
+    ref = torch.nn.grad.conv2d_weight(a, (C, C, 3, 3), dy.double(), padding=1)
+    src = make_src(ua, x, c0)
+    dyd = to_nhwc(dy)
+
+    def run(form):
+        ua.ops.set_c32_winograd(form)
+        try:
+            assert bool(ua._lib.lib().unet_conv3x3_bwd_weight_is_winograd(N, H, W, C, C, 1)) == bool(form)
+            dw = torch.zeros(C, C, 3, 3, device=DEV)
+            ua.ops.conv_in_bwd_weight(src, SLOPE, dyd, dw, 0, 3, 1)
+            wide = torch.full((C, 96, 3, 3), 7.0, device=DEV)
+            ua.ops.conv_in_bwd_weight(src, SLOPE, dyd, wide, 64, 3, 1)
+        finally:
+            ua.ops.set_c32_winograd(True)
+        return dw, wide
+
+    dw, wide = run("always")
+    dw_d, wide_d = run(False)
+    check(dw.cpu(), ref, 2e-5, "Winograd weight gradient (32 channels) vs fp64")
+    check(dw, dw_d, 2e-5, "Winograd vs direct weight gradient")
+    assert torch.equal(wide[:, 64:], dw) and bool((wide[:, :64] == 7.0).all())
+    assert torch.equal(wide_d[:, 64:], dw_d)
+
+
 X3_FUSED_CASES = [  # shapes the split patch kernel takes in the fused pipeline
     (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # 128 columns, two sources
     (2, 256, 256, 64, 0, 64, 1, 3, True, False),     # 64 columns, 8-row tiles

@@ -55,7 +55,13 @@ for form in (0, 2):
     dx1, part, tiles = dg(True)
     t_d = timeit(lambda: dg(False))
     t_b = timeit(lambda: dg(True))
-    res[form] = (y.clone(), [s.clone() for s in st], dx0.clone(), dx1.clone(), part, tiles)
+    dw = torch.zeros(C, C, 3, 3, device="cuda")
+    def wg():
+        return ops.conv_in_bwd_weight(src, 0.01, dy, dw, 0, 3, 1)
+    wg()
+    t_w = timeit(wg)
+    res[form] = (y.clone(), [s.clone() for s in st], dx0.clone(), dx1.clone(), part, tiles, dw.clone())
+    print(f"          weight gradient {t_w * 1e6:7.1f} us {fl / t_w * 1e-12:6.1f} TF/s", flush=True)
     print(f"{'winograd' if form else 'direct  '}: fwd {t_f * 1e6:7.1f} us {fl / t_f * 1e-12:6.1f} TF/s | dgrad "
           f"{t_d * 1e6:7.1f} us {fl / t_d * 1e-12:6.1f} | dgrad+bs {t_b * 1e6:7.1f} us {fl / t_b * 1e-12:6.1f}", flush=True)
 lib().unet_set_c32_winograd(1)  # back to the default (size rule)
@@ -69,3 +75,4 @@ d, wv = res[0], res[2]
 print("y rel", rel(wv[0], d[0]), "stats rel", [rel(a, bb) for a, bb in zip(wv[1], d[1])])
 print("dx rel", rel(wv[2], d[2]), "dx(bs) rel", rel(wv[3], d[3]), "tiles", wv[5], d[5],
       "partial rel", rel(wv[4].view(torch.float32)[:wv[5] * N * C * 2], d[4].view(torch.float32)[:d[5] * N * C * 2]))
+print("dw rel", rel(wv[6], d[6]))

@@ -246,6 +246,7 @@ bool patch_f32_applicable(const IgemmParams& p);              // conv_patch.hip
 int launch_patch_f32_auto(const IgemmParams& p, hipStream_t stream,    // returns 1 if no tile fits
                           int* stats_px = nullptr, int* bs_px = nullptr);
 int launch_patch_up_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
+int& c32_winograd_flag();                                      // unet_set_c32_winograd, conv_c32.hip
 bool c32_applicable(const IgemmParams& p);                    // 32 -> 32 channels, conv_c32.hip
 int launch_c32(const IgemmParams& p, int fused, hipStream_t stream, int* tile_px);
 bool patch_s2_applicable(const IgemmParams& p);               // stride-2 forward, conv_patch.hip

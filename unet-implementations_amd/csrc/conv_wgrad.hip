@@ -1552,6 +1552,283 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
     }
 }
 
+// ---------------------------------------------------------------------------
+// Winograd F(3x3, 2x2) weight gradient of the 32 -> 32 channel layers at full resolution (the
+// direct kernel: 349 us each, three per step), by the recipe of conv_wino32q_kernel
+// (conv_c32.hip): the (ci, co) tile IS the layer, so one persistent workgroup per CU keeps all
+// 16 xi accumulators (wave (i, h): row i of the xi grid, output-channel half h: 32 VGPRs) over
+// its whole walk and transforms BOTH operands on chip per unit of 4 x 16 pixels (16 tiles = four
+// k steps): waves 0-3 take V = B^T d B of the activated x patch in LDS, waves 4-7 E' = G' e G'^T
+// of the 2 x 2 dy tiles straight from global memory (G' = G without its halves, which the
+// epilogue applies: exact).  No exchange and no store per unit - two barriers - and ONE
+// A^T M A + slab per workgroup at the end.
+// ---------------------------------------------------------------------------
+constexpr int WQ_PW = 18, WQ_PPIX = 108, WQ_LDA = 36, WQ_SLOTS = WQ_PPIX * 8;
+constexpr int WQ_PASSES = (WQ_SLOTS + 511) / 512;          // 2
+constexpr int WQ_VP = 36;                                   // row pitch of V / E (floats)
+constexpr int WQ_V = 16 * 16 * WQ_VP;                       // [xi][tile slot 16][channel 32 (+4)]
+constexpr size_t WQ_LDS = ((size_t)WQ_PPIX * WQ_LDA + 2 * WQ_V) * sizeof(float);
+static_assert(4 * 3 * 1024 <= 2 * WQ_V, "the epilogue exchange lives in the V / E stages");
+
+template <bool ACT>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradParams p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Pb = smem;
+  float* const Vs = smem + WQ_PPIX * WQ_LDA;
+  float* const Es = Vs + WQ_V;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W;
+  const int tiles_x = W / 32, tiles_y = H / 8;
+  const int G = gridDim.x;
+  int t_first, t_stride, t_end;
+  if ((ntiles & 7) == 0 && (G & 7) == 0) {
+    const int per = ntiles >> 3, xcd = blockIdx.x & 7;
+    t_first = xcd * per + (blockIdx.x >> 3);
+    t_stride = G >> 3;
+    t_end = (xcd + 1) * per;
+  } else {
+    t_first = blockIdx.x; t_stride = G; t_end = ntiles;
+  }
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+  // ---- patch slots of this thread ----
+  int pp_rel[WQ_PASSES], pp_lds[WQ_PASSES], pp_rc[WQ_PASSES];
+#pragma unroll
+  for (int i = 0; i < WQ_PASSES; ++i) {
+    const int slot = tid + 512 * i;
+    const bool valid = slot < WQ_SLOTS;
+    const int pix = valid ? slot >> 3 : 0, seg = slot & 7;
+    const int prow = pix / WQ_PW, pcol = pix - prow * WQ_PW;
+    pp_rel[i] = ((prow * W + pcol) * 32 + seg * 4) * 4;
+    pp_lds[i] = pix * WQ_LDA + seg * 4;
+    pp_rc[i] = valid ? (prow | (pcol << 8)) : (1 << 20);
+  }
+  f32x4 pr[WQ_PASSES];
+  f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  unsigned okm = 0;
+  int n_coef = -1;
+  auto tile_pos = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % tiles_x;
+    const int r = tile / tiles_x;
+    const int ty = r % tiles_y;
+    n = r / tiles_y; y0 = ty * 8; x0 = tx * 32;
+  };
+  // ---- operand roles: waves 0-3 transform x, waves 4-7 dy; slot tt = 4 (wave & 3) + (lane >> 4)
+  //      sits at tile row (tt & 3) >> 1, tile column 4 (tt & 1) + (tt >> 2) ----
+  const bool xside = wave < 4;   // uniform
+  const int cp = tid & 15, tt = (tid >> 4) & 15;
+  const int t_ty = (tt & 3) >> 1, t_tx = 4 * (tt & 1) + (tt >> 2);
+  const unsigned t_srca = lds_addr(Pb + ((2 * t_ty) * WQ_PW + 2 * t_tx) * WQ_LDA + 2 * cp);
+  float* const t_dst = (xside ? Vs : Es) + tt * WQ_VP + 2 * cp;
+  f32x2v en[4];   // dy side: the next unit's 2 x 2 tile (channel pair cp)
+  auto load_unit = [&](int n, int yu, int xu) {   // patch of x (all threads) + dy tile (waves 4-7)
+    const int base = ((n * H + yu - 1) * W + xu - 1) * 128;
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < WQ_PASSES; ++i) {
+      const int prow = pp_rc[i] & 0xff, pcol = pp_rc[i] >> 8;
+      const bool ok = (unsigned)(yu - 1 + prow) < (unsigned)H && (unsigned)(xu - 1 + pcol) < (unsigned)W;
+      okm |= (ok ? 1u : 0u) << i;
+      const unsigned off = ok ? (unsigned)(base + pp_rel[i]) : 0x80000000u;
+      pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+    }
+    if (!xside) {   // uniform
+      const float* d = p.dy + (((size_t)n * H + yu + 2 * t_ty) * W + xu + 2 * t_tx) * 32 + 2 * cp;
+      en[0] = *reinterpret_cast<const f32x2v*>(d);
+      en[1] = *reinterpret_cast<const f32x2v*>(d + 32);
+      en[2] = *reinterpret_cast<const f32x2v*>(d + (size_t)W * 32);
+      en[3] = *reinterpret_cast<const f32x2v*>(d + (size_t)W * 32 + 32);
+    }
+  };
+  auto load_act = [&](int n) {
+    if (ACT) {
+      const size_t o = (size_t)n * 32 + (tid & 7) * 4;
+      ca = *reinterpret_cast<const f32x4*>(p.alpha + o);
+      cb = *reinterpret_cast<const f32x4*>(p.beta + o);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < WQ_PASSES; ++i) {
+      if (ACT) pr[i] = act4(pr[i], ca, cb, p.slope, (okm >> i) & 1u);
+      if (512 * (i + 1) <= WQ_SLOTS || tid + 512 * i < WQ_SLOTS)
+        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = pr[i];
+    }
+  };
+  auto transform_x = [&]() {   // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]
+    f32x2v d[4][4];
+    for_range<0, 16>([&](auto ic) {
+      constexpr int r = decltype(ic)::value / 4, c = decltype(ic)::value % 4;
+      d[r][c] = lds_rd64<((r * WQ_PW + c) * WQ_LDA) * 4>(t_srca);
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_wait<0>(d[r][0], d[r][1], d[r][2], d[r][3]);
+    f32x2v t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t[0][c] = d[0][c] - d[2][c];
+      t[1][c] = d[1][c] + d[2][c];
+      t[2][c] = d[2][c] - d[1][c];
+      t[3][c] = d[3][c] - d[1][c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float* dst = t_dst + (4 * a) * (16 * WQ_VP);
+      *reinterpret_cast<f32x2v*>(dst) = t[a][0] - t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 16 * WQ_VP) = t[a][1] + t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 2 * 16 * WQ_VP) = t[a][2] - t[a][1];
+      *reinterpret_cast<f32x2v*>(dst + 3 * 16 * WQ_VP) = t[a][3] - t[a][1];
+    }
+  };
+  auto transform_dy = [&](const f32x2v (&e)[4]) {   // E' = G' e G'^T,  G' = [1 0; 1 1; 1 -1; 0 1]
+    f32x2v t[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      t[0][b] = e[b];
+      t[1][b] = e[b] + e[2 + b];
+      t[2][b] = e[b] - e[2 + b];
+      t[3][b] = e[2 + b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float* dst = t_dst + (4 * a) * (16 * WQ_VP);
+      *reinterpret_cast<f32x2v*>(dst) = t[a][0];
+      *reinterpret_cast<f32x2v*>(dst + 16 * WQ_VP) = t[a][0] + t[a][1];
+      *reinterpret_cast<f32x2v*>(dst + 2 * 16 * WQ_VP) = t[a][0] - t[a][1];
+      *reinterpret_cast<f32x2v*>(dst + 3 * 16 * WQ_VP) = t[a][1];
+    }
+  };
+
+  // ---- products: wave (wi, wh): xi = 4 wi + j; M[ci][co] += sum over tile slots k = 4 q + fk ----
+  const int wi = wave & 3, wh = wave >> 2;
+  const int fn = lane & 15, fk = lane >> 4;
+  const float* const a_src = Vs + (4 * wi * 16 + fk) * WQ_VP + fn;        // + (j * 16 + 4 q) * VP + 16 cbi
+  const float* const b_src = Es + (4 * wi * 16 + fk) * WQ_VP + 16 * wh + fn;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (t_first < t_end) {
+    {
+      int n, y0, x0;
+      tile_pos(t_first, n, y0, x0);
+      load_unit(n, y0, x0);
+      load_act(n);
+      n_coef = n;
+      store_patch();
+    }
+    __syncthreads();
+    for (int tile = t_first; tile < t_end; tile += t_stride) {
+      const int nxt = tile + t_stride;
+      const bool more = nxt < t_end;
+      int n, y0, x0;
+      tile_pos(tile, n, y0, x0);
+      for_range<0, 4>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        f32x2v ec[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ec[k] = en[k];   // this unit's dy tile (loaded a unit ago)
+        bool have_next = true;
+        int nn = n;
+        if constexpr (u < 3) {
+          load_unit(n, y0 + 4 * ((u + 1) >> 1), x0 + 16 * ((u + 1) & 1));
+        } else {
+          have_next = more;
+          if (more) {   // uniform
+            int ny, nx;
+            tile_pos(nxt, nn, ny, nx);
+            load_unit(nn, ny, nx);
+          }
+        }
+        if (xside) transform_x(); else transform_dy(ec);   // uniform
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float b = b_src[(j * 16 + 4 * q) * WQ_VP];
+            const float a0 = a_src[(j * 16 + 4 * q) * WQ_VP];
+            const float a1 = a_src[(j * 16 + 4 * q) * WQ_VP + 16];
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[j][1], 0, 0, 0);
+          }
+        if (have_next) {   // uniform
+          if (nn != n_coef) { load_act(nn); n_coef = nn; }   // uniform, once per image
+          store_patch();
+        }
+        __syncthreads();
+      });
+    }
+  }
+
+  // ---- epilogue: the halves of G (xi row / column 1 or 2), dW = A^T M A with
+  //      A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]: columns in registers, rows across the waves ----
+  const float si = (wi == 1 || wi == 2) ? 0.5f : 1.f;
+  float* const X = Vs;   // [xi row 4][v 3][ci 32][co 32]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m0 = acc[0][c][r] * si, m1 = acc[1][c][r] * (0.5f * si), m2 = acc[2][c][r] * (0.5f * si),
+                  m3 = acc[3][c][r] * si;
+      float* o = X + (size_t)(wi * 3) * 1024 + (16 * c + 4 * fk + r) * 32 + 16 * wh + fn;
+      o[0] = m0 + m1 + m2;
+      o[1024] = m1 - m2;
+      o[2048] = m1 + m2 + m3;
+    }
+  __syncthreads();
+  float* const slab = p.partial + (size_t)blockIdx.x * 9 * 1024;
+#pragma unroll
+  for (int k = 0; k < 18; ++k) {
+    const int idx = tid + 512 * k;
+    const int uv = idx >> 10, rc = idx & 1023;
+    const int u = uv / 3, v = uv - 3 * u;
+    const float x0 = X[(0 * 3 + v) * 1024 + rc], x1 = X[(1 * 3 + v) * 1024 + rc];
+    const float x2 = X[(2 * 3 + v) * 1024 + rc], x3 = X[(3 * 3 + v) * 1024 + rc];
+    slab[idx] = u == 0 ? x0 + x1 + x2 : (u == 1 ? x1 - x2 : x1 + x2 + x3);
+  }
+}
+
+// shapes it takes: the layer is ONE 32 x 32 channel tile, stride 1, whole 8 x 32-pixel tiles,
+// enough of them for one workgroup per CU
+// (unet_set_c32_winograd: 1 = when there is a tile for every CU, 2 = always, 0 = never)
+bool wgrad_wino32_ok(int N, int H, int W, int Cx, int Cout, int stride) {
+  const int f = unet_conv::c32_winograd_flag();
+  if (!(f && stride == 1 && Cx == 32 && Cout == 32 && H % 8 == 0 && W % 32 == 0 &&
+        (long long)N * H * W * 128 < (1LL << 31)))
+    return false;
+  return f == 2 || (long long)N * (H / 8) * (W / 32) >= 256;
+}
+WgradPlan make_plan_wino32(int N, int H, int W) {
+  WgradPlan pl{};
+  const long long t = (long long)N * (H / 8) * (W / 32);
+  pl.nw = 8; pl.ci_t = pl.co_t = 32; pl.npp = 1; pl.sps = 1; pl.S = 16;
+  pl.split = (int)(t < 256 ? t : 256);
+  pl.total_segs = (int)t; pl.segs_per_block = 1; pl.segs_per_row = W / 32;
+  const size_t E = (size_t)9 * 32 * 32;
+  pl.ws_floats = (size_t)pl.split * E + 2 * (size_t)ceil_div(pl.split, kSlabChunk) * E;
+  return pl;
+}
+int launch_wgrad_wino32(const WgradParams& p, hipStream_t stream) {
+  const int ntiles = p.N * (p.H / 8) * (p.W / 32);
+  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+  if (p.alpha) {
+    auto kern = conv_wgrad_wino32_kernel<true>;
+    UNET_SET_DYN_LDS(kern, WQ_LDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WQ_LDS, stream, p, ntiles);
+  } else {
+    auto kern = conv_wgrad_wino32_kernel<false>;
+    UNET_SET_DYN_LDS(kern, WQ_LDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WQ_LDS, stream, p, ntiles);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_wino32");
+  return UNET_OK;
+}
+
 int launch_wgrad_wino(const WgradParams& p, hipStream_t stream) {
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   if (p.alpha) {
@@ -1883,6 +2160,10 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
     const size_t d = make_plan_wino(N, H, W, Cx, Cout).ws_floats;
     if (d > m) m = d;
   }
+  if (stride == 1 && Cx == 32 && Cout == 32 && H % 8 == 0 && W % 32 == 0) {   // (whatever the switch says)
+    const size_t d = make_plan_wino32(N, H, W).ws_floats;
+    if (d > m) m = d;
+  }
   return m * sizeof(float);
 }
 
@@ -1891,7 +2172,7 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
 extern "C" int unet_conv3x3_bwd_weight_is_winograd(int N, int H, int W, int Cx, int Cout,
                                                    int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || Cx <= 3 || Cout <= 0) return 0;
-  return (wgrad_wino_ok(N, H, W, Cx, Cout, stride) &&
+  return ((wgrad_wino_ok(N, H, W, Cx, Cout, stride) || wgrad_wino32_ok(N, H, W, Cx, Cout, stride)) &&
           wgrad_batch_chunk(N, H, W, Cx, Cout, stride) >= N) ? 1 : 0;
 }
 
@@ -1921,9 +2202,13 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   const bool wino = prec == 0 && !b16 && !center_only && Cx != 3 &&
                     wgrad_wino_ok(N, H, W, Cx, Cout, stride) &&
                     wgrad_batch_chunk(N, H, W, Cx, Cout, stride) >= N;
-  const WgradPlan pl = wino ? make_plan_wino(N, H, W, Cx, Cout)
-                            : make_plan(N, H, W, Cx, Cout, stride, pprec, wide);
-  const size_t need = (wino ? pl.ws_floats
+  // ... and the 32 -> 32 channel layers their own (one workgroup per CU keeps the whole M)
+  const bool wino32 = prec == 0 && !b16 && !center_only && wgrad_wino32_ok(N, H, W, Cx, Cout, stride) &&
+                      wgrad_batch_chunk(N, H, W, Cx, Cout, stride) >= N;
+  const WgradPlan pl = wino32 ? make_plan_wino32(N, H, W)
+                       : wino ? make_plan_wino(N, H, W, Cx, Cout)
+                              : make_plan(N, H, W, Cx, Cout, stride, pprec, wide);
+  const size_t need = ((wino || wino32) ? pl.ws_floats
                             : wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec, wide)) * sizeof(float);
   if (workspace_bytes < need || need == 0) {
     unet_set_error("conv3x3_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -1987,7 +2272,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int nslab = 0;
     for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
       const int nc = N - nb < nmax ? N - nb : nmax;
-      const WgradPlan pc = wino ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide);
+      const WgradPlan pc = (wino || wino32) ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide);
       WgradParams p{};
       p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
                                            (size_t)nb * H * W * Cx * es);
@@ -2004,7 +2289,8 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       p.alpha = act_alpha ? act_alpha + (size_t)nb * Cx : nullptr;
       p.beta = act_alpha ? act_beta + (size_t)nb * Cx : nullptr;
       p.slope = slope;
-      const int rc = wino ? launch_wgrad_wino(p, stream) : launch_wgrad_plan(p, pc, stride, prec, stream);
+      const int rc = wino32 ? launch_wgrad_wino32(p, stream)
+                     : wino ? launch_wgrad_wino(p, stream) : launch_wgrad_plan(p, pc, stride, prec, stream);
       if (rc != UNET_OK) return rc;
       nslab += pc.split * pc.sps;
     }
