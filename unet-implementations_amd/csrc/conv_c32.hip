@@ -559,6 +559,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
           z_dst[r * 128 + nb * 64] = m0 + (m1 + m2);
           z_dst[512 + r * 128 + nb * 64] = (m1 - m2) - m3;
         }
+      // the next unit's patch (in the registers since the top of this unit): its buffer was last
+      // read by this unit's transform, one barrier back, and is next read behind the one below
+      if (have_next) {   // uniform
+        if (nn != n_coef) {   // uniform: a new image - its coefficients (rare: once per image)
+          load_act(nn);
+          n_coef = nn;
+        }
+        store_patch();
+      }
       __syncthreads();
       // row pass: Y[a][b] = sum_i A^T[a][i] Z[i][b]
       float ov[8];
@@ -619,17 +628,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
           if (lh == 0) red[wave * 32 + li] = float2{s1, s2};
         }
       }
-      if (have_next) {   // uniform
-        if (nn != n_coef) {   // uniform: a new image - its coefficients (rare: once per image)
-          load_act(nn);
-          if (!FUSED && p.bs_partial) cf = bwd_coef(p, nn, li);
-          n_coef = nn;
-        }
-        store_patch();   // this unit's transform lies two barriers back
+      if constexpr (u == 3) {
+        // (the BSTATS coefficients of the next tile's image; the statistics above used this one's)
+        if (!FUSED && p.bs_partial && have_next && nn != n) cf = bwd_coef(p, nn, li);   // uniform
+        __syncthreads();   // the summaries in `red`; units 0-2 need no third barrier
       }
-      __syncthreads();
     });
-    if (summaries && tid < 32) {   // red is rewritten eleven barriers from now
+    if (summaries && tid < 32) {   // red is rewritten eight barriers from now
       const float2* rr = red + tid;
       const size_t dst = ((size_t)n * (tiles_x * tiles_y) + (y0 / C32_TH) * tiles_x + (x0 >> 5)) * 32 + tid;
       if (FUSED) {
