@@ -485,7 +485,10 @@ int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
  * switch rather than an entry point: 1 (default) = Winograd when the launch fills the chip (at
  * least 512 tiles of 8 x 32 pixels: the persistent kernel runs two workgroups per CU), 2 =
  * Winograd for every shape the kernel tiles, 0 = the direct kernel.  Returns the previous
- * setting.  (csrc/conv_c32.hip) */
+ * setting.  The weight gradient of the same layers (unet_conv_in_bwd_weight /
+ * unet_conv3x3_bwd_weight with Cx = Cout = 32, stride 1, H % 8 == 0, W % 32 == 0) follows the
+ * same switch: Winograd F(3x3,2x2) when there is an 8 x 32 tile for every CU (1) / always (2).
+ * (csrc/conv_c32.hip, csrc/conv_wgrad.hip) */
 int unet_set_c32_winograd(int on);
 /* 1 when a 3x3 fused forward / data gradient of this shape runs that Winograd form (for FLOP
  * accounting: it issues 16/36 of the direct kernel's matrix-core FLOPs). */

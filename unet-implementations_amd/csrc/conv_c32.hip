@@ -656,6 +656,343 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// conv3x3(cat(upsample2x(act(low)), act(skip))) -> 32 channels at full resolution (the first
+// convolution of the last decoder stage: 64 low-resolution + 32 skip channels; 982 us in the
+// direct patch kernel, the largest launch of the step) by the same recipe: K = 96 is THREE
+// register-resident chunks of 32 input channels.  One workgroup of FOUR waves per CU, so that a
+// wave owns 512 registers: wave w = row w of the xi grid keeps U of all three chunks for all 32
+// output columns (192 registers) and ONE accumulator set; per 4 x 16-pixel unit the chunks pass through the same patch and V
+// buffers (stage -> transform -> products, two barriers each), then one exchange + epilogue.
+// The patch of an up-sampled chunk is blended while it is staged: the four bilinear taps
+// (align_corners = False at exactly 2x: weights 0.25 / 0.75 by the parity of the pixel, indices
+// clamped at the border) are loaded and ACTIVATED first, then blended; pixels outside the image
+// stay zero (the zero padding of the convolution applies to the up-sampled tensor).
+// ---------------------------------------------------------------------------
+constexpr int WU_PASSES = Q_PASSES;                          // 4 passes of 256 threads
+constexpr size_t WU_LDS = Q_LDS;
+
+__global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParams p, int ntiles) {
+  constexpr int LDA = C32_LDA, PW = Q_PW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Pb = smem;
+  float* const Vs = smem + Q_PPIX * LDA;
+  float* const Zs = Vs + Q_V;
+  float2* const red = reinterpret_cast<float2*>(Zs + Q_Z);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row of the xi grid
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = p.Hin, W = p.Win, hl = H >> 1, wl = W >> 1;
+  const int tiles_x = W / C32_TW, tiles_y = H / C32_TH;
+  const int G = gridDim.x;
+  int t_first, t_stride, t_end;
+  if ((ntiles & 7) == 0 && (G & 7) == 0) {
+    const int per = ntiles >> 3, xcd = blockIdx.x & 7;
+    t_first = xcd * per + (blockIdx.x >> 3);
+    t_stride = G >> 3;
+    t_end = (xcd + 1) * per;
+  } else {
+    t_first = blockIdx.x; t_stride = G; t_end = ntiles;
+  }
+  if (t_first >= t_end) return;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src1), 0, (int)p.src1_bytes, 0x00020000);
+
+  // ---- U = G g G^T of the three chunks: row `wave` of the xi grid, both column halves ----
+  const int fn = lane & 15, fk = lane >> 4;
+  float ub[3][4][2][8];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ub[c][j][nb][k] = 0.f;
+  // (one tap at a time: unrolled, the compiler hoists all 216 weight loads above the arithmetic)
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
+    const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
+    const int u = (int)(e & 3u), v = (int)((e >> 2) & 3u);
+    const int wt = (int)(e >> 4);
+    const float gu = wino_g(wave, u);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float* wp = p.w + (size_t)wt * p.tap_stride + (size_t)(p.n_off + 16 * nb + fn) * 96 + 2 * fk;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2w w2 = *reinterpret_cast<const f32x2w*>(wp + 32 * c + 8 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float cf = gu * wino_g(j, v);
+            ub[c][j][nb][2 * q] = fmaf(cf, w2[0], ub[c][j][nb][2 * q]);
+            ub[c][j][nb][2 * q + 1] = fmaf(cf, w2[1], ub[c][j][nb][2 * q + 1]);
+          }
+        }
+    }
+  }
+
+  // ---- patch slots of this thread: pixel (prow, pcol) of the 6 x 18 patch, channel quad seg ----
+  int pp_lds[WU_PASSES], pp_rc[WU_PASSES];
+#pragma unroll
+  for (int i = 0; i < WU_PASSES; ++i) {
+    const int slot = tid + 256 * i;
+    const bool valid = slot < Q_SLOTS;
+    const int pix = valid ? slot >> 3 : 0;
+    const int prow = pix / PW, pcol = pix - prow * PW;
+    pp_lds[i] = pix * LDA + (slot & 7) * 4;
+    pp_rc[i] = valid ? (prow | (pcol << 8)) : (1 << 20);
+  }
+  const int seg4 = (tid & 7) * 4;
+  f32x4 pr[WU_PASSES][4];   // up chunk: the four taps; skip chunk: [i][0]
+  f32x4 ca, cb;
+  unsigned okm = 0;
+  auto tile_pos = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx = tile % tiles_x;
+    const int r = tile / tiles_x;
+    const int ty = r % tiles_y;
+    n = r / tiles_y; y0 = ty * C32_TH; x0 = tx * C32_TW;
+  };
+  // chunk c of the unit at (n, yu, xu): loads into the registers (yu, xu are multiples of 4 / 16:
+  // the parity of a slot's pixel, hence its blend weights, never changes)
+  auto load_chunk = [&](int c, int n, int yu, int xu) {   // c uniform
+    okm = 0;
+    if (c < 2) {
+#pragma unroll
+      for (int i = 0; i < WU_PASSES; ++i) {
+        const int Y = yu - 1 + (pp_rc[i] & 0xff), X = xu - 1 + (pp_rc[i] >> 8);
+        const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        okm |= (ok ? 1u : 0u) << i;
+        int ylo = ((Y + 1) >> 1) - 1, xlo = ((X + 1) >> 1) - 1;
+        int yhi = ylo + 1, xhi = xlo + 1;
+        ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
+        yhi = yhi > hl - 1 ? hl - 1 : yhi; xhi = xhi > wl - 1 ? wl - 1 : xhi;
+        const int ch = (32 * c + seg4) * 4;
+        const unsigned o00 = (unsigned)((((n * hl + ylo) * wl + xlo) * 64) * 4 + ch);
+        const unsigned o01 = (unsigned)((((n * hl + ylo) * wl + xhi) * 64) * 4 + ch);
+        const unsigned o10 = (unsigned)((((n * hl + yhi) * wl + xlo) * 64) * 4 + ch);
+        const unsigned o11 = (unsigned)((((n * hl + yhi) * wl + xhi) * 64) * 4 + ch);
+        pr[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o00 : 0x80000000u, 0, 0));
+        pr[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o01 : 0x80000000u, 0, 0));
+        pr[i][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o10 : 0x80000000u, 0, 0));
+        pr[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o11 : 0x80000000u, 0, 0));
+      }
+      const size_t o = (size_t)n * 64 + 32 * c + seg4;
+      ca = *reinterpret_cast<const f32x4*>(p.act0_alpha + o);
+      cb = *reinterpret_cast<const f32x4*>(p.act0_beta + o);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WU_PASSES; ++i) {
+        const int Y = yu - 1 + (pp_rc[i] & 0xff), X = xu - 1 + (pp_rc[i] >> 8);
+        const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+        okm |= (ok ? 1u : 0u) << i;
+        const unsigned off = (unsigned)((((n * H + Y) * W + X) * 32 + seg4) * 4);
+        pr[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? off : 0x80000000u, 0, 0));
+      }
+      const size_t o = (size_t)n * 32 + seg4;
+      ca = *reinterpret_cast<const f32x4*>(p.act1_alpha + o);
+      cb = *reinterpret_cast<const f32x4*>(p.act1_beta + o);
+    }
+  };
+  auto store_chunk = [&](int c) {   // c uniform: activate (, blend), registers -> LDS patch
+#pragma unroll
+    for (int i = 0; i < WU_PASSES; ++i) {
+      const bool ok = (okm >> i) & 1u;
+      f32x4 v;
+      if (c < 2) {
+        // odd pixel 2k+1 sits at source 0.25 past k: taps (k, k+1) weigh (0.75, 0.25); even pixel
+        // 2k at 0.25 before k: taps (k-1, k) weigh (0.25, 0.75).  Patch row prow is image row
+        // yu - 1 + prow with yu even: odd image row <=> even prow.
+        const float wy1 = ((pp_rc[i] & 1) == 0) ? 0.25f : 0.75f, wy0 = 1.f - wy1;
+        const float wx1 = (((pp_rc[i] >> 8) & 1) == 0) ? 0.25f : 0.75f, wx0 = 1.f - wx1;
+        const f32x4 p00 = act4(pr[i][0], ca, cb, p.slope, ok), p01 = act4(pr[i][1], ca, cb, p.slope, ok);
+        const f32x4 p10 = act4(pr[i][2], ca, cb, p.slope, ok), p11 = act4(pr[i][3], ca, cb, p.slope, ok);
+        v = (p00 * wx0 + p01 * wx1) * wy0 + (p10 * wx0 + p11 * wx1) * wy1;
+      } else {
+        v = act4(pr[i][0], ca, cb, p.slope, ok);
+      }
+      if (256 * (i + 1) <= Q_SLOTS || tid + 256 * i < Q_SLOTS)
+        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = v;
+    }
+  };
+
+  // ---- input transform, products, exchange: the mappings of conv_wino32q_kernel ----
+  const int cp = tid & 15, tt = tid >> 4;
+  const int t_ty = (tt & 3) >> 1, t_tx = 4 * (tt & 1) + (tt >> 2);
+  const unsigned t_srca = lds_addr(Pb + ((2 * t_ty) * PW + 2 * t_tx) * LDA + 2 * cp);
+  float* const t_dst = Vs + tt * W32_VP + 2 * cp;
+  auto transform = [&]() {
+    f32x2v d[4][4];
+    for_range_c<0, 16>([&](auto ic) {
+      constexpr int r = decltype(ic)::value / 4, c = decltype(ic)::value % 4;
+      d[r][c] = lds_rd64<((r * PW + c) * LDA) * 4>(t_srca);
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_wait<0>(d[r][0], d[r][1], d[r][2], d[r][3]);
+    f32x2v t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t[0][c] = d[0][c] - d[2][c];
+      t[1][c] = d[1][c] + d[2][c];
+      t[2][c] = d[2][c] - d[1][c];
+      t[3][c] = d[1][c] - d[3][c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float* dst = t_dst + (4 * a) * (16 * W32_VP);
+      *reinterpret_cast<f32x2v*>(dst) = t[a][0] - t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 16 * W32_VP) = t[a][1] + t[a][2];
+      *reinterpret_cast<f32x2v*>(dst + 2 * 16 * W32_VP) = t[a][2] - t[a][1];
+      *reinterpret_cast<f32x2v*>(dst + 3 * 16 * W32_VP) = t[a][1] - t[a][3];
+    }
+  };
+  const float* const a_src = Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk;
+  float* const z_dst = Zs + (wave * 2) * 512 + lane;
+  const float* const z_src = Zs + wave * 128 + (li >> 4) * 64 + 32 * lh + (li & 15);
+  const int o_ty = wave >> 1, o_tx0 = 4 * (wave & 1) + 2 * lh;
+  const float bv = p.bias ? p.bias[li] : 0.f;
+
+  {
+    int n, y0, x0;
+    tile_pos(t_first, n, y0, x0);
+    load_chunk(0, n, y0, x0);
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  for (int tile = t_first; tile < t_end; tile += t_stride) {
+    const int nxt = tile + t_stride;
+    const bool more = nxt < t_end;
+    int n, y0, x0;
+    tile_pos(tile, n, y0, x0);
+    // (a runtime loop over the four units: unrolled, the body's twelve chunk steps cost registers)
+    float pm = 0.f, pq = 0.f, hm = 0.f, hq = 0.f;   // running (mean, M2): pair of units, half tile
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+      const int yu = y0 + 4 * (u >> 1), xu = x0 + 16 * (u & 1);
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[j][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for_range_c<0, 3>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        // the next chunk (of this unit, of the next unit, of the next tile): its loads go out now
+        bool have_next = true;
+        if constexpr (c < 2) {
+          load_chunk(c + 1, n, yu, xu);
+        } else if (u < 3) {   // uniform
+          load_chunk(0, n, y0 + 4 * ((u + 1) >> 1), x0 + 16 * ((u + 1) & 1));
+        } else {
+          have_next = more;
+          if (more) {   // uniform
+            int nn, ny, nx;
+            tile_pos(nxt, nn, ny, nx);
+            load_chunk(0, nn, ny, nx);
+          }
+        }
+        transform();
+        __syncthreads();
+        f32x2w af[2][4];
+        auto frag = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            af[q & 1][j] = *reinterpret_cast<const f32x2w*>(a_src + j * 16 * W32_VP + 8 * q);
+        };
+        frag(std::integral_constant<int, 0>{});
+        for_range_c<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          if constexpr (q + 1 < 4) frag(std::integral_constant<int, q + 1>{});
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb)
+                acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q & 1][j][e], ub[c][j][nb][2 * q + e],
+                                                                  acc[j][nb], 0, 0, 0);
+        });
+        if constexpr (c == 2) {   // column pass of A^T M A over this wave's row of xi
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
+              z_dst[r * 128 + nb * 64] = m0 + (m1 + m2);
+              z_dst[512 + r * 128 + nb * 64] = (m1 - m2) - m3;
+            }
+        }
+        if (have_next) store_chunk(c < 2 ? c + 1 : 0);   // uniform
+        __syncthreads();
+      });
+      // row pass: Y[a][b] = sum_i A^T[a][i] Z[i][b]
+      float ov[8];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float z[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) z[i][b] = z_src[e * 16 + (i * 2 + b) * 512];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          ov[4 * e + b] = z[0][b] + (z[1][b] + z[2][b]) + bv;
+          ov[4 * e + 2 + b] = (z[1][b] - z[2][b]) - z[3][b] + bv;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = k >> 2, a = (k >> 1) & 1, b = k & 1;
+        const size_t pix = ((size_t)n * H + yu + 2 * o_ty + a) * W + xu + 2 * (o_tx0 + e) + b;
+        p.out[pix * p.ldo + li] = ov[k];
+      }
+      if (p.stats) {   // uniform: (mean, M2) of this unit's 8 values
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sm += ov[k];
+        const float mean = sm * 0.125f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float dd = ov[k] - mean; m2 = fmaf(dd, dd, m2); }
+        // equal-count merges: units (0, 1) and (2, 3) into pairs, then the two pairs
+        if ((u & 1) == 0) { pm = mean; pq = m2; }   // uniform
+        else {
+          wf_merge_eq(pm, pq, mean, m2, 8.f);
+          if (u == 1) { hm = pm; hq = pq; }
+          else wf_merge_eq(hm, hq, pm, pq, 16.f);
+        }
+      }
+    }
+    if (p.stats) {   // uniform
+      const float mb = __shfl_xor(hm, 32, 64), qb = __shfl_xor(hq, 32, 64);
+      wf_merge_eq(hm, hq, mb, qb, 32.f);
+      if (lh == 0) red[wave * 32 + li] = float2{hm, hq};
+      __syncthreads();
+      if (tid < 32) {
+        const float2* rr = red + tid;
+        const size_t dst = ((size_t)n * (tiles_x * tiles_y) + (y0 / C32_TH) * tiles_x + (x0 >> 5)) * 32 + tid;
+        float mean[2], m2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          mean[k] = rr[(2 * k) * 32].x; m2[k] = rr[(2 * k) * 32].y;
+          wf_merge_eq(mean[k], m2[k], rr[(2 * k + 1) * 32].x, rr[(2 * k + 1) * 32].y, 64.f);
+        }
+        wf_merge_eq(mean[0], m2[0], mean[1], m2[1], 128.f);
+        p.stats[dst] = float2{mean[0], m2[0]};
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // process-wide choice between the two forms of these layers (unet_set_c32_winograd)
@@ -737,3 +1074,25 @@ extern "C" int unet_conv_c32_is_winograd(int N, int H, int W, int Cin, int Cout,
     return 0;
   return f == 2 || (long long)N * (H / 8) * (W / 32) >= 512;
 }
+
+namespace unet_conv {
+// (64 up-sampled + 32 skip) -> 32 channels, both sources activated on load, whole 8 x 32 tiles,
+// a tile for every CU: the Winograd form of launch_patch_up<32, ...> (conv_patch.hip)
+bool wino_up32_applicable(const IgemmParams& p) {
+  const int f = c32_winograd_flag();
+  if (!(f && p.C0 == 64 && p.C1 == 32 && p.Ncols == 32 && p.ntaps == 9 && p.Hin % 8 == 0 &&
+        p.Win % 32 == 0 && p.act0_alpha && p.act1_alpha && p.ldo == 32 && !p.accumulate &&
+        (long long)p.N * p.Hin * p.Win * 128 < (1LL << 31)))
+    return false;
+  return f == 2 || (long long)p.N * (p.Hin / 8) * (p.Win / 32) >= 256;
+}
+int launch_wino_up32(const IgemmParams& p, hipStream_t stream) {
+  const int ntiles = p.N * (p.Hin / C32_TH) * (p.Win / C32_TW);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  auto kern = conv_wino_up32_kernel;
+  UNET_SET_DYN_LDS(kern, WU_LDS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), WU_LDS, stream, p, ntiles);
+  UNET_CHECK_LAUNCH("conv_wino_up32");
+  return UNET_OK;
+}
+}  // namespace unet_conv

@@ -249,6 +249,8 @@ int launch_patch_up_auto(const IgemmParams& p, hipStream_t stream, int* stats_px
 int& c32_winograd_flag();                                      // unet_set_c32_winograd, conv_c32.hip
 bool c32_applicable(const IgemmParams& p);                    // 32 -> 32 channels, conv_c32.hip
 int launch_c32(const IgemmParams& p, int fused, hipStream_t stream, int* tile_px);
+bool wino_up32_applicable(const IgemmParams& p);              // (64 up + 32) -> 32, conv_c32.hip
+int launch_wino_up32(const IgemmParams& p, hipStream_t stream);
 bool patch_s2_applicable(const IgemmParams& p);               // stride-2 forward, conv_patch.hip
 int launch_patch_s2_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
 int launch_dgrad_s2_patch_auto(const IgemmParams& p, hipStream_t stream, int* bs_tiles_out);

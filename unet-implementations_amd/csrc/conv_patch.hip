@@ -2082,6 +2082,10 @@ int launch_patch_up_auto(const IgemmParams& p0, hipStream_t stream, int* stats_p
     *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
     return launch_patch_up<64, 64, 32, 4>(p, stream);
   }
+  if (wino_up32_applicable(p)) {   // conv_c32.hip: K = 96 as three register-resident Winograd chunks
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_wino_up32(p, stream);
+  }
   if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 512) {
     *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
     return launch_patch_up<32, 64, 32, 8>(p, stream);
