@@ -493,6 +493,11 @@ int unet_set_c32_winograd(int on);
 /* 1 when a 3x3 fused forward / data gradient of this shape runs that Winograd form (for FLOP
  * accounting: it issues 16/36 of the direct kernel's matrix-core FLOPs). */
 int unet_conv_c32_is_winograd(int N, int H, int W, int Cin, int Cout, int stride);
+/* The same switch covers unet_conv_up_in_fwd of the last decoder stage, (64 up-sampled + 32 skip)
+ * -> 32 channels with both sources activated on load: K = 96 as three register-resident Winograd
+ * chunks, the bilinear up-sampling folded into the input transform (1: with an 8 x 32 tile for
+ * every CU, 2: every shape with H % 8 == 0 and W % 32 == 0).  1 when this shape takes it: */
+int unet_conv_up_c32_is_winograd(int N, int H, int W, int C0, int C1, int Cout);
 size_t unet_wino_weight_floats(int Cout, int Cin);
 int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin,
                            unet_stream_t stream);

@@ -758,6 +758,48 @@ def test_conv_up_in_fwd_winograd(ua, case):
     check(st[2], st2[2], 5e-5, "alpha")
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64), (1, 8, 32), (3, 40, 96), (2, 256, 256)])
+def test_conv_up_in_fwd_c32_winograd(ua, case):
+    """The last decoder stage's first convolution, (64 up-sampled + 32 skip) -> 32 channels, on
+    its own Winograd kernel (csrc/conv_c32.hip: conv_wino_up32_kernel - three register-resident
+    chunks, the bilinear up-sampling folded into the input transform of a 3 x 3 low-resolution
+    window) against F.interpolate + torch.cat + F.conv2d in fp64 and against the direct
+    up-sampling-loader kernel: one-tile images (every border rule at once), odd tile counts."""
+    N, H, W = case
+    C0, C1, Cout = 64, 32, 32
+    low = rnd(N, C0, H // 2, W // 2, seed=1)
+    skip = rnd(N, C1, H, W, seed=2)
+    c0, c1 = coeffs(N, C0, 10), coeffs(N, C1, 20)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=(2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma, beta = rnd(Cout, seed=5) * 0.2 + 1.0, rnd(Cout, seed=6) * 0.2
+    parts = [F.interpolate(act_ref(low, *c0), scale_factor=2, mode="bilinear", align_corners=False),
+             act_ref(skip, *c1)]
+    y_ref = F.conv2d(torch.cat(parts, 1), w.double(), b.double(), padding=1)
+    wf, _ = ua.ops.pack_conv3x3_weights(w.to(DEV), want_wd=False)
+    args = (make_src(ua, low, c0), make_src(ua, skip, c1), SLOPE, wf, b.to(DEV), gamma.to(DEV),
+            beta.to(DEV), 1e-5, None)
+    lib = ua._lib.lib()
+    ua.ops.set_c32_winograd("always")
+    try:
+        assert lib.unet_conv_up_c32_is_winograd(N, H, W, C0, C1, Cout) == 1
+        y, st = ua.ops.conv_up_in_fwd(*args)
+    finally:
+        ua.ops.set_c32_winograd(True)
+    assert lib.unet_conv_up_c32_is_winograd(N, H, W, C0, C1, Cout) == int(N * (H // 8) * (W // 32) >= 256)
+    check(from_nhwc(y), y_ref, 2e-5, "y (Winograd, folded up-sampling)")
+    assert (st[0].cpu().double() - y_ref.mean(dim=(2, 3))).abs().max() <= 2e-5 * (y_ref.abs().max() + 1)
+    check(st[1].cpu(), 1.0 / torch.sqrt(y_ref.var(dim=(2, 3), unbiased=False) + 1e-5), 5e-5, "rstd")
+    if ua.ops.conv_up_in_fwd_supported(args[0], args[1], Cout):   # the direct kernel tiles it too
+        ua.ops.set_c32_winograd(False)
+        try:
+            y2, st2 = ua.ops.conv_up_in_fwd(*args)
+        finally:
+            ua.ops.set_c32_winograd(True)
+        check(y, y2, 2e-5, "Winograd vs direct up-sampling loader")
+        check(st[2], st2[2], 5e-5, "alpha")
+
+
 # --------------------------------------------------------------------------- reductions from the producer
 def _next_norm(ua, N, C, H, W, seed):
     """A layer l as the producer of dL/da_l sees it: raw output, statistics, affine, mask."""

@@ -111,6 +111,7 @@ SIGNATURES = {
     "unet_conv_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_set_c32_winograd": (_i, [_i]),
     "unet_conv_c32_is_winograd": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_conv_up_c32_is_winograd": (_i, [_i, _i, _i, _i, _i, _i]),
     "unet_wino_weight_floats": (_sz, [_i, _i]),
     "unet_pack_wino_weights": (_i, [_p, _p, _p, _i, _i, _p]),
     "unet_pack_wino_weights_batched": (_i, [_p, _i, _i, _p]),

@@ -665,13 +665,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
 // wave owns 512 registers: wave w = row w of the xi grid keeps U of all three chunks for all 32
 // output columns (192 registers) and ONE accumulator set; per 4 x 16-pixel unit the chunks pass through the same patch and V
 // buffers (stage -> transform -> products, two barriers each), then one exchange + epilogue.
-// The patch of an up-sampled chunk is blended while it is staged: the four bilinear taps
-// (align_corners = False at exactly 2x: weights 0.25 / 0.75 by the parity of the pixel, indices
-// clamped at the border) are loaded and ACTIVATED first, then blended; pixels outside the image
-// stay zero (the zero padding of the convolution applies to the up-sampled tensor).
+// An up-sampled chunk never exists at full resolution: bilinear up-sampling (align_corners =
+// False at exactly 2x: weights 0.25 / 0.75 by the parity of the pixel, indices clamped at the
+// border) is linear, so it is folded into the input transform - the loader stages the ACTIVATED
+// 4 x 10 low-resolution pixels under the unit and the transform reads a 3 x 3 window of them
+// (see transform_up; the zero padding of the convolution applies to the up-sampled tensor: the
+// interpolated rows / columns outside the image are zero).  (A first version blended the four
+// taps per patch pixel in the loader: 16 loads and ~400 VALU instructions per thread and chunk,
+// 1062 us - hardly better than the direct kernel.)
 // ---------------------------------------------------------------------------
 constexpr int WU_PASSES = Q_PASSES;                          // 4 passes of 256 threads
-constexpr size_t WU_LDS = Q_LDS;
+constexpr int WU_LSLOTS = 4 * 10 * 8;                        // f32x4 slots of the low-resolution patch
+constexpr size_t WU_LDS = Q_LDS + 4 * 10 * C32_LDA * sizeof(float);
 
 __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParams p, int ntiles) {
   constexpr int LDA = C32_LDA, PW = Q_PW;
@@ -680,6 +685,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
   float* const Vs = smem + Q_PPIX * LDA;
   float* const Zs = Vs + Q_V;
   float2* const red = reinterpret_cast<float2*>(Zs + Q_Z);
+  float* const Lb = reinterpret_cast<float*>(red + 4 * 32);   // low-resolution patch: 4 x 10 pixels
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row of the xi grid
@@ -740,7 +746,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
     }
   }
 
-  // ---- patch slots of this thread: pixel (prow, pcol) of the 6 x 18 patch, channel quad seg ----
+  // ---- staging slots of this thread: skip chunk = the 6 x 18 patch (4 passes), up-sampled chunk
+  //      = the 4 x 10 LOW-resolution pixels under it (2 passes); channel quad seg ----
   int pp_lds[WU_PASSES], pp_rc[WU_PASSES];
 #pragma unroll
   for (int i = 0; i < WU_PASSES; ++i) {
@@ -751,8 +758,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
     pp_lds[i] = pix * LDA + (slot & 7) * 4;
     pp_rc[i] = valid ? (prow | (pcol << 8)) : (1 << 20);
   }
+  int lp_lds[2], lp_rc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = tid + 256 * i;
+    const bool valid = slot < WU_LSLOTS;
+    const int pix = valid ? slot >> 3 : 0;
+    const int lr = pix / 10, lc = pix - lr * 10;
+    lp_lds[i] = pix * LDA + (slot & 7) * 4;
+    lp_rc[i] = valid ? (lr | (lc << 8)) : (1 << 20);
+  }
   const int seg4 = (tid & 7) * 4;
-  f32x4 pr[WU_PASSES][4];   // up chunk: the four taps; skip chunk: [i][0]
+  f32x4 pr[WU_PASSES];
   f32x4 ca, cb;
   unsigned okm = 0;
   auto tile_pos = [&](int tile, int& n, int& y0, int& x0) {
@@ -761,29 +778,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
     const int ty = r % tiles_y;
     n = r / tiles_y; y0 = ty * C32_TH; x0 = tx * C32_TW;
   };
-  // chunk c of the unit at (n, yu, xu): loads into the registers (yu, xu are multiples of 4 / 16:
-  // the parity of a slot's pixel, hence its blend weights, never changes)
+  // chunk c of the unit at (n, yu, xu): loads into the registers
   auto load_chunk = [&](int c, int n, int yu, int xu) {   // c uniform
     okm = 0;
-    if (c < 2) {
+    if (c < 2) {   // low-resolution rows yu / 2 - 1 .. + 2, columns xu / 2 - 1 .. + 8
 #pragma unroll
-      for (int i = 0; i < WU_PASSES; ++i) {
-        const int Y = yu - 1 + (pp_rc[i] & 0xff), X = xu - 1 + (pp_rc[i] >> 8);
-        const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+      for (int i = 0; i < 2; ++i) {
+        const int Y = (yu >> 1) - 1 + (lp_rc[i] & 0xff), X = (xu >> 1) - 1 + (lp_rc[i] >> 8);
+        const bool ok = (unsigned)Y < (unsigned)hl && (unsigned)X < (unsigned)wl;
         okm |= (ok ? 1u : 0u) << i;
-        int ylo = ((Y + 1) >> 1) - 1, xlo = ((X + 1) >> 1) - 1;
-        int yhi = ylo + 1, xhi = xlo + 1;
-        ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
-        yhi = yhi > hl - 1 ? hl - 1 : yhi; xhi = xhi > wl - 1 ? wl - 1 : xhi;
-        const int ch = (32 * c + seg4) * 4;
-        const unsigned o00 = (unsigned)((((n * hl + ylo) * wl + xlo) * 64) * 4 + ch);
-        const unsigned o01 = (unsigned)((((n * hl + ylo) * wl + xhi) * 64) * 4 + ch);
-        const unsigned o10 = (unsigned)((((n * hl + yhi) * wl + xlo) * 64) * 4 + ch);
-        const unsigned o11 = (unsigned)((((n * hl + yhi) * wl + xhi) * 64) * 4 + ch);
-        pr[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o00 : 0x80000000u, 0, 0));
-        pr[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o01 : 0x80000000u, 0, 0));
-        pr[i][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o10 : 0x80000000u, 0, 0));
-        pr[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? o11 : 0x80000000u, 0, 0));
+        const unsigned off = (unsigned)((((n * hl + Y) * wl + X) * 64 + 32 * c + seg4) * 4);
+        pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? off : 0x80000000u, 0, 0));
       }
       const size_t o = (size_t)n * 64 + 32 * c + seg4;
       ca = *reinterpret_cast<const f32x4*>(p.act0_alpha + o);
@@ -795,32 +800,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
         const bool ok = (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
         okm |= (ok ? 1u : 0u) << i;
         const unsigned off = (unsigned)((((n * H + Y) * W + X) * 32 + seg4) * 4);
-        pr[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? off : 0x80000000u, 0, 0));
+        pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? off : 0x80000000u, 0, 0));
       }
       const size_t o = (size_t)n * 32 + seg4;
       ca = *reinterpret_cast<const f32x4*>(p.act1_alpha + o);
       cb = *reinterpret_cast<const f32x4*>(p.act1_beta + o);
     }
   };
-  auto store_chunk = [&](int c) {   // c uniform: activate (, blend), registers -> LDS patch
+  auto store_chunk = [&](int c) {   // c uniform: activate, registers -> LDS
+    if (c < 2) {
 #pragma unroll
-    for (int i = 0; i < WU_PASSES; ++i) {
-      const bool ok = (okm >> i) & 1u;
-      f32x4 v;
-      if (c < 2) {
-        // odd pixel 2k+1 sits at source 0.25 past k: taps (k, k+1) weigh (0.75, 0.25); even pixel
-        // 2k at 0.25 before k: taps (k-1, k) weigh (0.25, 0.75).  Patch row prow is image row
-        // yu - 1 + prow with yu even: odd image row <=> even prow.
-        const float wy1 = ((pp_rc[i] & 1) == 0) ? 0.25f : 0.75f, wy0 = 1.f - wy1;
-        const float wx1 = (((pp_rc[i] >> 8) & 1) == 0) ? 0.25f : 0.75f, wx0 = 1.f - wx1;
-        const f32x4 p00 = act4(pr[i][0], ca, cb, p.slope, ok), p01 = act4(pr[i][1], ca, cb, p.slope, ok);
-        const f32x4 p10 = act4(pr[i][2], ca, cb, p.slope, ok), p11 = act4(pr[i][3], ca, cb, p.slope, ok);
-        v = (p00 * wx0 + p01 * wx1) * wy0 + (p10 * wx0 + p11 * wx1) * wy1;
-      } else {
-        v = act4(pr[i][0], ca, cb, p.slope, ok);
-      }
-      if (256 * (i + 1) <= Q_SLOTS || tid + 256 * i < Q_SLOTS)
-        *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = v;
+      for (int i = 0; i < 2; ++i)
+        if (tid + 256 * i < WU_LSLOTS)
+          *reinterpret_cast<f32x4*>(Lb + lp_lds[i]) = act4(pr[i], ca, cb, p.slope, (okm >> i) & 1u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WU_PASSES; ++i)
+        if (256 * (i + 1) <= Q_SLOTS || tid + 256 * i < Q_SLOTS)
+          *reinterpret_cast<f32x4*>(Pb + pp_lds[i]) = act4(pr[i], ca, cb, p.slope, (okm >> i) & 1u);
     }
   };
 
@@ -852,6 +849,51 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
       *reinterpret_cast<f32x2v*>(dst + 16 * W32_VP) = t[a][1] + t[a][2];
       *reinterpret_cast<f32x2v*>(dst + 2 * 16 * W32_VP) = t[a][2] - t[a][1];
       *reinterpret_cast<f32x2v*>(dst + 3 * 16 * W32_VP) = t[a][1] - t[a][3];
+    }
+  };
+  // The same for an up-sampled chunk, WITHOUT building the up-sampled patch: d = Ry L Rx^T with L
+  // the 3 x 3 low-resolution window under the tile (rows R - 1 .. R + 1 for output rows 2R, 2R+1)
+  // and Ry / Rx the interpolation of its four input rows / columns 2R - 1 .. 2R + 2:
+  //   2R-1: 0.75 L0 + 0.25 L1 (zero when outside the image: the convolution's padding)
+  //   2R  : 0.25 L0 + 0.75 L1 (L1 alone in the first row: the index clamps)
+  //   2R+1: 0.75 L1 + 0.25 L2 (L1 alone in the last row)
+  //   2R+2: 0.25 L1 + 0.75 L2 (zero when outside the image)
+  // so V = B^T (Ry L Rx^T) B costs 9 reads instead of 16 and no blending in the loader.
+  const unsigned l_srca = lds_addr(Lb + (t_ty * 10 + t_tx) * LDA + 2 * cp);
+  auto transform_up = [&](int yu, int xu) {
+    const int R = (yu >> 1) + t_ty, C = (xu >> 1) + t_tx;
+    const bool fr = R == 0, lr = R == hl - 1, fc = C == 0, lc = C == wl - 1;
+    // coefficient pairs of the four interpolated rows / columns
+    const float ra0 = fr ? 0.f : 0.75f, rb0 = fr ? 0.f : 0.25f, ra1 = fr ? 0.f : 0.25f, rb1 = fr ? 1.f : 0.75f;
+    const float ra2 = lr ? 1.f : 0.75f, rb2 = lr ? 0.f : 0.25f, ra3 = lr ? 0.f : 0.25f, rb3 = lr ? 0.f : 0.75f;
+    const float ka0 = fc ? 0.f : 0.75f, kb0 = fc ? 0.f : 0.25f, ka1 = fc ? 0.f : 0.25f, kb1 = fc ? 1.f : 0.75f;
+    const float ka2 = lc ? 1.f : 0.75f, kb2 = lc ? 0.f : 0.25f, ka3 = lc ? 0.f : 0.25f, kb3 = lc ? 0.f : 0.75f;
+    f32x2v L[3][3];
+    for_range_c<0, 9>([&](auto ic) {
+      constexpr int r = decltype(ic)::value / 3, c = decltype(ic)::value % 3;
+      L[r][c] = lds_rd64<((r * 10 + c) * LDA) * 4>(l_srca);
+    });
+#pragma unroll
+    for (int r = 0; r < 3; ++r) lds_wait<0>(L[r][0], L[r][1], L[r][2]);
+    f32x2v t[4][3];   // B^T Ry L
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x2v u0 = L[0][c] * ra0 + L[1][c] * rb0, u1 = L[0][c] * ra1 + L[1][c] * rb1;
+      const f32x2v u2 = L[1][c] * ra2 + L[2][c] * rb2, u3 = L[1][c] * ra3 + L[2][c] * rb3;
+      t[0][c] = u0 - u2;
+      t[1][c] = u1 + u2;
+      t[2][c] = u2 - u1;
+      t[3][c] = u1 - u3;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const f32x2v w0 = t[a][0] * ka0 + t[a][1] * kb0, w1 = t[a][0] * ka1 + t[a][1] * kb1;
+      const f32x2v w2 = t[a][1] * ka2 + t[a][2] * kb2, w3 = t[a][1] * ka3 + t[a][2] * kb3;
+      float* dst = t_dst + (4 * a) * (16 * W32_VP);
+      *reinterpret_cast<f32x2v*>(dst) = w0 - w2;
+      *reinterpret_cast<f32x2v*>(dst + 16 * W32_VP) = w1 + w2;
+      *reinterpret_cast<f32x2v*>(dst + 2 * 16 * W32_VP) = w2 - w1;
+      *reinterpret_cast<f32x2v*>(dst + 3 * 16 * W32_VP) = w1 - w3;
     }
   };
   const float* const a_src = Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk;
@@ -899,7 +941,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
             load_chunk(0, nn, ny, nx);
           }
         }
-        transform();
+        if constexpr (c < 2) transform_up(yu, xu); else transform();
         __syncthreads();
         f32x2w af[2][4];
         auto frag = [&](auto qc) {

@@ -1958,7 +1958,19 @@ extern "C" int unet_conv_up_in_fwd_supported(int N, int H, int W, int C0, int C1
   if (Cout % 128 == 0 && mt * (Cout / 128) >= 512) return 1;
   if (Cout % 64 == 0 && mt * (Cout / 64) >= 512) return 1;
   if (Cout == 32 && H % 8 == 0 && M / 256 >= 512) return 1;
+  // (the Winograd kernel of the (64 + 32) -> 32 layer forced for every shape: tests)
+  if (Cout == 32 && C0 == 64 && C1 == 32 && H % 8 == 0 && c32_winograd_flag() == 2) return 1;
   return 0;
+}
+
+// 1 when unet_conv_up_in_fwd runs this shape (both sources activated on load) on the Winograd
+// kernel of csrc/conv_c32.hip (conv_wino_up32_kernel): 16/36 of the direct matrix FLOPs
+extern "C" int unet_conv_up_c32_is_winograd(int N, int H, int W, int C0, int C1, int Cout) {
+  const int f = c32_winograd_flag();
+  if (!(f && N > 0 && C0 == 64 && C1 == 32 && Cout == 32 && H > 0 && W > 0 && H % 8 == 0 &&
+        W % 32 == 0 && (long long)N * H * W * 128 < (1LL << 31)))
+    return 0;
+  return f == 2 || (long long)N * (H / 8) * (W / 32) >= 256;
 }
 
 extern "C" int unet_conv_up_in_fwd(const unet_act_src* low, const unet_act_src* skip, float slope,

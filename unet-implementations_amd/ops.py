@@ -720,7 +720,9 @@ def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask, wu=None):
                                         ws.numel(), ctypes.byref(px), N, H, W, Cout, _stream()))
     if t0 is not None:
         alg = 2.0 * N * H * W * 9 * (C0 + C1) * Cout
-        _timer.end("conv_igemm", alg, 1, t0, executed=alg * 16.0 / 36.0 if wu is not None else None)
+        wino = wu is not None or (low.alpha is not None and skip.alpha is not None and bool(
+            lib().unet_conv_up_c32_is_winograd(N, H, W, C0, C1, Cout)))
+        _timer.end("conv_igemm", alg, 1, t0, executed=alg * 16.0 / 36.0 if wino else None)
     check(lib().unet_conv_in_stats_finalize(_ptr(y), _ptr(ws), ws.numel(), px.value, _ptr(gamma),
                                             _ptr(beta), eps, _ptr(mask), _ptr(st[0]), _ptr(st[1]),
                                             _ptr(st[2]), _ptr(st[3]), N, H * W, Cout, _stream()))
