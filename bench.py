@@ -87,7 +87,7 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
         "algorithmic": ach, "algorithmic_frac": ach / peak,
         "traffic": traffic, "traffic_source": src,
         "kernel": "convolution forward + data-gradient group ("
-                  + {"fp32": "conv_wino_kernel, conv_wino32q_kernel (Winograd F(2x2,3x3): 16/36 of the "
+                  + {"fp32": "conv_wino_kernel, conv_wino32q_kernel, conv_wino_up32_kernel (Winograd F(2x2,3x3): 16/36 of the "
                              "direct MFMA FLOPs), conv_patch_f32_kernel, conv_patch_up_kernel, "
                              "conv_patch_s2_kernel, conv_igemm_kernel, conv_dgrad_s2_patch_kernel",
                      "bf16": "conv_patch_b16_kernel, conv_igemm_bf16_kernel on bf16 tensors",

@@ -10,6 +10,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find $out/pmc_${name}_$c -name "*counter_collection.csv" | head -1)
   # keep only the rows of the convolution group (the full CSV is large)
   head -1 "$f" > $out/${name}_$c.csv
-  grep -E "conv_wino_kernel|conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_wino32q_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel" "$f" >> $out/${name}_$c.csv
+  grep -E "conv_wino_kernel|conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_wino32q_kernel|conv_wino_up32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel" "$f" >> $out/${name}_$c.csv
   rm -rf $out/pmc_${name}_$c
 done
