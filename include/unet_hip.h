@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 5
+#define UNET_ABI_VERSION 6
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -498,6 +498,21 @@ int unet_conv_c32_is_winograd(int N, int H, int W, int Cin, int Cout, int stride
  * chunks, the bilinear up-sampling folded into the input transform (1: with an 8 x 32 tile for
  * every CU, 2: every shape with H % 8 == 0 and W % 32 == 0).  1 when this shape takes it: */
 int unet_conv_up_c32_is_winograd(int N, int H, int W, int C0, int C1, int Cout);
+/* unet_conv_in_bwd_weight of a 32 -> 32 channel layer with the layer's InstanceNorm + LeakyReLU +
+ * dropout backward (Our_UNet/models/unet.py:118-127 under autograd) applied ON LOAD by the dy side
+ * of the Winograd weight-gradient kernel, which reads every pixel exactly once: g = dL/da [N][H][W]
+ * [Cout] (w.r.t. the layer's activated output), y = the layer's raw convolution output, coef5 /
+ * sums from unet_instnorm_bwd_coefs.  Writes dz = dL/dy to dz_out (may alias g) for the layer's
+ * data gradient, fills dgamma / dbeta / dbias (each may be null) and the weight gradient as
+ * unet_conv_in_bwd_weight does: the elementwise unet_instnorm_lrelu_drop_bwd pass of such a
+ * layer disappears.  x must be activated on load (alpha / beta).  (csrc/conv_wgrad.hip) */
+int unet_conv_in_bwd_weight_dz_supported(int N, int H, int W, int Cx, int Cout);
+int unet_conv_in_bwd_weight_dz(const unet_act_src* x, float slope, const float* g, const float* y,
+                               const float* coef5, const float* sums, const float* gamma,
+                               const float* rstd, float dz_slope, float* dz_out, float* dgamma,
+                               float* dbeta, float* dbias, float* dw_oihw, int ci_offset,
+                               int Cin_total, void* workspace, size_t workspace_bytes, int N, int H,
+                               int W, int Cout, unet_stream_t stream);
 size_t unet_wino_weight_floats(int Cout, int Cin);
 int unet_pack_wino_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin,
                            unet_stream_t stream);

@@ -38,7 +38,7 @@ def test_python_binding_covers_every_declared_symbol(ua):
 
 def test_abi_version_and_device_count(ua):
     lib = ua.lib()
-    assert lib.unet_abi_version() == 5
+    assert lib.unet_abi_version() == 6
     assert lib.unet_device_count() >= 0
 
 

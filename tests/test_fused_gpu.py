@@ -341,6 +341,51 @@ def test_c32_winograd_weight_gradient(ua, case):
     assert torch.equal(wide_d[:, 64:], dw_d)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64), (1, 8, 32), (3, 40, 96), (2, 256, 256)])
+def test_c32_weight_gradient_applies_the_instnorm_backward_on_load(ua, case):
+    """unet_conv_in_bwd_weight_dz: the dy side of the 32 -> 32 channel Winograd weight gradient
+    forms dz = dL/dy from (g, y) on load and writes it for the data gradient - against the
+    elementwise pass (unet_instnorm_lrelu_drop_bwd) followed by the plain weight gradient: dz,
+    dgamma, dbeta, dbias and dw."""
+    N, H, W = case
+    C = 32
+    x = rnd(N, C, H, W, seed=1)
+    c0 = coeffs(N, C, 10)
+    src = make_src(ua, x, c0)
+    y, st, gamma, beta, mask = _next_norm(ua, N, C, H, W, 10)
+    ua.ops.set_c32_winograd("always")
+    try:
+        assert ua.ops.conv_in_bwd_weight_dz_supported(N, H, W, C, C)
+        # g = dL/da of the layer and its per-tile reductions, as the net gets them: from the
+        # data gradient of the layer behind it (BSTATS epilogue)
+        w2 = rnd(C, C, 3, 3, seed=7, scale=0.1)
+        _, wd2 = ua.ops.pack_conv3x3_weights(w2.to(DEV))
+        nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+        g = ua.ops.conv3x3_bwd_data(to_nhwc(rnd(N, C, H, W, seed=2)), wd2, 0, C, H, W, 1, nxt=nn)
+        assert nn.tiles == H * W // 256
+        # reference: elementwise pass, then the (Winograd) weight gradient of its result
+        dgam, dbet, dbia = (torch.zeros(C, device=DEV) for _ in range(3))
+        dz_ref = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), y, st[0], st[1], gamma, beta, mask, SLOPE,
+                                                dgam, dbet, dbia)
+        dw_ref = torch.zeros(C, C, 3, 3, device=DEV)
+        ua.ops.conv_in_bwd_weight(src, SLOPE, dz_ref, dw_ref, 0, 3, 1)
+        coef5, sums = ua.ops.instnorm_bwd_coefs(y, st[0], st[1], gamma, beta, mask,
+                                                (nn.partial, nn.tiles))
+        dgam2, dbet2, dbia2 = (torch.zeros(C, device=DEV) for _ in range(3))
+        dw = torch.zeros(C, C, 3, 3, device=DEV)
+        g2 = g.clone()
+        dz = ua.ops.conv_in_bwd_weight_dz(src, SLOPE, g2, y, coef5, sums, gamma, st[1], SLOPE,
+                                          dgam2, dbet2, dbia2, dw, 0)
+    finally:
+        ua.ops.set_c32_winograd(True)
+    assert dz.data_ptr() == g2.data_ptr()          # written over g
+    check(dz, dz_ref, 2e-5, "dz formed on load vs the elementwise pass")
+    check(dw, dw_ref, 5e-5, "weight gradient")
+    check(dgam2, dgam, 5e-5, "dgamma")
+    check(dbet2, dbet, 5e-5, "dbeta")
+    assert (dbia2 - dbia).abs().max() <= 1e-3 * (1 + dbet.abs().max())   # both ~0 (closed form)
+
+
 X3_FUSED_CASES = [  # shapes the split patch kernel takes in the fused pipeline
     (1, 256, 256, 32, 32, 128, 1, 3, True, True),    # 128 columns, two sources
     (2, 256, 256, 64, 0, 64, 1, 3, True, False),     # 64 columns, 8-row tiles

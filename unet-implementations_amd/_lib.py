@@ -104,6 +104,9 @@ SIGNATURES = {
     "unet_stem_u8_bwd_weight": (_i, [_p, _c.POINTER(_f), _c.POINTER(_f), _p, _p, _p, _sz, _i, _i,
                                      _i, _i, _p]),
     "unet_conv_in_bwd_weight": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_conv_in_bwd_weight_dz_supported": (_i, [_i, _i, _i, _i, _i]),
+    "unet_conv_in_bwd_weight_dz": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i,
+                                        _p, _sz, _i, _i, _i, _i, _p]),
     "unet_conv_in_bwd_weight_bf16x3": (_i, [_ps, _f, _p, _p, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i,
                                             _p]),
     "unet_upsample2x_in_fwd": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
@@ -196,7 +199,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.unet_abi_version() != 5:
+    if handle.unet_abi_version() != 6:
         raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

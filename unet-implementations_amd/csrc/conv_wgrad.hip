@@ -49,6 +49,19 @@ struct WgradParams {
   const float* beta;   // [N][Cx]
   float slope;
   int b16;             // x and dy are bf16 tensors (mixed-precision pipeline)
+  // conv_wgrad_wino32_kernel<.., DZ>: `dy` holds g = dL/da (gradient w.r.t. the layer's ACTIVATED
+  // output); the kernel forms dz = dL/dy of the layer's InstanceNorm + LeakyReLU + dropout
+  // backward while it loads its dy tiles - dz = (z > 0 ? P : P slope) g + (Q y + R),
+  // z = y a1 + b1, coefficient planes [5][N][C] from unet_instnorm_bwd_coefs - uses it, and
+  // WRITES it to dz_out (may alias dy: every pixel is read once) for the data gradient.
+  const float* dz_y;      // raw conv output y of the layer, [N][H][W][Cout]
+  const float* dz_coef;   // [5][N][Cout]: a1, b1, P, Q, R
+  float* dz_out;
+  const float2* dz_sums;  // [N][Cout] (S1, S2)
+  const float* dz_gamma;  // [Cout]
+  const float* dz_rstd;   // [N][Cout]
+  float* dz_dgamma; float* dz_dbeta; float* dz_dbias;   // [Cout] each (may be null)
+  float dz_slope;
 };
 
 // Epilogue shared by the weight-gradient kernels.  A wave holds nine 32x32 accumulator blocks
@@ -1570,7 +1583,7 @@ constexpr int WQ_V = 16 * 16 * WQ_VP;                       // [xi][tile slot 16
 constexpr size_t WQ_LDS = ((size_t)WQ_PPIX * WQ_LDA + 2 * WQ_V) * sizeof(float);
 static_assert(4 * 3 * 1024 <= 2 * WQ_V, "the epilogue exchange lives in the V / E stages");
 
-template <bool ACT>
+template <bool ACT, bool DZ>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradParams p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Pb = smem;
@@ -1592,6 +1605,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
   }
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  if (DZ && blockIdx.x == 0) {   // parameter gradients of the layer's norm / bias (N x 32 sums)
+    const float hw = (float)(H * W), inv = 1.f / hw;
+    if (tid < 32) {
+      float dg = 0.f, db = 0.f, dbi = 0.f;
+      for (int q = 0; q < p.N; ++q) {
+        const float2 v = p.dz_sums[(size_t)q * 32 + tid];
+        db += v.x;
+        dg += v.y;
+        dbi += p.dz_gamma[tid] * p.dz_rstd[(size_t)q * 32 + tid] * (v.x - hw * (v.x * inv));
+      }
+      if (p.dz_dgamma) p.dz_dgamma[tid] = dg;
+      if (p.dz_dbeta) p.dz_dbeta[tid] = db;
+      if (p.dz_dbias) p.dz_dbias[tid] = dbi;
+    }
+  }
 
   // ---- patch slots of this thread ----
   int pp_rel[WQ_PASSES], pp_lds[WQ_PASSES], pp_rc[WQ_PASSES];
@@ -1623,6 +1651,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
   const unsigned t_srca = lds_addr(Pb + ((2 * t_ty) * WQ_PW + 2 * t_tx) * WQ_LDA + 2 * cp);
   float* const t_dst = (xside ? Vs : Es) + tt * WQ_VP + 2 * cp;
   f32x2v en[4];   // dy side: the next unit's 2 x 2 tile (channel pair cp)
+  f32x2v yn[4];   // DZ: the same of the layer's raw output y
+  f32x2v cz[5];   // DZ: a1, b1, P, Q, R of image n_cz for this channel pair
+  int n_cz = -1;
+  size_t en_off = 0;   // element offset of the tile in the registers (DZ: where dz goes)
   auto load_unit = [&](int n, int yu, int xu) {   // patch of x (all threads) + dy tile (waves 4-7)
     const int base = ((n * H + yu - 1) * W + xu - 1) * 128;
     okm = 0;
@@ -1635,12 +1667,45 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
       pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
     }
     if (!xside) {   // uniform
-      const float* d = p.dy + (((size_t)n * H + yu + 2 * t_ty) * W + xu + 2 * t_tx) * 32 + 2 * cp;
+      const size_t o = (((size_t)n * H + yu + 2 * t_ty) * W + xu + 2 * t_tx) * 32 + 2 * cp;
+      const float* d = p.dy + o;
       en[0] = *reinterpret_cast<const f32x2v*>(d);
       en[1] = *reinterpret_cast<const f32x2v*>(d + 32);
       en[2] = *reinterpret_cast<const f32x2v*>(d + (size_t)W * 32);
       en[3] = *reinterpret_cast<const f32x2v*>(d + (size_t)W * 32 + 32);
+      if (DZ) {
+        const float* yy = p.dz_y + o;
+        yn[0] = *reinterpret_cast<const f32x2v*>(yy);
+        yn[1] = *reinterpret_cast<const f32x2v*>(yy + 32);
+        yn[2] = *reinterpret_cast<const f32x2v*>(yy + (size_t)W * 32);
+        yn[3] = *reinterpret_cast<const f32x2v*>(yy + (size_t)W * 32 + 32);
+        en_off = o;
+      }
     }
+  };
+  // DZ: dz of the tile in (e, y) with the coefficients of image n; written out, returned in e
+  auto apply_dz = [&](f32x2v (&e)[4], const f32x2v (&y)[4], size_t off, int n) {
+    if (n != n_cz) {   // uniform: once per image
+      const size_t plane = (size_t)p.N * 32;
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        cz[k] = *reinterpret_cast<const f32x2v*>(p.dz_coef + k * plane + (size_t)n * 32 + 2 * cp);
+      n_cz = n;
+    }
+    const f32x2v ps = cz[2] * p.dz_slope;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x2v z = y[k] * cz[0] + cz[1];
+      f32x2v sel;
+      sel[0] = z[0] > 0.f ? cz[2][0] : ps[0];
+      sel[1] = z[1] > 0.f ? cz[2][1] : ps[1];
+      e[k] = sel * e[k] + (cz[3] * y[k] + cz[4]);
+    }
+    float* o = p.dz_out + off;
+    *reinterpret_cast<f32x2v*>(o) = e[0];
+    *reinterpret_cast<f32x2v*>(o + 32) = e[1];
+    *reinterpret_cast<f32x2v*>(o + (size_t)W * 32) = e[2];
+    *reinterpret_cast<f32x2v*>(o + (size_t)W * 32 + 32) = e[3];
   };
   auto load_act = [&](int n) {
     if (ACT) {
@@ -1729,9 +1794,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
       tile_pos(tile, n, y0, x0);
       for_range<0, 4>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        f32x2v ec[4];
+        f32x2v ec[4], yc[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ec[k] = en[k];   // this unit's dy tile (loaded a unit ago)
+        for (int k = 0; k < 4; ++k) { ec[k] = en[k]; yc[k] = yn[k]; }   // this unit's dy tile (loaded a unit ago)
+        const size_t ec_off = en_off;
         bool have_next = true;
         int nn = n;
         if constexpr (u < 3) {
@@ -1744,7 +1810,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
             load_unit(nn, ny, nx);
           }
         }
-        if (xside) transform_x(); else transform_dy(ec);   // uniform
+        if (xside) transform_x();   // uniform
+        else {
+          if (DZ) apply_dz(ec, yc, ec_off, n);
+          transform_dy(ec);
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -1816,12 +1886,16 @@ WgradPlan make_plan_wino32(int N, int H, int W) {
 int launch_wgrad_wino32(const WgradParams& p, hipStream_t stream) {
   const int ntiles = p.N * (p.H / 8) * (p.W / 32);
   const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-  if (p.alpha) {
-    auto kern = conv_wgrad_wino32_kernel<true>;
+  if (p.dz_y) {   // (the fused pipeline: the x operand is always activated on load)
+    auto kern = conv_wgrad_wino32_kernel<true, true>;
+    UNET_SET_DYN_LDS(kern, WQ_LDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WQ_LDS, stream, p, ntiles);
+  } else if (p.alpha) {
+    auto kern = conv_wgrad_wino32_kernel<true, false>;
     UNET_SET_DYN_LDS(kern, WQ_LDS);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WQ_LDS, stream, p, ntiles);
   } else {
-    auto kern = conv_wgrad_wino32_kernel<false>;
+    auto kern = conv_wgrad_wino32_kernel<false, false>;
     UNET_SET_DYN_LDS(kern, WQ_LDS);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WQ_LDS, stream, p, ntiles);
   }
@@ -2182,7 +2256,8 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
                                 bool center_only, hipStream_t stream, int prec = 0,
                                 const float* act_alpha = nullptr, const float* act_beta = nullptr,
                                 float slope = 0.f, const unsigned char* x_u8 = nullptr,
-                                const float* u8_mean_std = nullptr, int b16 = 0) {
+                                const float* u8_mean_std = nullptr, int b16 = 0,
+                                const WgradParams* dz = nullptr) {
   // b16: x (except the RGB image) and dy are bf16 tensors; prec is then 1 (bf16 matrix cores
   // for the stride-1 layers, fp32 matrix cores on bf16 storage for the rest)
   const long long es = b16 ? 2 : 4;
@@ -2289,6 +2364,12 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       p.alpha = act_alpha ? act_alpha + (size_t)nb * Cx : nullptr;
       p.beta = act_alpha ? act_beta + (size_t)nb * Cx : nullptr;
       p.slope = slope;
+      if (dz) {   // the InstanceNorm backward applied by the dy side of the Winograd kernel
+        UNET_REQUIRE(wino32 && act_alpha, "conv_in_bwd_weight_dz: shape not taken by conv_wgrad_wino32_kernel");
+        p.dz_y = dz->dz_y; p.dz_coef = dz->dz_coef; p.dz_out = dz->dz_out; p.dz_sums = dz->dz_sums;
+        p.dz_gamma = dz->dz_gamma; p.dz_rstd = dz->dz_rstd; p.dz_dgamma = dz->dz_dgamma;
+        p.dz_dbeta = dz->dz_dbeta; p.dz_dbias = dz->dz_dbias; p.dz_slope = dz->dz_slope;
+      }
       const int rc = wino32 ? launch_wgrad_wino32(p, stream)
                      : wino ? launch_wgrad_wino(p, stream) : launch_wgrad_plan(p, pc, stride, prec, stream);
       if (rc != UNET_OK) return rc;
@@ -2402,6 +2483,36 @@ extern "C" int unet_conv_in_bwd_weight(const unet_act_src* x, float slope, const
   return conv_bwd_weight_impl(x->x, x->C, dy, dw_oihw, ci_offset, Cin_total, nullptr, workspace,
                               workspace_bytes, N, H, W, Cout, stride, ksize == 1,
                               (hipStream_t)stream, 0, x->alpha, x->beta, slope);
+}
+
+// unet_conv_in_bwd_weight of a 32 -> 32 channel layer with the layer's InstanceNorm + LeakyReLU +
+// dropout backward applied ON LOAD: `g` = dL/da (w.r.t. the activated output), y / coef5 / sums as
+// for unet_conv3x3_bwd_data_dz_wino (unet_instnorm_bwd_coefs).  Writes dz = dL/dy to dz_out (may
+// alias g) for the layer's data gradient, dgamma / dbeta / dbias, and the weight gradient.
+// Shapes: unet_conv_in_bwd_weight_dz_supported.
+extern "C" int unet_conv_in_bwd_weight_dz_supported(int N, int H, int W, int Cx, int Cout) {
+  return (N > 0 && H > 0 && W > 0 && wgrad_wino32_ok(N, H, W, Cx, Cout, 1) &&
+          wgrad_batch_chunk(N, H, W, Cx, Cout, 1) >= N) ? 1 : 0;
+}
+extern "C" int unet_conv_in_bwd_weight_dz(const unet_act_src* x, float slope, const float* g,
+                                          const float* y, const float* coef5, const float* sums,
+                                          const float* gamma, const float* rstd, float dz_slope,
+                                          float* dz_out, float* dgamma, float* dbeta, float* dbias,
+                                          float* dw_oihw, int ci_offset, int Cin_total,
+                                          void* workspace, size_t workspace_bytes, int N, int H,
+                                          int W, int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && x->alpha && x->beta && g && y && coef5 && sums && gamma && rstd && dz_out,
+               "conv_in_bwd_weight_dz: null pointer");
+  UNET_REQUIRE(unet_conv_in_bwd_weight_dz_supported(N, H, W, x->C, Cout),
+               "conv_in_bwd_weight_dz: shape N=%d %dx%d %d->%d not supported", N, H, W, x->C, Cout);
+  WgradParams dz{};
+  dz.dz_y = y; dz.dz_coef = coef5; dz.dz_out = dz_out;
+  dz.dz_sums = reinterpret_cast<const float2*>(sums);
+  dz.dz_gamma = gamma; dz.dz_rstd = rstd; dz.dz_slope = dz_slope;
+  dz.dz_dgamma = dgamma; dz.dz_dbeta = dbeta; dz.dz_dbias = dbias;
+  return conv_bwd_weight_impl(x->x, x->C, g, dw_oihw, ci_offset, Cin_total, nullptr, workspace,
+                              workspace_bytes, N, H, W, Cout, 1, false, (hipStream_t)stream, 0,
+                              x->alpha, x->beta, slope, nullptr, nullptr, 0, &dz);
 }
 
 // The same in the split-bf16 operand mode (fp32 tensors, fp32-class accuracy): stride-1 3x3

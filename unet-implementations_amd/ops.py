@@ -503,6 +503,34 @@ def instnorm_bwd_coefs(y, mean, rstd, gamma, beta, mask, partials):
     return coef5, sums
 
 
+def conv_in_bwd_weight_dz_supported(N, H, W, Cx, Cout):
+    """The fp32 weight gradient of this (stride-1, 3x3) layer can apply the layer's InstanceNorm
+    backward on load (32 -> 32 channels on the Winograd kernel: csrc/conv_wgrad.hip)?"""
+    return bool(lib().unet_conv_in_bwd_weight_dz_supported(N, H, W, Cx, Cout))
+
+
+def conv_in_bwd_weight_dz(x, slope, g, y, coef5, sums, gamma, rstd, dz_slope, dgamma, dbeta, dbias,
+                          dw_oihw, ci_offset, in_place=True):
+    """Weight gradient of a fused 32 -> 32 channel layer whose dy side forms dz = dL/dy from
+    (g, y) on load (unet_conv_in_bwd_weight_dz).  Returns dz (written over g unless in_place is
+    False) for the layer's data gradient; dgamma / dbeta / dbias are filled."""
+    x, rx = _act(x)
+    N, H, W, Cx = x.shape
+    Cout = g.shape[3]
+    assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous() and y.shape == g.shape
+    ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1), g)
+    dz = g if in_place else _f32(tuple(g.shape), g)
+    t0 = _timer.begin("wgrad") if _timer is not None else None
+    check(lib().unet_conv_in_bwd_weight_dz(
+        rx, slope, _ptr(g), _ptr(y), _ptr(coef5), _ptr(sums), _ptr(gamma), _ptr(rstd), dz_slope,
+        _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(dw_oihw), ci_offset,
+        dw_oihw.shape[1], _ptr(ws), ws.numel(), N, H, W, Cout, _stream()))
+    if t0 is not None:
+        alg = 2.0 * N * H * W * 9 * Cx * Cout
+        _timer.end("conv_wgrad", alg, 2, t0, executed=alg * 16.0 / 36.0)
+    return dz
+
+
 def conv3x3_bwd_data_dz(g, y, coef5, sums, gamma, rstd, slope, dgamma, dbeta, dbias, ud,
                         cin_total, ci_offset, ccols, nxt=None):
     """Winograd data gradient whose loader applies the InstanceNorm backward of the layer to

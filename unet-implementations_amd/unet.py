@@ -774,6 +774,7 @@ class _UNetFunction(torch.autograd.Function):
             # also writes dy for the weight gradient): no elementwise pass over the layer tensor.
             # Needs the reductions from the producer of g_a and a Winograd data gradient of this dy.
             dx_fold = None
+            wgrad_done = False
             fold_ud = rec.get("ud1") if low is not None else rec.get("ud")
             if model.fold_instnorm_backward and nn_ is not None and nn_.tiles > 0 and \
                     fold_ud is not None and not dx0_acc and dx0_out is None and \
@@ -790,6 +791,25 @@ class _UNetFunction(torch.autograd.Function):
                     cc_, nxt=None if low is not None else nxt)
                 if nxt is not None and low is None:
                     saved[i - 1]["nxt"] = nxt
+            elif model.fold_instnorm_backward and fused and not b16_bwd and not x3_bwd and \
+                    model.winograd and low is None and \
+                    x1 is None and l.ksize == 3 and l.stride == 1 and l.conv.weight.requires_grad and \
+                    nn_ is not None and nn_.tiles > 0 and isinstance(x0, ops.Act) and \
+                    x0.alpha is not None and g_a.dtype == torch.float32 and \
+                    ops.conv_in_bwd_weight_dz_supported(*x0.shape, l.conv.weight.shape[0]):
+                # 32 -> 32 channel layers: the dy side of the Winograd weight gradient reads every
+                # pixel once, so IT applies the InstanceNorm backward on load and writes dz (over
+                # g) for the data gradient - no elementwise pass over the layer tensor.  (Off by
+                # default like the rest of the fold: measured -0.16 ms of elementwise pass against
+                # +0.09 ms in the weight gradient, whose traffic goes from 0.5 to 1.1 GB.)
+                coef5, sums = ops.instnorm_bwd_coefs(rec["y"], st[0], st[1], l.norm.weight.detach(),
+                                                     l.norm.bias.detach(), rec["mask"],
+                                                     (nn_.partial, nn_.tiles))
+                dy = ops.conv_in_bwd_weight_dz(x0, slope, g_a, rec["y"], coef5, sums,
+                                               l.norm.weight.detach(), st[1], l.slope,
+                                               gv(l.norm.weight), gv(l.norm.bias), gv(l.conv.bias),
+                                               gv(l.conv.weight), 0)
+                wgrad_done = True
             else:
                 dy = ops.instnorm_lrelu_drop_bwd(g_a, rec["y"], st[0], st[1],
                                                  l.norm.weight.detach(), l.norm.bias.detach(),
@@ -800,7 +820,7 @@ class _UNetFunction(torch.autograd.Function):
             if dbg is not None:
                 dbg.append((l.name, "dy", dy.clone()))
             dw = gv(l.conv.weight)
-            want_dw = l.conv.weight.requires_grad
+            want_dw = l.conv.weight.requires_grad and not wgrad_done
             if low is not None:
                 # conv3x3(upsample2x(act(low))): both gradients of the up-sampled operand are
                 # GEMMs over the LOW-resolution pixels once dy is reduced to its nine D_tap
