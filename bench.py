@@ -35,7 +35,7 @@ def hbm_traffic(args):
     pmc_traffic.py).  A committed measurement of the default workload, not of this run."""
     if args.matmul != "fp32" or args.hw != 512 or args.batch != 8 or args.clip:
         return None, None
-    for name in ("r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json",
+    for name in ("r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json",
                  "r01_igemm_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -258,6 +258,12 @@ def main():
         else:
             dist.init_process_group(backend=backend, **kw)
 
+    # the CPU baseline (the oracle on the host cores) runs BEFORE the GPU legs: the GPU phases
+    # then form one contiguous stretch that a coarse utilisation sampler can see
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline()
+
     torch.manual_seed(1234)          # same initial replica on every rank
     if args.clip:
         model = ua.CLIPUNet(with_clip_features=True, clip_dim=512).to(dev).train()
@@ -345,13 +351,20 @@ def main():
 
     enqueue = enqueue_ms()
 
+    # The data-parallel step is capturable too (RCCL's collectives become graph nodes on RCCL's
+    # stream).  At N = 1 the leg always runs (with UNET_BENCH_RCCL=1 through the one-rank RCCL
+    # group, collectives captured); at N > 1 it is opt-in (UNET_BENCH_DDP_GRAPH=1): no multi-GPU
+    # node was ever available to rehearse it, and a hang there would cost the whole bench line.
+    ddp_graph = use_dist and backend == "nccl" and \
+        (solo_rccl or bool(os.environ.get("UNET_BENCH_DDP_GRAPH")))
+
     def graph_leg():
         """The same K steps replayed from ONE HIP graph (ua.GraphedTrainStep): what the step
-        costs once the host walk is out of the way.  Single process, plain UNet only (the
-        bucketed all-reduce hook is not captured)."""
-        if use_dist or args.clip or args.no_graph:
+        costs once the host walk is out of the way.  Plain UNet only; with a process group the
+        bucketed all-reduces are captured with the step (backend nccl = RCCL)."""
+        if (use_dist and not ddp_graph) or args.clip or args.no_graph:
             return None
-        gstep = ua.GraphedTrainStep(model, opt, lossf, img, tgt)
+        gstep = ua.GraphedTrainStep(model, opt, lossf, img, tgt, grad_sync=sync)
         for _ in range(2):
             gstep(img, tgt)
         fence()
@@ -361,10 +374,15 @@ def main():
         t_enq = time.perf_counter() - t
         fence()
         dt_g = time.perf_counter() - t
+        if use_dist:
+            tt = torch.tensor([dt_g], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_g = tt.item()
         opt.use_device_hyper(False)
-        return {"value": args.batch * args.steps / dt_g, "unit": "images/s",
+        return {"value": args.batch * world * args.steps / dt_g, "unit": "images/s",
                 "ms_per_step": 1e3 * dt_g / args.steps,
                 "enqueue_ms_per_step": 1e3 * t_enq / args.steps,
+                "collectives_captured": bool(use_dist),
                 "note": "train step captured once in a HIP graph and replayed (same kernels, "
                         "same order; dropout masks drawn inside the graph)"}
 
@@ -466,8 +484,8 @@ def main():
             result["graph_replay"] = graph
         if alt is not None:
             result["alt_modes"] = alt
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+        if cpu_base is not None:
+            result["cpu_baseline"] = cpu_base
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()

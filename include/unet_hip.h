@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 6
+#define UNET_ABI_VERSION 7
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -244,6 +244,17 @@ int unet_dice_wce_loss_fwd_bwd(const float* logits_nchw, const int64_t* target, 
                                int N, int H, int W, float smooth, float w_dice, float w_ce,
                                int ignore_index, int dynamic_weights, const float* class_weights,
                                float grad_scale, unet_stream_t stream);
+
+/* The gradient pass alone, for a caller that learns dL/d(loss) only later (autograd's
+ * backward): run unet_dice_wce_loss_fwd_bwd / _shard_apply with dlogits == NULL, keep the SAME
+ * workspace (it holds the class weights and Dice coefficients of that call) and call this with
+ * `upstream` = a device float holding dL/d(loss) (NULL = 1).  dlogits = upstream * the gradient
+ * the one-call form writes (bit-identical for upstream == 1).  Replaces the autograd backward
+ * of SimpleLoss.forward (Our_UNet/models/losses.py:64-82) without an extra scaling pass. */
+int unet_dice_wce_loss_grad(const float* logits_nchw, const int64_t* target,
+                            const void* workspace, size_t workspace_bytes, const float* upstream,
+                            float* dlogits_nchw, int N, int H, int W, int ignore_index,
+                            unet_stream_t stream);
 
 /* The same loss over a batch SHARDED across processes (data parallel, SURVEY.md 8e
  * "global-exact"): the value and gradient of SimpleLoss on the concatenated batch.
@@ -485,7 +496,9 @@ int unet_conv_wino_supported(int N, int H, int W, int C0, int C1, int Cout);
  * switch rather than an entry point: 1 (default) = Winograd when the launch fills the chip (at
  * least 512 tiles of 8 x 32 pixels: the persistent kernel runs two workgroups per CU), 2 =
  * Winograd for every shape the kernel tiles, 0 = the direct kernel.  Returns the previous
- * setting.  The weight gradient of the same layers (unet_conv_in_bwd_weight /
+ * setting.  The switch is kept PER CALLING THREAD (ABI 7; it was process-wide): a caller sets it
+ * around its own launches and restores it, so two models on two threads - or a framework's
+ * backward thread - cannot change each other's dispatch.  The weight gradient of the same layers (unet_conv_in_bwd_weight /
  * unet_conv3x3_bwd_weight with Cx = Cout = 32, stride 1, H % 8 == 0, W % 32 == 0) follows the
  * same switch: Winograd F(3x3,2x2) when there is an 8 x 32 tile for every CU (1) / always (2).
  * (csrc/conv_c32.hip, csrc/conv_wgrad.hip) */

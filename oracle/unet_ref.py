@@ -321,10 +321,51 @@ def leaf_state_dict(sd):
 
 
 # ---------------------------------------------------------------- validation / input pipeline
+def segmentation_metrics(preds, targets, num_classes=3, ignore_index=255):
+    """Accumulators of SegmentationMetrics over a list of (pred, target) batches of class maps
+    (numpy [B, H, W]) and the derived scores, restating Our_UNet/utils/metrics.py:59-91
+    (`_update_single`: per-class intersection, union, TP / FP / FN over the valid pixels),
+    :93-151 (pixel accuracy, IoU, Dice, nan for an empty denominator) and :121-169 (means over
+    the non-nan classes).  PINNED: tests/golden/metrics.npz was recorded from the reference
+    class itself (tests/tools/make_golden.py metrics_run)."""
+    inter = np.zeros(num_classes)
+    union = np.zeros(num_classes)
+    tp, fp, fn = np.zeros(num_classes), np.zeros(num_classes), np.zeros(num_classes)
+    total = correct = 0
+    for pred_b, target_b in zip(preds, targets):
+        for pred, target in zip(pred_b, target_b):
+            mask = target != ignore_index
+            total += mask.sum()
+            correct += ((pred == target) & mask).sum()
+            for c in range(num_classes):
+                pc, tc = (pred == c) & mask, (target == c) & mask
+                i = (pc & tc).sum()
+                inter[c] += i
+                union[c] += pc.sum() + tc.sum() - i
+                tp[c] += i
+                fp[c] += pc.sum() - i
+                fn[c] += tc.sum() - i
+    nan = float("nan")
+    iou = [float(inter[c] / union[c]) if union[c] > 0 else nan for c in range(num_classes)]
+    dice = [float(2 * tp[c] / (2 * tp[c] + fp[c] + fn[c])) if (2 * tp[c] + fp[c] + fn[c]) > 0
+            else nan for c in range(num_classes)]
+
+    def mean_valid(v):
+        v = [x for x in v if not np.isnan(x)]
+        return float(sum(v) / len(v)) if v else nan
+
+    return dict(intersections=inter, unions=union, true_positives=tp, false_positives=fp,
+                false_negatives=fn, total_pixels=int(total), correct_pixels=int(correct),
+                pixel_accuracy=float(correct / total) if total > 0 else nan,
+                iou=np.array(iou), dice=np.array(dice), mean_iou=mean_valid(iou),
+                mean_dice=mean_valid(dice))
+
+
 # PARITY UNPINNED for the three functions below: Our_UNet/src/train.py imports cv2, which is not
 # installed here, so the reference's validate() / dataset code could not be executed to record
 # fixtures.  They restate the arithmetic read from the source lines cited; the argmax/count part
-# is integer-exact against torch.argmax in tests/test_kernels_gpu.py.
+# is integer-exact against torch.argmax in tests/test_kernels_gpu.py and - through
+# `segmentation_metrics` above - pinned to the reference's SegmentationMetrics.
 def batch_dice_scores(logits, masks, ignore_label=255):
     """Per-class Dice of one validation batch, as Our_UNet/src/train.py:556-577 computes it:
     argmax predictions, ignore pixels masked out, 2I/(|P|+|M|+1e-5), or 1.0 for an absent class."""

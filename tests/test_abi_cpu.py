@@ -38,7 +38,8 @@ def test_python_binding_covers_every_declared_symbol(ua):
 
 def test_abi_version_and_device_count(ua):
     lib = ua.lib()
-    assert lib.unet_abi_version() == 6
+    header_version = int(re.search(r"#define\s+UNET_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.unet_abi_version() == header_version == ua._lib.ABI_VERSION
     assert lib.unet_device_count() >= 0
 
 

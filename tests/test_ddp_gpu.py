@@ -257,3 +257,82 @@ def test_rccl_call_path_with_a_single_rank():
     covered = sorted(out["ranges"])
     assert covered[0][0] == 0 and covered[-1][1] == garena.numel()
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "buckets must tile the arena"
+
+
+def _worker_rccl_graph(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from unet_implementations_amd import ddp
+    from oracle import unet_ref as O
+    for graphed in (False, True):
+        ua, model, img, tgt = _setup(0)
+        img2, tgt2 = O.synthetic_batch(777, N_PER_RANK, HW, HW)
+        img2, tgt2 = img2.cuda(), tgt2.cuda()
+        model.dropout_mask_override = [m.cuda() if m is not None else None
+                                       for m in model.dropout_mask_override]
+        opt = ua.create_optimizer(model)
+        lossf = ua.get_loss_function()
+        sync = ddp.GradBucketAllReduce(model, opt, bucket_bytes=8 << 20, always_reduce=True)
+        ddp.broadcast_parameters(model)
+        if graphed:
+            gstep = ua.GraphedTrainStep(model, opt, lossf, img, tgt, grad_sync=sync)
+            out["capture_ranges"] = list(sync.sent_ranges)
+            step = gstep
+        else:
+            def step(x, y, model=model, opt=opt, lossf=lossf, sync=sync):
+                return ua.train_step(model, opt, lossf, x, y, grad_sync=sync.finish)
+        losses = []
+        for k, batch in enumerate(((img, tgt), (img2, tgt2), (img, tgt), (img2, tgt2))):
+            if k == 2:
+                opt.param_groups[0]["lr"] *= 0.5
+            losses.append(step(*batch).item())
+        torch.cuda.synchronize()
+        arena, garena = model.flat_parameters()
+        tag = "graph" if graphed else "eager"
+        out[tag] = (losses, arena.cpu(), garena.cpu(), opt._flat_buf.cpu())
+        del model, opt
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graph_captured_data_parallel_step_equals_the_eager_one():
+    """GraphedTrainStep(..., grad_sync=GradBucketAllReduce) with backend nccl (= RCCL, one rank
+    with `always_reduce`, so every bucketed all-reduce is really issued): the collectives are
+    captured with the step (forked onto RCCL's stream where a bucket becomes final, joined before
+    the SGD launch).  Four replayed steps - the last two after a learning-rate change - must
+    leave losses, parameters, the last gradient arena and the momentum bit-identical to four
+    eager data-parallel steps, and the captured step must have shipped the whole arena."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_rccl_graph, args=(1, _free_port(), out), nprocs=1, join=True)
+    eager, graph = out["eager"], out["graph"]
+    assert eager[0] == graph[0], f"losses differ: {eager[0]} vs {graph[0]}"
+    assert torch.equal(eager[1], graph[1]), "parameters differ after four steps"
+    assert torch.equal(eager[2], graph[2]), "gradient arenas differ"
+    assert torch.equal(eager[3], graph[3]), "momentum differs"
+    covered = sorted(out["capture_ranges"])
+    assert covered[0][0] == 0 and covered[-1][1] == eager[2].numel()
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "buckets must tile the arena"
+
+
+def test_graphed_step_refuses_a_host_side_backend():
+    """gloo runs its collectives on the host: capturing them is impossible, so GraphedTrainStep
+    must refuse instead of silently replaying a step without the exchange."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from unet_implementations_amd import ddp
+        ua, model, img, tgt = _setup(0)
+        opt = ua.create_optimizer(model)
+        sync = ddp.GradBucketAllReduce(model, opt)
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            ua.GraphedTrainStep(model, opt, ua.get_loss_function(), img, tgt, grad_sync=sync)
+        with pytest.raises(RuntimeError, match="pass its GradBucketAllReduce"):
+            ua.GraphedTrainStep(model, opt, ua.get_loss_function(), img, tgt)
+    finally:
+        dist.destroy_process_group()

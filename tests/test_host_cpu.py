@@ -82,8 +82,32 @@ def test_cpu_tensors_are_rejected(ua):
         m(torch.randn(1, 3, 64, 64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ua.SimpleLoss()(torch.randn(1, 3, 8, 8), torch.zeros(1, 8, 8, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
+    # blocks are callable on their own (as in the reference), on the device only
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.encoder_stages[0](torch.randn(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.decoder_stages[0](torch.randn(1, 512, 2, 2), torch.randn(1, 512, 4, 4))
+
+
+def test_hooks_on_inner_modules_are_refused(ua):
+    """The fused walk fires stage-level hooks only; a hook on an inner module (the reference's
+    Grad-CAM helper accepts any layer, Our_UNet/utils/visualize.py:401-402) must raise instead of
+    silently never firing.  The check runs before anything touches the device."""
+    m = ua.UNet()
+    h = m.decoder_stages[0].conv_block.block[0].register_forward_hook(lambda *a: None)
+    with pytest.raises(NotImplementedError, match="decoder_stages.0.conv_block.block.0"):
+        m._plan or m._build_plan()
+        m._check_hooks()
+    h.remove()
+    m._check_hooks()
+    h = m.encoder_stages[2].block.register_full_backward_hook(lambda *a: None)
+    with pytest.raises(NotImplementedError, match="encoder_stages.2.block"):
+        m._check_hooks()
+    h.remove()
+    for mod in (m.encoder_stages[1], m.decoder_stages[2], m.decoder_stages[2].conv_block,
+                m.segmentation_output, m):
+        mod.register_forward_hook(lambda *a: None)
+    m._check_hooks()        # stage-level hooks are supported
 
 
 def test_spatial_dropout_mask_draw_matches_reference_recipe(ua):

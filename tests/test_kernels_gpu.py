@@ -421,6 +421,28 @@ def test_loss_golden(ua, golden):
     check(dl2.cpu(), torch.from_numpy(g["loss2_dlogits"]), 2e-5, "golden dlogits (static w)")
 
 
+def test_loss_gradient_pass_applies_the_upstream_scalar(ua):
+    """unet_dice_wce_loss_grad (what SimpleLoss's autograd backward launches): with no upstream
+    scalar it writes the very bits the one-call form writes; with dL/dloss = s on the device it
+    writes round(dlogits * s), i.e. what the separate `dlogits.mul_(s)` pass of round 3 produced -
+    and (s * loss).backward() through the module agrees with the oracle's autograd."""
+    lg, tg = _loss_case(5, 2, 64, 96, None)
+    lgd, tgd = lg.to(DEV), tg.to(DEV)
+    out, dl = ua.ops.dice_wce_loss_fwd_bwd(lgd, tgd, 1e-5, 1.0, 1.0, 255, True)
+    ws = ua.ops.dice_wce_loss_workspace(lgd)
+    out2, none = ua.ops.dice_wce_loss_fwd_bwd(lgd, tgd, 1e-5, 1.0, 1.0, 255, True, want_grad=False,
+                                              ws=ws)
+    assert none is None and torch.equal(out, out2)
+    assert torch.equal(ua.ops.dice_wce_loss_grad(lgd, tgd, ws, None, 255), dl)
+    s = torch.tensor(-2.75, device=DEV)
+    assert torch.equal(ua.ops.dice_wce_loss_grad(lgd, tgd, ws, s, 255), dl * s)
+    lgr = lg.clone().requires_grad_(True)
+    (O.simple_loss(lgr, tg) * 0.3).backward()
+    x = lgd.clone().requires_grad_(True)
+    (ua.SimpleLoss()(x, tgd) * 0.3).backward()
+    check(x.grad.cpu(), lgr.grad, 2e-5, "dlogits of 0.3 * loss")
+
+
 def test_simple_loss_module(ua, golden):
     g = golden("ops_small")
     lg = torch.from_numpy(g["loss_logits"]).to(DEV).requires_grad_(True)
@@ -537,6 +559,52 @@ def test_upblock_golden(ua, golden):
             check(v.cpu(), ref, 5e-5, f"UpBlock grad {k}")
 
 
+def test_convblock_and_upblock_modules_run_stand_alone(ua, golden):
+    """`ConvBlock.forward(x)` / `UpBlock.forward(x, skip)` called directly, as the reference's
+    are (Our_UNet/models/unet.py:136-141, :203-231): NCHW in / out, differentiable through the
+    HIP entry points - against the reference fixtures of test_convblock_golden /
+    test_upblock_golden (train mode with the recorded dropout draws; eval mode)."""
+    g = golden("ops_small")
+    blk = ua.ConvBlock(32, 64, [3, 3], [2, 2], n_convs=2, spatial_dropout_rate=0.2)
+    blk.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("cb_p_")})
+    blk = blk.to(DEV).train()
+    blk.dropout_mask_override = [torch.from_numpy(g["cb_mask0"]), torch.from_numpy(g["cb_mask1"])]
+    x = torch.from_numpy(g["cb_x"]).to(DEV).requires_grad_(True)
+    y = blk(x)
+    check(y.detach().cpu(), torch.from_numpy(g["cb_y"]), 2e-5, "ConvBlock module fwd")
+    y.backward(torch.from_numpy(g["cb_gy"]).to(DEV))
+    check(x.grad.cpu(), torch.from_numpy(g["cb_gx"]), 5e-5, "ConvBlock module gx")
+    for k, p in blk.named_parameters():
+        ref = torch.from_numpy(g["cb_g_" + k])
+        if k.endswith("bias") and ref.abs().max() < 1e-4:
+            assert (p.grad.cpu() - ref).abs().max() < 1e-4
+        else:
+            check(p.grad.cpu(), ref, 5e-5, f"ConvBlock module grad {k}")
+    # without an override, train mode draws its own masks (values 0 or 1/(1-p) per (n, c))
+    blk.dropout_mask_override = None
+    y2 = blk(x.detach())
+    assert y2.shape == y.shape and not torch.equal(y2, y.detach())
+
+    up = ua.UpBlock(64, 32, 32, [3, 3], n_convs=2)
+    up.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ub_p_")})
+    up = up.to(DEV).eval()
+    xl = torch.from_numpy(g["ub_x"]).to(DEV).requires_grad_(True)
+    sk = torch.from_numpy(g["ub_skip"]).to(DEV).requires_grad_(True)
+    yu = up(xl, sk)
+    check(yu.detach().cpu(), torch.from_numpy(g["ub_y"]), 2e-5, "UpBlock module fwd")
+    yu.backward(torch.from_numpy(g["ub_gy"]).to(DEV))
+    check(xl.grad.cpu(), torch.from_numpy(g["ub_gx"]), 5e-5, "UpBlock module gx")
+    check(sk.grad.cpu(), torch.from_numpy(g["ub_gskip"]), 5e-5, "UpBlock module gskip")
+    for k, p in up.named_parameters():
+        ref = torch.from_numpy(g["ub_g_" + k])
+        if k.endswith("bias") and ref.abs().max() < 1e-4:
+            assert (p.grad.cpu() - ref).abs().max() < 1e-4
+        else:
+            check(p.grad.cpu(), ref, 5e-5, f"UpBlock module grad {k}")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        blk(torch.zeros(1, 32, 8, 8))
+
+
 # ---------------------------------------------------------------- split-bf16 ("bf16x3") mode
 # fp32 operands split into 3 bf16 terms, 6 products, fp32 accumulation: must be as accurate as
 # the fp32 matrix-core kernels.  Both are compared with an fp64 convolution of the same fp32
@@ -631,6 +699,59 @@ def test_argmax_dice_counts_exact(ua, n, h, w):
     for c in range(3):
         pc, mc = (ref_p == c) & valid, (target == c) & valid
         assert counts[c].tolist() == [int((pc & mc).sum()), int(pc.sum()), int(mc.sum())]
+
+
+def test_segmentation_metrics_golden(ua, golden):
+    """f2 PINNED: tests/golden/metrics.npz holds the accumulators the REFERENCE's
+    SegmentationMetrics (Our_UNet/utils/metrics.py:59-91) produced for argmax predictions of the
+    stored logits - exact ties, a class absent from the labels, a class never predicted, an
+    all-ignored image, a 255 ring.  `unet_argmax_dice_counts` must reproduce the predictions and
+    intersections / unions / TP / FP / FN bit-exactly (integers), per batch and accumulated, and
+    the drop-in `SegmentationMetrics` the derived IoU / Dice / precision / recall / means as the
+    identical float64 quotients (nan where the reference returns nan)."""
+    g = golden("metrics")
+    fields = ("intersections", "unions", "true_positives", "false_positives", "false_negatives")
+    acc = ua.SegmentationMetrics(num_classes=3, ignore_index=255)
+    acc_maps = ua.SegmentationMetrics(num_classes=3, ignore_index=255)
+
+    def same(m, tag):
+        for f in fields:
+            assert np.array_equal(getattr(m, f), g[f"{tag}_{f}"]), (tag, f)
+        assert m.total_pixels == int(g[f"{tag}_total_pixels"])
+        assert m.correct_pixels == int(g[f"{tag}_correct_pixels"])
+        for f, fn in (("iou", m.compute_iou), ("dice", m.compute_dice),
+                      ("precision", m.compute_precision), ("recall", m.compute_recall)):
+            got = np.array([fn(c) for c in range(3)])
+            assert np.array_equal(got, g[f"{tag}_{f}"], equal_nan=True), (tag, f, got)
+        for f, v in (("pixel_accuracy", m.compute_pixel_accuracy()),
+                     ("mean_iou", m.compute_mean_iou()), ("mean_dice", m.compute_mean_dice())):
+            ref = float(g[f"{tag}_{f}"])
+            assert v == ref or (np.isnan(v) and np.isnan(ref)), (tag, f, v, ref)
+
+    for k in range(int(g["n_batches"])):
+        lg = torch.from_numpy(g[f"b{k}_logits"]).cuda()
+        t = torch.from_numpy(g[f"b{k}_target"]).cuda()
+        preds, counts = ua.ops.argmax_dice_counts(lg, t)
+        assert np.array_equal(preds.cpu().numpy(), g[f"b{k}_pred"])
+        c = counts.cpu().numpy().astype(np.float64)
+        assert np.array_equal(c[:, 0], g[f"b{k}_intersections"])
+        assert np.array_equal(c[:, 1] + c[:, 2] - c[:, 0], g[f"b{k}_unions"])
+        assert np.array_equal(c[:, 1] - c[:, 0], g[f"b{k}_false_positives"])
+        assert np.array_equal(c[:, 2] - c[:, 0], g[f"b{k}_false_negatives"])
+        one = ua.SegmentationMetrics()
+        one.update_from_logits(lg, t)
+        same(one, f"b{k}")
+        acc.update_from_logits(lg, t)
+        acc_maps.update(preds, t)               # the reference's update(pred, target) form
+    same(acc, "acc")
+    same(acc_maps, "acc")
+    d = acc.get_all_metrics()
+    assert set(d) == {"pixel_accuracy", "mean_iou", "mean_dice", "class_metrics"}
+    assert set(d["class_metrics"]["class_1"]) == {"iou", "dice", "precision", "recall", "f1_score"}
+    acc.reset()
+    assert acc.total_pixels == 0 and np.isnan(acc.compute_mean_iou())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        acc.update_from_logits(torch.zeros(1, 3, 8, 8), torch.zeros(1, 8, 8, dtype=torch.int64))
 
 
 def test_predict_masks_is_argmax_of_eval_forward(ua):

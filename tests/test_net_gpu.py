@@ -201,7 +201,30 @@ def test_tie_free_network_gradients_per_element(ua, golden, fused):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("hw", [64, 128])
+def _winograd_selection(ua, n, hw):
+    """Which Winograd kernels the fused fp32 step picks at batch n, hw x hw (the library's own
+    predicates - the ones ops.py / the C entry points consult)."""
+    L = ua.lib()
+    sel = {
+        "c32 forward / data gradient (conv_wino32q)":
+            bool(L.unet_conv_c32_is_winograd(n, hw, hw, 32, 32, 1)),
+        "c32 up-sampling layer (conv_wino_up32)":
+            bool(L.unet_conv_up_c32_is_winograd(n, hw, hw, 64, 32, 32)),
+        "c32 weight gradient (conv_wgrad_wino32)":
+            bool(L.unet_conv3x3_bwd_weight_is_winograd(n, hw, hw, 32, 32, 1)),
+    }
+    for c, s in ((64, 2), (128, 4), (256, 8), (512, 16)):
+        h = hw // s
+        sel[f"{c} channels forward / data gradient (conv_wino)"] = \
+            bool(L.unet_conv_wino_supported(n, h, h, c, 0, c))
+        sel[f"{c} channels weight gradient (conv_wgrad_wino)"] = \
+            bool(L.unet_conv3x3_bwd_weight_is_winograd(n, h, h, c, c, 1))
+        sel[f"{c} channels up-sampling loader (conv_wino UP)"] = \
+            bool(L.unet_conv_up_wino_supported(n, h, h, min(2 * c, 512), c, c))
+    return sel
+
+
+@pytest.mark.parametrize("hw", [64, 128, 512])
 def test_default_slope_gradients_per_element_with_the_hip_branch_pattern(ua, hw):
     """Whole-network gradients at the REFERENCE slope 0.01, element by element, away from ties.
 
@@ -216,8 +239,17 @@ def test_default_slope_gradients_per_element_with_the_hip_branch_pattern(ua, hw)
     to 2e-4 of each tensor's max magnitude (measured: <= 1.2e-4, on the 512-channel layers whose
     InstanceNorm runs over 4 or 16 pixels at these image sizes; every other tensor <= 1e-4) - the check that `z > 0 ? 1 : slope` in the
     InstanceNorm-backward kernels, the data-gradient epilogues and the activation-on-load of the
-    weight gradients is right at the reference slope."""
+    weight gradients is right at the reference slope.
+
+    hw = 512 (round 4): the size at which the step really runs its Winograd kernels - the
+    one-chunk 32-channel family (conv_wino32q, conv_wino_up32, conv_wgrad_wino32) and the 64- and
+    128-channel conv_wino / conv_wgrad_wino launches; asserted below, so the reference-slope
+    branch of their BSTATS epilogues and of their activation-on-load is held per element."""
     n = 2
+    if hw == 512:
+        sel = _winograd_selection(ua, n, hw)
+        must = [k for k in sel if k.startswith(("c32", "64 ", "128 "))]
+        assert all(sel[k] for k in must), {k: sel[k] for k in must}
     sd0 = O.fill_state_dict(29)
     model = ua.UNet()
     model.load_state_dict(sd0)
@@ -385,6 +417,56 @@ def test_graph_captured_train_step_equals_the_eager_walk(ua, mode):
     assert eager[0] == graph[0], f"losses differ: {eager[0]} vs {graph[0]}"
     assert torch.equal(eager[1], graph[1]), "parameters differ after four steps"
     assert torch.equal(eager[2], graph[2]), "momentum differs after four steps"
+
+
+def test_graphed_step_keeps_momentum_loaded_from_a_checkpoint(ua, tmp_path):
+    """Resume, then capture: FusedSGD.load_state_dict leaves the loaded momentum in
+    state[p]['momentum_buffer'] until the flat arena adopts it.  GraphedTrainStep must adopt it
+    BEFORE its throw-away steps and restore exactly that (round 3 zeroed it: mu = 0.99 of history
+    silently lost).  Two replayed steps after the resume == two eager steps after the resume."""
+    sd0 = O.fill_state_dict(41)
+    img, tgt = O.synthetic_batch(12, 2, 64, 64)
+    img, tgt = img.to(DEV), tgt.to(DEV)
+    masks = [m.to(DEV) if m is not None else None for m in O.draw_dropout_masks(15, 2)]
+    a = ua.UNet()
+    a.load_state_dict(sd0)
+    a = a.to(DEV).train()
+    a.dropout_mask_override = masks
+    opt_a = ua.create_optimizer(a)
+    lossf = ua.get_loss_function()
+    for _ in range(2):
+        ua.train_step(a, opt_a, lossf, img, tgt)
+    path = ua.save_checkpoint(a, opt_a, None, epoch=0, best_dice=0.0, output_dir=tmp_path)
+    assert float(opt_a._flat_buf.abs().max()) > 0
+    outs = []
+    for graphed in (False, True):
+        b = ua.UNet().to(DEV).train()
+        b.dropout_mask_override = masks
+        opt_b = ua.create_optimizer(b)
+        ua.load_checkpoint(path, b, opt_b, None, device=DEV)
+        assert opt_b._flat_buf is None
+        if graphed:
+            step = ua.GraphedTrainStep(b, opt_b, lossf, img, tgt)
+            assert torch.equal(opt_b._flat_buf, opt_a._flat_buf), "capture lost the loaded momentum"
+        else:
+            def step(x, y, b=b, opt_b=opt_b):
+                return ua.train_step(b, opt_b, lossf, x, y)
+        losses = [step(img, tgt).item() for _ in range(2)]
+        arena, _ = b.flat_parameters()
+        outs.append((losses, arena.detach().clone(), opt_b._flat_buf.detach().clone()))
+        # a second GraphedTrainStep on the same optimizer keeps the hyper-parameter tensor the
+        # first graph reads, and an eager step afterwards runs on the CURRENT learning rate
+        if graphed:
+            hyper = opt_b._hyper
+            ua.GraphedTrainStep(b, opt_b, lossf, img, tgt)
+            assert opt_b._hyper is hyper
+            opt_b.param_groups[0]["lr"] = 0.0
+            opt_b.param_groups[0]["weight_decay"] = 0.0
+            before = arena.detach().clone()
+            ua.train_step(b, opt_b, lossf, img, tgt)          # eager, device-side hyper still on
+            assert torch.equal(b.flat_parameters()[0], before), "eager step used a stale lr"
+    (le, pe, be), (lg, pg, bg) = outs
+    assert le == lg and torch.equal(pe, pg) and torch.equal(be, bg)
 
 
 def test_graph_captured_step_draws_fresh_dropout_masks(ua):
@@ -859,6 +941,120 @@ def test_full_size_batch_split_invariance(ua, precision):
     n_head = 96 + 4          # arena tail: head weight [3,32,1,1] + bias [3] padded to 4 floats
     eh = ((full_grad[-n_head:] - part_grad[-n_head:]).norm() / part_grad[-n_head:].norm()).item()
     assert eh <= 1e-4, f"head gradient: {eh:.2e}"
+
+
+def _per_tensor_errors(model, full, part, names=None):
+    """max |full - part| / max |part| per parameter tensor of two gradient arenas"""
+    out = {}
+    for (k, p), off in zip(model.named_parameters(), model._offsets):
+        a, b = full[off:off + p.numel()], part[off:off + p.numel()]
+        out[k] = ((a - b).abs().max().item(), b.abs().max().item())
+    return out
+
+
+def test_full_size_batch_split_tie_free_gradients_per_element(ua):
+    """The bench configuration (bs 8, 512 x 512) is the only place where the 256- and 512-channel
+    Winograd launches (conv_wino_kernel forward / data gradient / up-sampling loader,
+    conv_wgrad_wino_kernel) are selected: at N = 2 those layers have too few tiles and run the
+    direct kernels, which the reference fixtures and the per-element oracle tests pin.  With
+    negative_slope = 1 there is no LeakyReLU branch that a different summation order could flip,
+    so the bs-8 gradient arena must equal the SUM of the four bs-2 arenas on EVERY element of
+    every tensor to 1e-4 of that tensor's max magnitude (and the logits to 2e-5): this holds each
+    N=8-only instantiation against the direct kernels of the N=2 runs, element by element."""
+    N, hw = 8, 512
+    sel8, sel2 = _winograd_selection(ua, N, hw), _winograd_selection(ua, 2, hw)
+    assert all(sel8.values()), sel8
+    only8 = [k for k in sel8 if not sel2[k]]
+    assert any(k.startswith("256 ") for k in only8) and any(k.startswith("512 ") for k in only8), \
+        f"expected the 256/512-channel Winograd forms to be N=8-only: {only8}"
+    sd0 = O.fill_state_dict(78, trained_like=True)
+    img, _ = O.synthetic_batch(4322, N, hw, hw)
+    img = img.to(DEV)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    dlogits = (torch.randn(N, 3, hw, hw, generator=g) * 1e-3).to(DEV)
+    masks = O.draw_dropout_masks(92, N)
+
+    def run(sl):
+        model = ua.UNet(nonlin_kwargs={"negative_slope": 1.0, "inplace": True})
+        model.load_state_dict(sd0)
+        model = model.to(DEV).train()
+        model.dropout_mask_override = [m[sl] for m in masks]
+        out = model(img[sl])
+        out.backward(dlogits[sl])
+        _, garena = model.flat_parameters()
+        return model, out.detach(), garena.detach().clone()
+
+    model, full_logits, full_grad = run(slice(0, N))
+    part_grad = torch.zeros_like(full_grad)
+    for i in range(0, N, 2):
+        _, lg, gr = run(slice(i, i + 2))
+        e = relerr(full_logits[i:i + 2], lg)
+        assert e <= 2e-5, f"images {i}..{i + 1}: bs-8 vs bs-2 logits differ by {e:.2e}"
+        part_grad += gr
+    bad = []
+    for k, (err, scale) in _per_tensor_errors(model, full_grad, part_grad).items():
+        if scale < 1e-6:          # conv biases under InstanceNorm: exact 0 up to rounding
+            continue
+        if err > 1e-4 * scale:
+            bad.append(f"{k}: {err / scale:.2e}")
+    assert not bad, "\n".join(bad)
+
+
+def test_clip_unet_full_size_batch_split(ua):
+    """BASELINE config 5 at its stated size: CLIPUNet, bs 8, 512 x 512, CLIP features
+    [8, 512, 16, 16] (the fixture clip64.npz covers a 2 x 2 bottleneck grid only).  At this size
+    the fusion layer is unet_conv_in_fwd(ksize = 1) at M = 2048 rows, K = 1024, and the rest of
+    the network runs its bs-8 selections.  Per-sample network => the bs-8 pass must equal four
+    bs-2 passes: logits to 2e-5 and, on the tie-free network (negative_slope = 1), every element
+    of all 94 gradients to 1e-4 of the tensor's max (CLIP_UNet/models/unet.py:441-478)."""
+    N, hw, clip_dim = 8, 512, 512
+    sd0 = O.fill_state_dict(79, trained_like=True, clip_dim=clip_dim)
+    img, _ = O.synthetic_batch(4323, N, hw, hw)
+    img = img.to(DEV)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    clip = torch.randn(N, clip_dim, hw // 32, hw // 32, generator=g).to(DEV)
+    dlogits = (torch.randn(N, 3, hw, hw, generator=g) * 1e-3).to(DEV)
+    masks = O.draw_dropout_masks(93, N)
+
+    def run(sl):
+        model = ua.CLIPUNet(with_clip_features=True, clip_dim=clip_dim,
+                            nonlin_kwargs={"negative_slope": 1.0, "inplace": True})
+        model.load_state_dict(sd0)
+        model = model.to(DEV).train()
+        model.dropout_mask_override = [m[sl] for m in masks]
+        out = model(img[sl], clip[sl])
+        out.backward(dlogits[sl])
+        _, garena = model.flat_parameters()
+        return model, out.detach(), garena.detach().clone()
+
+    model, full_logits, full_grad = run(slice(0, N))
+    assert len(list(model.parameters())) == 94
+    part_grad = torch.zeros_like(full_grad)
+    for i in range(0, N, 2):
+        _, lg, gr = run(slice(i, i + 2))
+        e = relerr(full_logits[i:i + 2], lg)
+        assert e <= 2e-5, f"images {i}..{i + 1}: bs-8 vs bs-2 logits differ by {e:.2e}"
+        part_grad += gr
+    bad = []
+    errs = _per_tensor_errors(model, full_grad, part_grad)
+    assert errs["clip_fusion_conv.0.weight"][1] > 0      # the fusion layer did get a gradient
+    for k, (err, scale) in errs.items():
+        if scale < 1e-6:
+            continue
+        if err > 1e-4 * scale:
+            bad.append(f"{k}: {err / scale:.2e}")
+    assert not bad, "\n".join(bad)
+    # and the default-slope network at this size against the same split (logits only: the
+    # gradients of a LeakyReLU network can flip ties between two tilings)
+    def run01(sl):
+        model = ua.CLIPUNet(with_clip_features=True, clip_dim=clip_dim)
+        model.load_state_dict(sd0)
+        model = model.to(DEV).eval()
+        with torch.no_grad():
+            return model(img[sl], clip[sl])
+    full = run01(slice(0, N))
+    for i in range(0, N, 4):
+        assert relerr(full[i:i + 4], run01(slice(i, i + 4))) <= 2e-5
 
 
 def test_drawn_dropout_masks_have_the_reference_distribution(ua):

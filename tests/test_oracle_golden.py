@@ -150,3 +150,38 @@ def test_clip_variant_restatement(golden):
     loss, logits, grads = O.train_step(osd, [None] * len(osd), img, tgt, masks, clip_features=clip)
     assert relerr(logits, torch.from_numpy(g["train_logits"])) <= 1e-5
     assert abs(loss.item() - float(g["loss_0"])) <= 1e-5 * abs(float(g["loss_0"]))
+
+
+METRIC_FIELDS = ("intersections", "unions", "true_positives", "false_positives", "false_negatives")
+
+
+def test_segmentation_metrics_restatement(golden):
+    """oracle.segmentation_metrics against the accumulators and scores recorded from the
+    reference's SegmentationMetrics (Our_UNet/utils/metrics.py:59-151): integer-exact counts,
+    identical quotients (nan where the reference returns nan), per batch and accumulated; the
+    stored predictions are torch.argmax of the stored logits (first maximum wins on ties)."""
+    g = golden("metrics")
+    preds, targets = [], []
+    for k in range(int(g["n_batches"])):
+        lg, t = torch.from_numpy(g[f"b{k}_logits"]), g[f"b{k}_target"]
+        p = lg.argmax(dim=1).numpy()
+        assert np.array_equal(p, g[f"b{k}_pred"])
+        r = O.segmentation_metrics([p], [t])
+        for f in METRIC_FIELDS:
+            assert np.array_equal(r[f], g[f"b{k}_{f}"]), (k, f)
+        assert r["total_pixels"] == int(g[f"b{k}_total_pixels"])
+        assert r["correct_pixels"] == int(g[f"b{k}_correct_pixels"])
+        for f in ("iou", "dice"):
+            assert np.array_equal(r[f], g[f"b{k}_{f}"], equal_nan=True), (k, f)
+        preds.append(p)
+        targets.append(t)
+    r = O.segmentation_metrics(preds, targets)
+    for f in METRIC_FIELDS:
+        assert np.array_equal(r[f], g[f"acc_{f}"]), f
+    for f in ("iou", "dice"):
+        assert np.array_equal(r[f], g[f"acc_{f}"], equal_nan=True)
+    for f in ("pixel_accuracy", "mean_iou", "mean_dice"):
+        assert r[f] == float(g[f"acc_{f}"])
+    # the fixture does contain the edge cases it claims
+    assert np.isnan(g["b0_iou"][2]) or g["b0_unions"][2] > 0
+    assert g["b0_true_positives"][2] == 0 and g["b1_true_positives"][1] == 0

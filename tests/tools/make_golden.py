@@ -23,6 +23,7 @@ from models.losses import SimpleLoss as RefLoss  # noqa: E402  (reference)
 from models.unet import ConvBlock as RefConvBlock  # noqa: E402
 from models.unet import UNet as RefUNet  # noqa: E402
 from models.unet import UpBlock as RefUpBlock  # noqa: E402
+from utils.metrics import SegmentationMetrics as RefMetrics  # noqa: E402  (numpy + torch only)
 
 from oracle import unet_ref as O  # noqa: E402
 
@@ -278,12 +279,76 @@ def slope1_run():
     print("net64_slope1.npz written, loss", loss.item())
 
 
+def metrics_run():
+    """SegmentationMetrics (Our_UNet/utils/metrics.py:7-235) on argmax predictions of synthetic
+    logits: two batches with exact logit ties, a class that never occurs in the targets, a class
+    that is never predicted, an all-ignored image and a 255 ring.  Records the logits / targets
+    and the reference's accumulators and derived scores, per case and accumulated."""
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    h, w = 24, 40
+    cases = []
+    # batch 0: random logits with ties; targets {0, 1, 255 ring}: class 2 absent from the labels
+    lg0 = torch.randn(3, 3, h, w, generator=g)
+    lg0[:, :, : h // 4] = lg0[:, :1, : h // 4]                    # three-way ties -> class 0
+    lg0[:, 2, h // 4: h // 2] = lg0[:, 1, h // 4: h // 2]         # 1/2 ties -> first maximum
+    t0 = torch.randint(0, 2, (3, h, w), generator=g)
+    t0[:, 5:9, 10:30] = 255
+    t0[1] = 255                                                   # an all-ignored image
+    cases.append((lg0, t0))
+    # batch 1: class 1 never predicted (its logit pushed down); all three classes labelled
+    lg1 = torch.randn(2, 3, h, w, generator=g)
+    lg1[:, 1] -= 100.0
+    t1 = torch.randint(0, 3, (2, h, w), generator=g)
+    t1[torch.rand(2, h, w, generator=g) < 0.1] = 255
+    cases.append((lg1, t1))
+    acc = RefMetrics(num_classes=3, ignore_index=255)
+    fields = ("intersections", "unions", "true_positives", "false_positives", "false_negatives")
+
+    def record(tag, m):
+        for f in fields:
+            out[f"{tag}_{f}"] = np.asarray(getattr(m, f), dtype=np.float64)
+        out[f"{tag}_total_pixels"] = np.int64(m.total_pixels)
+        out[f"{tag}_correct_pixels"] = np.int64(m.correct_pixels)
+        out[f"{tag}_pixel_accuracy"] = np.float64(m.compute_pixel_accuracy())
+        out[f"{tag}_iou"] = np.array([m.compute_iou(c) for c in range(3)])
+        out[f"{tag}_dice"] = np.array([m.compute_dice(c) for c in range(3)])
+        out[f"{tag}_precision"] = np.array([m.compute_precision(c) for c in range(3)])
+        out[f"{tag}_recall"] = np.array([m.compute_recall(c) for c in range(3)])
+        out[f"{tag}_mean_iou"] = np.float64(m.compute_mean_iou())
+        out[f"{tag}_mean_dice"] = np.float64(m.compute_mean_dice())
+
+    for k, (lg, t) in enumerate(cases):
+        pred = lg.argmax(dim=1)                  # what evaluate / validate feed the class
+        one = RefMetrics(num_classes=3, ignore_index=255)
+        one.update(pred, t)
+        acc.update(pred, t)
+        out[f"b{k}_logits"], out[f"b{k}_target"] = npf(lg), t.numpy().astype(np.int64)
+        out[f"b{k}_pred"] = pred.numpy().astype(np.uint8)
+        record(f"b{k}", one)
+        # the restatement agrees with the reference class
+        r = O.segmentation_metrics([pred.numpy()], [t.numpy()])
+        for f in fields:
+            assert np.array_equal(r[f], out[f"b{k}_{f}"]), f
+        assert np.array_equal(r["iou"], out[f"b{k}_iou"], equal_nan=True)
+        assert np.array_equal(r["dice"], out[f"b{k}_dice"], equal_nan=True)
+    record("acc", acc)
+    out["n_batches"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics.npz written: accumulated IoU", out["acc_iou"], "Dice", out["acc_dice"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-slope1", action="store_true")
     ap.add_argument("--skip-512", action="store_true")
     ap.add_argument("--only-clip", action="store_true")
+    ap.add_argument("--only-metrics", action="store_true")
     args = ap.parse_args()
+    if args.only_metrics:
+        os.makedirs(OUT, exist_ok=True)
+        metrics_run()
+        return
     if args.only_clip:
         os.makedirs(OUT, exist_ok=True)
         clip_run()
@@ -299,6 +364,7 @@ def main():
         net_run(512, 2, 3, "net512", full_logits=False)
     clip_run()
     slope1_run()
+    metrics_run()
 
 
 if __name__ == "__main__":

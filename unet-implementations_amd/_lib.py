@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(_HERE, "libunet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 7      # UNET_ABI_VERSION of include/unet_hip.h this binding was written against
+
 _c = ctypes
 _p = _c.c_void_p
 _i = _c.c_int
@@ -84,6 +86,7 @@ SIGNATURES = {
     "unet_dice_wce_loss_shard_stats": (_i, [_p, _p, _p, _p, _sz, _i, _i, _i, _f, _i, _p]),
     "unet_dice_wce_loss_shard_apply": (_i, [_p, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _i, _f, _f, _f,
                                             _i, _i, _p, _f, _p]),
+    "unet_dice_wce_loss_grad": (_i, [_p, _p, _p, _sz, _p, _p, _i, _i, _i, _i, _p]),
     "unet_argmax_dice_counts": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _p]),
     "unet_sgd_nesterov_step": (_i, [_p, _p, _p, _i64, _f, _f, _f, _i, _f, _p]),
@@ -199,7 +202,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if handle.unet_abi_version() != 6:
+    if handle.unet_abi_version() != ABI_VERSION:
         raise UNetHipError("libunet_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

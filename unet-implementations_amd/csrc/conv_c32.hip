@@ -1037,9 +1037,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
 
 }  // namespace
 
-// process-wide choice between the two forms of these layers (unet_set_c32_winograd)
+// choice between the two forms of these layers (unet_set_c32_winograd), per calling thread: the
+// host code sets it for its own calls, so two models on two threads (or autograd's backward
+// thread) cannot change each other's dispatch
 int& c32_winograd_flag() {
-  static int on = 1;
+  static thread_local int on = 1;
   return on;
 }
 

@@ -399,10 +399,14 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
                                                         const LossCoef* __restrict__ coef,
                                                         const float* __restrict__ dice_ab,
                                                         float* __restrict__ dlogits, int HW,
-                                                        int ignore_index) {
+                                                        int ignore_index,
+                                                        const float* __restrict__ upstream) {
   const int n = blockIdx.y;
   const float* z = logits + (size_t)n * 3 * HW;
   float* dz = dlogits + (size_t)n * 3 * HW;
+  // dL/d(loss) handed down by autograd (a device scalar; 1 for loss.backward()): applied to the
+  // finished gradient, i.e. the same rounding as a separate `dlogits *= g` pass
+  const float up = upstream ? upstream[0] : 1.f;
   const long long* tg = target + (size_t)n * HW;
   const float w0 = coef->w[0], w1 = coef->w[1], w2 = coef->w[2];
   const float iw = coef->inv_wsum, wd = coef->wdice;
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
       g1 += wd * p1 * (a1 - dot);
       g2 += wd * p2 * (a2 - dot);
     }
-    dz[p] = g0; dz[HW + p] = g1; dz[2 * HW + p] = g2;
+    dz[p] = g0 * up; dz[HW + p] = g1 * up; dz[2 * HW + p] = g2 * up;
   }
 }
 
@@ -653,9 +657,32 @@ extern "C" int unet_dice_wce_loss_fwd_bwd(const float* logits, const int64_t* ta
     if (gblocks < 1) gblocks = 1;
     hipLaunchKernelGGL(loss_grad_kernel, dim3(gblocks, N), dim3(256), 0, stream, logits,
                        reinterpret_cast<const long long*>(target), ws.coef, ws.dice_ab, dlogits, HW,
-                       ignore_index);
+                       ignore_index, nullptr);
     UNET_CHECK_LAUNCH("loss_grad");
   }
+  return UNET_OK;
+}
+
+extern "C" int unet_dice_wce_loss_grad(const float* logits, const int64_t* target,
+                                       const void* workspace, size_t workspace_bytes,
+                                       const float* upstream, float* dlogits, int N, int H, int W,
+                                       int ignore_index, unet_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  UNET_REQUIRE(logits && target && workspace && dlogits, "dice_wce_loss_grad: null pointer");
+  UNET_REQUIRE(N > 0 && N <= 1024 && H > 0 && W > 0, "dice_wce_loss_grad: bad shape");
+  if (workspace_bytes < loss_ws_layout(N, nullptr, nullptr)) {
+    unet_set_error("dice_wce_loss_grad: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  LossWs ws;
+  loss_ws_layout(N, &ws, reinterpret_cast<char*>(const_cast<void*>(workspace)));
+  const int HW = H * W;
+  int gblocks = ceil_div(HW, 256 * 4);
+  if (gblocks < 1) gblocks = 1;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(gblocks, N), dim3(256), 0, stream, logits,
+                     reinterpret_cast<const long long*>(target), ws.coef, ws.dice_ab, dlogits, HW,
+                     ignore_index, upstream);
+  UNET_CHECK_LAUNCH("loss_grad");
   return UNET_OK;
 }
 
@@ -738,7 +765,7 @@ extern "C" int unet_dice_wce_loss_shard_apply(const float* logits, const int64_t
     if (gblocks < 1) gblocks = 1;
     hipLaunchKernelGGL(loss_grad_kernel, dim3(gblocks, N), dim3(256), 0, stream, logits,
                        reinterpret_cast<const long long*>(target), ws.coef, ws.dice_ab, dlogits, HW,
-                       ignore_index);
+                       ignore_index, nullptr);
     UNET_CHECK_LAUNCH("loss_grad");
   }
   return UNET_OK;

@@ -46,11 +46,17 @@ __device__ __forceinline__ void lds_wait(f32x2v& a, f32x2v& b, f32x2v& c, f32x2v
 // (M0 has no other user in these kernels: gfx9 LDS instructions do not read it; the s_nop is the
 // wait state between an SALU write of M0 and an LDS-DMA instruction, which nothing inserts inside
 // an asm block.  No register output: the DMA is behind the s_waitcnt vmcnt at the chunk barrier.)
+// M0 is on the clobber list so that the compiler knows the asm rewrites it (it is a reserved
+// register: clang warns that it will not PRESERVE it across the statement, which is exactly what
+// is meant here - nothing may assume an older M0 value survives; hence the pragma).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <int OFF>
 __device__ __forceinline__ void dma16_sbase(unsigned m0v, unsigned lane_off, const float* sbase) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
-               :: "s"(m0v), "v"(lane_off), "s"(sbase), "n"(OFF) : "memory");
+               :: "s"(m0v), "v"(lane_off), "s"(sbase), "n"(OFF) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ void reg_anchor(f32x4& a, f32x4& b) {
   asm volatile("" : "+v"(a), "+v"(b) :: "memory");
 }

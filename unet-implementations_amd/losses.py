@@ -13,6 +13,10 @@ from . import ops
 
 
 class _LossFunction(torch.autograd.Function):
+    """Forward: the loss value and, in the workspace, the class weights / Dice coefficients the
+    gradient needs.  Backward: ONE launch of the gradient kernel with autograd's upstream scalar
+    applied inside it (`unet_dice_wce_loss_grad`) - no stock-torch scaling pass over dlogits."""
+
     @staticmethod
     def forward(ctx, logits, target, mod, class_weights):
         want_grad = ctx.needs_input_grad[0]
@@ -21,26 +25,27 @@ class _LossFunction(torch.autograd.Function):
             import torch.distributed as dist
             stats, ws = ops.dice_wce_loss_shard_stats(logits, target, mod.smooth, mod.ignore_index)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=mod.process_group)
-            out, dl = ops.dice_wce_loss_shard_apply(
+            out, _ = ops.dice_wce_loss_shard_apply(
                 logits, target, stats, logits.shape[0] * world, ws, mod.smooth, mod.weight_dice,
                 mod.weight_ce, mod.ignore_index, mod.dynamic_weights, class_weights=class_weights,
-                grad_scale=mod.grad_scale, want_grad=want_grad)
-            ctx.dl = dl
-            mod.last_terms = out
-            return out[0].clone()
-        out, dl = ops.dice_wce_loss_fwd_bwd(
-            logits, target, mod.smooth, mod.weight_dice, mod.weight_ce, mod.ignore_index,
-            mod.dynamic_weights, class_weights=class_weights, grad_scale=mod.grad_scale,
-            want_grad=want_grad)
-        ctx.dl = dl
+                grad_scale=mod.grad_scale, want_grad=False)
+        else:
+            ws = ops.dice_wce_loss_workspace(logits)
+            out, _ = ops.dice_wce_loss_fwd_bwd(
+                logits, target, mod.smooth, mod.weight_dice, mod.weight_ce, mod.ignore_index,
+                mod.dynamic_weights, class_weights=class_weights, grad_scale=mod.grad_scale,
+                want_grad=False, ws=ws)
+        if want_grad:
+            ctx.held = (logits, target, ws, mod.ignore_index)
         mod.last_terms = out  # [total, ce, dice, w0, w1, w2, -, -] on device (no sync)
         return out[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        dl = ctx.dl
-        ctx.dl = None
-        return dl.mul_(g), None, None, None  # g is the 0-dim upstream gradient (1 for loss.backward())
+        logits, target, ws, ignore_index = ctx.held
+        ctx.held = None
+        # g is the 0-dim upstream gradient (1 for loss.backward()), read on the device
+        return ops.dice_wce_loss_grad(logits, target, ws, g, ignore_index), None, None, None
 
 
 class SimpleLoss(nn.Module):

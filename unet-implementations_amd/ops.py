@@ -282,13 +282,44 @@ def _c32_winograd(N, H, W, Cin, Cout, stride):
     return bool(lib().unet_conv_c32_is_winograd(N, H, W, Cin, Cout, stride))
 
 
-def set_c32_winograd(on):
-    """Process-wide choice for the 32 -> 32 channel stride-1 layers on the fused fp32 pipeline:
-    True (default) = the Winograd kernel for launches that fill the chip (>= 512 tiles of 8 x 32
-    pixels), "always" = for every shape it tiles, False = the direct kernel.  Returns the previous
-    setting in the same terms."""
+_c32_override = None
+
+
+def c32_winograd_override():
+    """The setting a direct `set_c32_winograd(...)` call left behind (tests, benchmarks), or None."""
+    return _c32_override
+
+
+class c32_winograd_scope:
+    """`with c32_winograd_scope(mode):` - the calling thread's switch set to `mode` (True /
+    False / "always") for the block and put back afterwards: how UNet.forward / backward pass
+    their model's choice to the entry points they call without leaving it behind."""
+
+    def __init__(self, mode):
+        self.code = 2 if mode == "always" else (1 if mode else 0)
+
+    def __enter__(self):
+        self.prev = lib().unet_set_c32_winograd(self.code)
+        return self
+
+    def __exit__(self, *exc):
+        lib().unet_set_c32_winograd(self.prev)
+        return False
+
+
+def set_c32_winograd(on, override=True):
+    """Choice for the 32 -> 32 channel stride-1 layers on the fused fp32 pipeline: True (default)
+    = the Winograd kernel for launches that fill the chip (>= 512 tiles of 8 x 32 pixels),
+    "always" = for every shape it tiles, False = the direct kernel.  Returns the previous setting
+    of the calling thread in the same terms.  The library keeps the switch PER THREAD;
+    `UNet.forward` applies `model.winograd` to its own calls only (`c32_winograd_scope`) and
+    hands the decision to its backward.  A direct call (override=True) is a test / benchmark
+    override for kernel-level calls: "always" then also wins over `model.winograd`."""
+    global _c32_override
     code = 2 if on == "always" else (1 if on else 0)
     prev = lib().unet_set_c32_winograd(code)
+    if override:
+        _c32_override = on if on == "always" else None
     return "always" if prev == 2 else bool(prev)
 
 
@@ -933,18 +964,40 @@ def head1x1_bwd(a, dlogits, w, dw, db):
 
 
 def dice_wce_loss_fwd_bwd(logits, target, smooth, w_dice, w_ce, ignore_index, dynamic_weights,
-                          class_weights=None, grad_scale=1.0, want_grad=True):
+                          class_weights=None, grad_scale=1.0, want_grad=True, ws=None):
+    """ws: a caller-kept workspace (dice_wce_loss_workspace) - needed when the gradient is taken
+    later with dice_wce_loss_grad (want_grad=False here)."""
     N, K, H, W = logits.shape
     if K != 3:
         raise ValueError("the fused loss kernel handles exactly 3 classes")
     out = _f32((8,), logits)
     dl = torch.empty_like(logits) if want_grad else None
-    ws = _ws(lib().unet_dice_wce_loss_workspace_bytes(N, H, W), logits)
+    if ws is None:
+        ws = _ws(lib().unet_dice_wce_loss_workspace_bytes(N, H, W), logits)
     check(lib().unet_dice_wce_loss_fwd_bwd(_ptr(logits), _ptr(target), _ptr(out), _ptr(dl),
                                            _ptr(ws), ws.numel(), N, H, W, smooth, w_dice, w_ce,
                                            ignore_index, 1 if dynamic_weights else 0,
                                            _ptr(class_weights), grad_scale, _stream()))
     return out, dl
+
+
+def dice_wce_loss_workspace(logits):
+    N, K, H, W = logits.shape
+    return _ws(lib().unet_dice_wce_loss_workspace_bytes(N, H, W), logits)
+
+
+def dice_wce_loss_grad(logits, target, ws, upstream, ignore_index):
+    """dL/dlogits of a loss whose forward ran with want_grad=False on the workspace `ws`
+    (dice_wce_loss_fwd_bwd(..., ws=ws) or dice_wce_loss_shard_apply): upstream (a device float,
+    dL/dloss from autograd, or None = 1) is applied inside the gradient kernel."""
+    N, K, H, W = logits.shape
+    dl = torch.empty_like(logits)
+    if upstream is not None:
+        upstream = upstream.reshape(1).float().contiguous()
+    check(lib().unet_dice_wce_loss_grad(_ptr(logits), _ptr(target), _ptr(ws), ws.numel(),
+                                        _ptr(upstream), _ptr(dl), N, H, W, ignore_index,
+                                        _stream()))
+    return dl
 
 
 def dice_wce_loss_shard_stats(logits, target, smooth, ignore_index):

@@ -35,13 +35,16 @@ class FusedSGD(torch.optim.Optimizer):
 
     def use_device_hyper(self, on=True):
         """Make the flat-arena step read its hyper-parameters from device memory, so that a step
-        captured in a HIP graph follows later changes of `param_groups[0]['lr']` (LR schedule)."""
+        captured in a HIP graph follows later changes of `param_groups[0]['lr']` (LR schedule).
+        The device tensor is created once and kept: a graph captured earlier keeps reading the
+        same address when a second GraphedTrainStep is built on this optimizer."""
         if not on:
             self._hyper = self._hyper_host = None
             return
-        arena, _ = self._model.flat_parameters()
-        self._hyper = torch.zeros(4, dtype=torch.float32, device=arena.device)
-        self._hyper_host = None
+        if self._hyper is None:
+            arena, _ = self._model.flat_parameters()
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=arena.device)
+            self._hyper_host = None
         self.sync_device_hyper()
 
     def sync_device_hyper(self):
@@ -76,6 +79,31 @@ class FusedSGD(torch.optim.Optimizer):
         self._flat_buf = None      # adopt the loaded momentum buffers on the next step
 
     @torch.no_grad()
+    def adopt_flat_momentum(self):
+        """Build the flat momentum arena (one buffer aliased by every state[p]['momentum_buffer'])
+        without taking a step.  Buffers that already exist - a checkpoint loaded through
+        load_state_dict - are copied in.  Returns True when none existed (zero momentum: the next
+        step is torch SGD's "first step", buf <- g).  No-op (returns None) once the arena exists."""
+        if self._flat_buf is not None:
+            return None
+        m = self._model
+        g = self.param_groups[0]
+        arena, _ = m.flat_parameters()
+        if len(self.param_groups) != 1 or len(g["params"]) != len(m._offsets):
+            raise RuntimeError("the flat momentum arena needs one parameter group holding every "
+                               "parameter of the model")
+        self._flat_buf = torch.zeros_like(arena)
+        fresh = True
+        for p, off in zip(g["params"], m._offsets):
+            st = self.state[p]
+            if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                # resumed from a checkpoint: adopt the loaded buffers
+                self._flat_buf[off:off + p.numel()].view_as(p).copy_(st["momentum_buffer"])
+                fresh = False
+            st["momentum_buffer"] = self._flat_buf[off:off + p.numel()].view_as(p)
+        return fresh
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -94,17 +122,12 @@ class FusedSGD(torch.optim.Optimizer):
         if flat:
             g = self.param_groups[0]
             arena, garena = self._model.flat_parameters()
-            first = self._flat_buf is None
-            if first:
-                self._flat_buf = torch.zeros_like(arena)
-                for p, off in zip(g["params"], self._model._offsets):
-                    st = self.state[p]
-                    if "momentum_buffer" in st and st["momentum_buffer"] is not None:
-                        # resumed from a checkpoint: adopt the loaded buffers
-                        self._flat_buf[off:off + p.numel()].view_as(p).copy_(st["momentum_buffer"])
-                        first = False
-                    st["momentum_buffer"] = self._flat_buf[off:off + p.numel()].view_as(p)
+            first = bool(self.adopt_flat_momentum())
             if self._hyper is not None:
+                # (an eager step after a GraphedTrainStep was built - a last batch of another
+                # shape, a data-parallel path that sets grad_scale - must not run on stale
+                # values; no-op when nothing changed, so also inside a capture)
+                self.sync_device_hyper()
                 ops.sgd_nesterov_step_dev(arena, garena, self._flat_buf, self._hyper, first)
             else:
                 ops.sgd_nesterov_step(arena, garena, self._flat_buf, g["lr"], g["momentum"],

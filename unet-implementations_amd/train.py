@@ -73,25 +73,44 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, optimizer, loss_function, images, masks)
         loss = step(images, masks)        # device scalar, no host sync
 
+    Data parallel: pass the model's `ddp.GradBucketAllReduce` as `grad_sync`.  Its bucketed
+    all-reduces are issued from the backward hooks while the step is being captured, so with
+    backend "nccl" (RCCL) they become nodes of the graph on RCCL's stream - forked from the
+    backward kernels where a bucket becomes final and joined before the SGD launch, exactly the
+    overlap of the eager step - and every rank replays its step with one host call.  The gloo
+    backend runs its collectives on the host and cannot be captured: use `train_step` there.
+
     Capturing runs `warmup` throw-away steps first (kernel attributes, workspaces, the packing
-    table); parameters, momentum and the step counter are restored afterwards.  The bucketed
-    all-reduce hook of ddp.GradBucketAllReduce is not captured: use the eager `train_step` there.
+    table, RCCL's communicator); parameters, momentum - including momentum just loaded from a
+    checkpoint - and the step counter are restored afterwards.
     """
 
-    def __init__(self, model, optimizer, loss_function, images, masks, warmup=2):
+    def __init__(self, model, optimizer, loss_function, images, masks, warmup=2, grad_sync=None):
         if not images.is_cuda:
             raise RuntimeError("GraphedTrainStep needs ROCm tensors (no CPU fallback exists)")
-        if model.grad_ready_hook is not None:
-            raise RuntimeError("the data-parallel gradient hook cannot be captured in a graph")
         if not isinstance(optimizer, FusedSGD):
             raise TypeError("GraphedTrainStep needs the FusedSGD optimizer")
+        if grad_sync is None and model.grad_ready_hook is not None:
+            raise RuntimeError("the model has a data-parallel gradient hook: pass its "
+                               "GradBucketAllReduce as grad_sync so the exchange is captured")
+        finish = None
+        if grad_sync is not None:
+            import torch.distributed as dist
+            backend = dist.get_backend(getattr(grad_sync, "group", None))
+            if backend != "nccl":
+                raise RuntimeError(f"the '{backend}' backend runs its collectives on the host and "
+                                   "cannot be captured in a HIP graph: use train_step (eager)")
+            finish = grad_sync.finish
         self.model, self.optimizer, self.loss_function = model, optimizer, loss_function
+        self.grad_sync = grad_sync
         self.images = images.detach().clone()
         self.masks = masks.detach().clone()
         arena, _ = model.flat_parameters()
         keep_arena = arena.detach().clone()
-        had_buf = optimizer._flat_buf is not None
-        keep_buf = optimizer._flat_buf.detach().clone() if had_buf else None
+        # the momentum the optimizer holds NOW (zeros for a fresh one, the loaded buffers after
+        # load_state_dict) is what the first replay must start from
+        optimizer.adopt_flat_momentum()
+        keep_buf = optimizer._flat_buf.detach().clone()
         keep_steps = optimizer._steps
         optimizer.use_device_hyper(True)
         cur = torch.cuda.current_stream()
@@ -99,18 +118,17 @@ class GraphedTrainStep:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                train_step(model, optimizer, loss_function, self.images, self.masks)
+                train_step(model, optimizer, loss_function, self.images, self.masks,
+                           grad_sync=finish)
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = train_step(model, optimizer, loss_function, self.images, self.masks)
+            self.loss = train_step(model, optimizer, loss_function, self.images, self.masks,
+                                   grad_sync=finish)
         # undo the throw-away steps (the captured step itself did not execute)
         with torch.no_grad():
             arena.copy_(keep_arena)
-            if had_buf:
-                optimizer._flat_buf.copy_(keep_buf)
-            else:      # zero momentum == "first step" of torch's SGD (buf <- g)
-                optimizer._flat_buf.zero_()
+            optimizer._flat_buf.copy_(keep_buf)
         optimizer._steps = keep_steps
 
     def __call__(self, images, masks):

@@ -89,8 +89,11 @@ class ConvBlock(nn.Module):
         self.block = nn.Sequential(*mods)
 
     def forward(self, x):
-        raise NotImplementedError(
-            "ConvBlock only holds parameters here; call UNet.forward (the fused HIP path)")
+        """The block on its own (reference: Our_UNet/models/unet.py:136-141 `self.block(x)`):
+        NCHW fp32 in, NCHW fp32 out, differentiable.  Inside `UNet.forward` the blocks are never
+        called - the network runs as one fused walk; a stand-alone call runs the same HIP entry
+        points layer by layer (conv -> statistics -> InstanceNorm + LeakyReLU + dropout)."""
+        return _run_block_standalone(self, x, None)
 
 
 class UpBlock(nn.Module):
@@ -110,8 +113,126 @@ class UpBlock(nn.Module):
                                     spatial_dropout_rate=spatial_dropout_rate)
 
     def forward(self, x, skip):
-        raise NotImplementedError(
-            "UpBlock only holds parameters here; call UNet.forward (the fused HIP path)")
+        """Bilinear 2x up-sampling of `x` to the skip's size, cat([up, skip]), conv block
+        (reference: Our_UNet/models/unet.py:203-231), stand-alone and differentiable; NCHW fp32.
+        The HIP up-sampling kernel is the exact-2x stencil the network uses."""
+        return _run_block_standalone(self.conv_block, x, skip)
+
+
+def _run_block_standalone(block, x, skip):
+    if not x.is_cuda:
+        raise RuntimeError("unet-implementations_amd blocks run on MI355X only: move the module "
+                           "and the input to a ROCm device (no CPU fallback exists)")
+    if x.dim() != 4 or (skip is not None and skip.dim() != 4):
+        raise ValueError("expected NCHW tensors")
+    if skip is not None and (skip.shape[2] != 2 * x.shape[2] or skip.shape[3] != 2 * x.shape[3]):
+        raise NotImplementedError("UpBlock on the HIP path up-samples by exactly 2x")
+    layers = _parse_block(block, False, type(block).__name__)
+    params = [q for l in layers for q in (l.conv.weight, l.conv.bias, l.norm.weight, l.norm.bias)]
+    return _BlockFunction.apply(block, layers, x, skip, *params)
+
+
+class _BlockFunction(torch.autograd.Function):
+    """One ConvBlock (optionally behind up-sample + concat) through the stand-alone entry points:
+    what `UNet(fused_pipeline=False)` runs per layer."""
+
+    @staticmethod
+    def forward(ctx, block, layers, x, skip, *params):
+        x0 = ops.nchw_to_nhwc(x.detach().contiguous().float())
+        x1 = None
+        if skip is not None:
+            x0 = ops.upsample2x_fwd(x0)
+            x1 = ops.nchw_to_nhwc(skip.detach().contiguous().float())
+        override = getattr(block, "dropout_mask_override", None)
+        masks = iter(override) if override is not None else None
+        recs = []
+        for l in layers:
+            w = l.conv.weight.detach()
+            if w.shape[0] % 32:
+                raise NotImplementedError("the HIP convolution needs Cout % 32 == 0")
+            wf, wd = ops.pack_conv3x3_weights(w.contiguous())
+            y = ops.conv3x3_fwd(x0, x1, wf, l.conv.bias.detach(), l.stride)
+            st = ops.instnorm_stats(y, l.norm.weight.detach(), l.norm.bias.detach(), l.norm.eps)
+            m = None
+            if l.drop is not None and l.drop.drop_prob > 0:
+                if masks is not None:
+                    m = next(masks).to(device=y.device, dtype=torch.float32).contiguous()
+                elif block.training:
+                    m = l.drop.draw_mask(y.shape[0], y.shape[3], y.device).contiguous()
+            a = ops.instnorm_lrelu_drop_fwd(y, st[2], st[3], m, l.slope)
+            recs.append((l, x0, x1, y, st, m, wd))
+            x0, x1 = a, None
+        ctx.recs, ctx.up = recs, skip is not None
+        return ops.nhwc_to_nchw(x0)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ops.nchw_to_nhwc(gout.contiguous().float())
+        grads = []
+        dx1 = None
+        for l, x0, x1, y, st, m, wd in reversed(ctx.recs):
+            C = y.shape[3]
+            dgm, dbt, dbias = (torch.empty(C, device=y.device) for _ in range(3))
+            dy = ops.instnorm_lrelu_drop_bwd(g, y, st[0], st[1], l.norm.weight.detach(),
+                                             l.norm.bias.detach(), m, l.slope, dgm, dbt, dbias)
+            dw = torch.empty_like(l.conv.weight)
+            ops.conv3x3_bwd_weight(x0, dy, dw, 0, l.stride)
+            N, H, W, C0 = x0.shape
+            if x1 is not None:
+                ops.conv3x3_bwd_weight(x1, dy, dw, C0, l.stride)
+                dx1 = ops.conv3x3_bwd_data(dy, wd, C0, x1.shape[3], H, W, l.stride)
+            first = l is ctx.recs[0][0]
+            if first and not ctx.needs_input_grad[2]:
+                g = None
+            elif C0 % 32:
+                raise NotImplementedError("the HIP data gradient needs a multiple of 32 input "
+                                          "channels (the RGB stem's input gets no gradient)")
+            else:
+                g = ops.conv3x3_bwd_data(dy, wd, 0, C0, H, W, l.stride)
+            grads = [dw, dbias, dgm, dbt] + grads
+        ctx.recs = None
+        gx = None
+        if g is not None:
+            gx = ops.nhwc_to_nchw(ops.upsample2x_bwd(g) if ctx.up else g)
+        gskip = ops.nhwc_to_nchw(dx1) if dx1 is not None else None
+        return (None, None, gx, gskip, *grads)
+
+
+def _parse_block(block, first_of_decoder, prefix):
+    """[Conv2d -> InstanceNorm2d(affine) -> LeakyReLU -> SpatialDropout2d?] x n of a ConvBlock as
+    `_Layer`s; raises NotImplementedError for anything the HIP path does not cover."""
+    mods = list(block.block)
+    layers, i = [], 0
+    while i < len(mods):
+        conv = mods[i]
+        if not isinstance(conv, nn.Conv2d):
+            raise NotImplementedError(f"{prefix}: unexpected module {type(conv).__name__}")
+        ks, st = _as_int(conv.kernel_size), _as_int(conv.stride)
+        if ks != 3 or st not in (1, 2) or _as_int(conv.padding) != 1 or conv.bias is None \
+                or conv.groups != 1 or _as_int(conv.dilation) != 1:
+            raise NotImplementedError(
+                f"{prefix}.block.{i}: the HIP path covers 3x3/pad 1/stride 1|2 convs with bias")
+        i += 1
+        norm = mods[i] if i < len(mods) else None
+        if not (isinstance(norm, nn.InstanceNorm2d) and norm.affine
+                and not norm.track_running_stats):
+            raise NotImplementedError(
+                f"{prefix}: the HIP path needs InstanceNorm2d(affine=True) after each conv")
+        i += 1
+        act = mods[i] if i < len(mods) else None
+        if not isinstance(act, nn.LeakyReLU):
+            raise NotImplementedError(f"{prefix}: the HIP path needs LeakyReLU after the norm")
+        i += 1
+        drop = None
+        if i < len(mods) and isinstance(mods[i], SpatialDropout2d):
+            drop = mods[i]
+            i += 1
+        if i < len(mods) and not isinstance(mods[i], nn.Conv2d):
+            raise NotImplementedError(
+                f"{prefix}: dropout_op={type(mods[i]).__name__} is not on the HIP path")
+        layers.append(_Layer(conv, norm, float(act.negative_slope), drop, st,
+                             first_of_decoder and not layers, f"{prefix}.block.{len(layers)}"))
+    return layers
 
 
 class _Layer:
@@ -241,38 +362,7 @@ class UNet(nn.Module):
 
     # -- fused-plan construction -------------------------------------------------------------
     def _block_layers(self, block, first_of_decoder, prefix):
-        mods = list(block.block)
-        layers, i = [], 0
-        while i < len(mods):
-            conv = mods[i]
-            if not isinstance(conv, nn.Conv2d):
-                raise NotImplementedError(f"{prefix}: unexpected module {type(conv).__name__}")
-            ks, st = _as_int(conv.kernel_size), _as_int(conv.stride)
-            if ks != 3 or st not in (1, 2) or _as_int(conv.padding) != 1 or conv.bias is None \
-                    or conv.groups != 1 or _as_int(conv.dilation) != 1:
-                raise NotImplementedError(
-                    f"{prefix}.block.{i}: the HIP path covers 3x3/pad 1/stride 1|2 convs with bias")
-            i += 1
-            norm = mods[i] if i < len(mods) else None
-            if not (isinstance(norm, nn.InstanceNorm2d) and norm.affine
-                    and not norm.track_running_stats):
-                raise NotImplementedError(
-                    f"{prefix}: the HIP path needs InstanceNorm2d(affine=True) after each conv")
-            i += 1
-            act = mods[i] if i < len(mods) else None
-            if not isinstance(act, nn.LeakyReLU):
-                raise NotImplementedError(f"{prefix}: the HIP path needs LeakyReLU after the norm")
-            i += 1
-            drop = None
-            if i < len(mods) and isinstance(mods[i], SpatialDropout2d):
-                drop = mods[i]
-                i += 1
-            if i < len(mods) and not isinstance(mods[i], nn.Conv2d):
-                raise NotImplementedError(
-                    f"{prefix}: dropout_op={type(mods[i]).__name__} is not on the HIP path")
-            layers.append(_Layer(conv, norm, float(act.negative_slope), drop, st,
-                                 first_of_decoder and not layers, f"{prefix}.block.{len(layers)}"))
-        return layers
+        return _parse_block(block, first_of_decoder, prefix)
 
     def _build_plan(self):
         enc = [self._block_layers(b, False, f"encoder_stages.{i}")
@@ -390,6 +480,7 @@ class UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of {1 << n_down} and >= {2 << n_down}")
         if self._plan is None:
             self._build_plan()
+        self._check_hooks()
         params = list(self.parameters())
         self._ensure_arena(params)
         self._param_index = {id(p): i for i, p in enumerate(params)}
@@ -400,6 +491,31 @@ class UNet(nn.Module):
         else:
             x_nhwc = ops.nchw_to_nhwc(x.contiguous().float())
         return _UNetFunction.apply(self, x_nhwc, self._bottleneck_input(x, extra), *params)
+
+    def _check_hooks(self):
+        """The fused walk fires hooks of the stage-level modules only (encoder_stages[i],
+        decoder_stages[i], its conv_block, segmentation_output, the model itself).  A hook on any
+        other sub-module (an inner Conv2d / norm / activation, a `.block` Sequential - the
+        reference's Grad-CAM helper accepts any target layer, Our_UNet/utils/visualize.py:
+        401-402) would never fire: raise instead of letting the caller fail later on a missing
+        feature map."""
+        inner = self.__dict__.get("_inner_modules")
+        if inner is None:
+            ok = {id(self), id(self.segmentation_output), id(self.encoder_stages),
+                  id(self.decoder_stages)}
+            ok.update(id(m) for m in self.encoder_stages)
+            for d in self.decoder_stages:
+                ok.update((id(d), id(d.conv_block)))
+            inner = self.__dict__["_inner_modules"] = [
+                (n, m) for n, m in self.named_modules() if id(m) not in ok]
+        for name, m in inner:
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or \
+                    m._backward_pre_hooks:
+                raise NotImplementedError(
+                    f"a hook is registered on {name}: the fused HIP walk never calls inner "
+                    "modules, so it would not fire.  Hook a stage-level module instead "
+                    "(encoder_stages[i], decoder_stages[i], decoder_stages[i].conv_block, "
+                    "segmentation_output).")
 
     def _bottleneck_input(self, x, extra):
         """Second source of the bottleneck fusion layer (NHWC) or None; CLIPUNet overrides."""
@@ -477,6 +593,23 @@ def _fire_backward_hooks(mods, make_grad):
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, extra, *params):
+        # The 32-channel layers' kernel choice is made HERE, applied to this walk's calls only and
+        # saved for the backward walk (which may run on autograd's own thread, after other
+        # models ran): the library's switch is per calling thread.
+        c32_mode = "always" if ops.c32_winograd_override() == "always" else bool(model.winograd)
+        with ops.c32_winograd_scope(c32_mode):
+            logits = _UNetFunction._forward(ctx, model, x, extra, params)
+        if any(ctx.needs_input_grad):
+            ctx.c32_mode = c32_mode
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        with ops.c32_winograd_scope(ctx.c32_mode):       # the forward's decision
+            return _UNetFunction._backward(ctx, dlogits)
+
+    @staticmethod
+    def _forward(ctx, model, x, extra, params):
         enc, dec = model._plan
         fusion = model._fusion_layer if extra is not None else None
         layers = [l for blk in enc for l in blk] + ([fusion] if fusion is not None else []) + \
@@ -509,8 +642,6 @@ class _UNetFunction(torch.autograd.Function):
                 wino.append((s1 and co % 64 == 0 and ci % 8 == 0,
                              s1 and ci % 64 == 0 and co % 8 == 0))
         # (the 32 -> 32 channel layers' Winograd form needs no weight form of its own: a switch)
-        if ops.set_c32_winograd(bool(model.winograd)) == "always":   # (a test's override stays)
-            ops.set_c32_winograd("always")
         table = model.__dict__.get("_pack_table")
         # (the bf16 planes: all three terms in the split mode; in the mixed-precision mode their
         # first plane is the bf16-rounded weight the patch kernels stage without a conversion)
@@ -682,7 +813,7 @@ class _UNetFunction(torch.autograd.Function):
         return logits
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def _backward(ctx, dlogits):
         model, saved, params = ctx.model, ctx.saved, ctx.params
         enc, dec = model._plan
         gv = model._grad_view
