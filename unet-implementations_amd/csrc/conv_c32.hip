@@ -467,10 +467,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
     }
   };
 
-  const float* const a_src = Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk;   // + j * 16 * VP + 8 q
-  float* const z_dst = Zs + (wave * 2) * 512 + lane;                         // + b * 512 + r * 128 + nb * 64
-  // row pass + epilogue: wave -> slots with r = wave; lane (li, lh) -> column li, k = 2 lh + e
-  const float* const z_src = Zs + wave * 128 + (li >> 4) * 64 + 32 * lh + (li & 15);   // + e * 16 + (i * 2 + b) * 512
+  const unsigned a_addr = lds_addr(Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk);   // + j * 16 * VP + 8 q
+  // Exchange Z[xi row][b][r][tile group fk][column c32 ^ 16 (fk & 1)] (c32 = 16 nb + fn): the
+  // readers (column li of tile group 2 lh + e) then read 32 consecutive floats per half wave -
+  // conflict-free; the first layout ([nb][fk][fn]) put columns li and li + 16 on the same bank
+  // (2-way on every read).  The writers' half waves (fk = 0, 1) land on the two halves of the
+  // banks thanks to the XOR - conflict-free as well.
+  float* const z_dst0 = Zs + (wave * 2) * 512 + fk * 32 + (fn + 16 * (fk & 1));         // nb = 0
+  float* const z_dst1 = Zs + (wave * 2) * 512 + fk * 32 + (fn + 16 * (1 - (fk & 1)));   // nb = 1; + b * 512 + r * 128
+  // row pass + epilogue: wave -> slots with r = wave; lane (li, lh) -> column li, fk = 2 lh + e
+  const float* const z_src0 = Zs + wave * 128 + 64 * lh + li;                 // e = 0; + (i * 2 + b) * 512
+  const float* const z_src1 = Zs + wave * 128 + 64 * lh + 32 + (li ^ 16);     // e = 1
   const int o_ty = wave >> 1, o_tx0 = 4 * (wave & 1) + 2 * lh;
   const bool summaries = FUSED ? p.stats != nullptr : p.bs_partial != nullptr;   // uniform
   const float bv = (FUSED && p.bias) ? p.bias[li] : 0.f;
@@ -527,11 +534,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
       __syncthreads();
       f32x4 acc[4][2];
       f32x2w af[2][4];
+      // hand-issued ds_read_b64 (lds_asm.h): left to the compiler, the reads of q and q + 1 fuse
+      // into ds_read2_b64, which the LDS serves in 16-lane groups over 32 banks - rows fn and
+      // fn + 8 of the 36-float pitch then collide (2-way) and the instruction takes 8 array
+      // cycles where two plain reads take 4 (the 0.27 conflict cycles per active LDS cycle of
+      // the round-3 PMC table)
       auto frag = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          af[q & 1][j] = *reinterpret_cast<const f32x2w*>(a_src + j * 16 * W32_VP + 8 * q);
+        for_range_c<0, 4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          af[q & 1][j] = lds_rd64<(j * 16 * W32_VP + 8 * q) * 4>(a_addr);
+        });
       };
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -541,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
       for_range_c<0, 4>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         if constexpr (q + 1 < 4) frag(std::integral_constant<int, q + 1>{});
+        lds_wait<(q + 1 < 4 ? 4 : 0)>(af[q & 1][0], af[q & 1][1], af[q & 1][2], af[q & 1][3]);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -556,8 +570,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
-          z_dst[r * 128 + nb * 64] = m0 + (m1 + m2);
-          z_dst[512 + r * 128 + nb * 64] = (m1 - m2) - m3;
+          float* const zd = nb == 0 ? z_dst0 : z_dst1;
+          zd[r * 128] = m0 + (m1 + m2);
+          zd[512 + r * 128] = (m1 - m2) - m3;
         }
       // the next unit's patch (in the registers since the top of this unit): its buffer was last
       // read by this unit's transform, one barrier back, and is next read behind the one below
@@ -577,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino32q_kernel(const IgemmParams 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) z[i][b] = z_src[e * 16 + (i * 2 + b) * 512];
+          for (int b = 0; b < 2; ++b) z[i][b] = (e == 0 ? z_src0 : z_src1)[(i * 2 + b) * 512];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           ov[4 * e + b] = z[0][b] + (z[1][b] + z[2][b]);
@@ -896,9 +911,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
       *reinterpret_cast<f32x2v*>(dst + 3 * 16 * W32_VP) = w1 - w3;
     }
   };
-  const float* const a_src = Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk;
-  float* const z_dst = Zs + (wave * 2) * 512 + lane;
-  const float* const z_src = Zs + wave * 128 + (li >> 4) * 64 + 32 * lh + (li & 15);
+  const unsigned a_addr = lds_addr(Vs + (4 * wave * 16 + fn) * W32_VP + 2 * fk);
+  // (the exchange layout of conv_wino32q_kernel: conflict-free on both sides)
+  float* const z_dst0 = Zs + (wave * 2) * 512 + fk * 32 + (fn + 16 * (fk & 1));
+  float* const z_dst1 = Zs + (wave * 2) * 512 + fk * 32 + (fn + 16 * (1 - (fk & 1)));
+  const float* const z_src0 = Zs + wave * 128 + 64 * lh + li;
+  const float* const z_src1 = Zs + wave * 128 + 64 * lh + 32 + (li ^ 16);
   const int o_ty = wave >> 1, o_tx0 = 4 * (wave & 1) + 2 * lh;
   const float bv = p.bias ? p.bias[li] : 0.f;
 
@@ -944,16 +962,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
         if constexpr (c < 2) transform_up(yu, xu); else transform();
         __syncthreads();
         f32x2w af[2][4];
-        auto frag = [&](auto qc) {
+        auto frag = [&](auto qc) {   // hand-issued ds_read_b64: see conv_wino32q_kernel
           constexpr int q = decltype(qc)::value;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            af[q & 1][j] = *reinterpret_cast<const f32x2w*>(a_src + j * 16 * W32_VP + 8 * q);
+          for_range_c<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            af[q & 1][j] = lds_rd64<(j * 16 * W32_VP + 8 * q) * 4>(a_addr);
+          });
         };
         frag(std::integral_constant<int, 0>{});
         for_range_c<0, 4>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           if constexpr (q + 1 < 4) frag(std::integral_constant<int, q + 1>{});
+          lds_wait<(q + 1 < 4 ? 4 : 0)>(af[q & 1][0], af[q & 1][1], af[q & 1][2], af[q & 1][3]);
 #pragma unroll
           for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -969,8 +989,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
-              z_dst[r * 128 + nb * 64] = m0 + (m1 + m2);
-              z_dst[512 + r * 128 + nb * 64] = (m1 - m2) - m3;
+              float* const zd = nb == 0 ? z_dst0 : z_dst1;
+              zd[r * 128] = m0 + (m1 + m2);
+              zd[512 + r * 128] = (m1 - m2) - m3;
             }
         }
         if (have_next) store_chunk(c < 2 ? c + 1 : 0);   // uniform
@@ -984,7 +1005,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_up32_kernel(const IgemmParam
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) z[i][b] = z_src[e * 16 + (i * 2 + b) * 512];
+          for (int b = 0; b < 2; ++b) z[i][b] = (e == 0 ? z_src0 : z_src1)[(i * 2 + b) * 512];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           ov[4 * e + b] = z[0][b] + (z[1][b] + z[2][b]) + bv;

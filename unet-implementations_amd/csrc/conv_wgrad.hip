@@ -1578,10 +1578,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradPara
 // ---------------------------------------------------------------------------
 constexpr int WQ_PW = 18, WQ_PPIX = 108, WQ_LDA = 36, WQ_SLOTS = WQ_PPIX * 8;
 constexpr int WQ_PASSES = (WQ_SLOTS + 511) / 512;          // 2
-constexpr int WQ_VP = 36;                                   // row pitch of V / E (floats)
-constexpr int WQ_V = 16 * 16 * WQ_VP;                       // [xi][tile slot 16][channel 32 (+4)]
+constexpr int WQ_VP = 32;                                   // row pitch of V / E (floats): see the products
+constexpr int WQ_V = 16 * 16 * WQ_VP;                       // [xi][tile slot 16][channel 32]
 constexpr size_t WQ_LDS = ((size_t)WQ_PPIX * WQ_LDA + 2 * WQ_V) * sizeof(float);
-static_assert(4 * 3 * 1024 <= 2 * WQ_V, "the epilogue exchange lives in the V / E stages");
+static_assert(16 * 1024 <= 2 * WQ_V, "the epilogue exchange lives in the V / E stages");
 
 template <bool ACT, bool DZ>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradParams p, int ntiles) {
@@ -1766,16 +1766,27 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
     }
   };
 
-  // ---- products: wave (wi, wh): xi = 4 wi + j; M[ci][co] += sum over tile slots k = 4 q + fk ----
-  const int wi = wave & 3, wh = wave >> 2;
+  // ---- products: wave w owns xi = 2 w and 2 w + 1 for the whole 32 x 32 (ci, co) block:
+  //      M[ci][co] += sum over tile slots k = 4 q + fk of V[k][ci] E[k][co].
+  // Both fragments are 8-byte reads of a CHANNEL PAIR (lane fn: channels 2 fn, 2 fn + 1 of tile
+  // slot fk), so one A read and one B read feed FOUR MFMAs (ci parity x co parity): 16 ds_read_b64
+  // per unit and wave where the first version (wave = xi row x co half, 4-byte fragments) issued
+  // 48 ds_read_b32, two-way bank-conflicted at the 36-float pitch (rows fk and fk + 1 share 12 of
+  // their 16 banks: the 0.33 conflict cycles per active LDS cycle of the round-3 PMC table).  A
+  // pitch of 32 floats puts the two tile slots of a 32-lane group on the two halves of the 64
+  // banks: conflict-free; the transforms' 8-byte stores (16-lane groups, 32 consecutive floats)
+  // are conflict-free at any pitch.  Hand-issued (lds_asm.h): hipcc would fuse the reads of two
+  // steps into ds_read2_b64, which the LDS serves at half the rate. ----
   const int fn = lane & 15, fk = lane >> 4;
-  const float* const a_src = Vs + (4 * wi * 16 + fk) * WQ_VP + fn;        // + (j * 16 + 4 q) * VP + 16 cbi
-  const float* const b_src = Es + (4 * wi * 16 + fk) * WQ_VP + 16 * wh + fn;
-  f32x4 acc[4][2];
+  const unsigned a_addr = lds_addr(Vs + (2 * wave * 16 + fk) * WQ_VP + 2 * fn);   // + (jj * 16 + 4 q) * VP
+  const unsigned b_addr = lds_addr(Es + (2 * wave * 16 + fk) * WQ_VP + 2 * fn);
+  f32x4 acc[2][2][2];   // [xi 2 w + jj][ci parity][co parity]; rows 4 fk + r <-> ci = 2 (4 fk + r) + parity
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) acc[j][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (t_first < t_end) {
     {
@@ -1816,16 +1827,28 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
           transform_dy(ec);
         }
         __syncthreads();
+        {
+          f32x2v fa[2], fb[2];
+          auto rd = [&](auto sc) {      // step s = 2 q + jj
+            constexpr int st = decltype(sc)::value;
+            constexpr int off = (((st & 1) * 16 + 4 * (st >> 1)) * WQ_VP) * 4;
+            fa[st & 1] = lds_rd64<off>(a_addr);
+            fb[st & 1] = lds_rd64<off>(b_addr);
+          };
+          rd(std::integral_constant<int, 0>{});
+          for_range<0, 8>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            constexpr int jj = st & 1, sl = st & 1;
+            if constexpr (st + 1 < 8) rd(std::integral_constant<int, st + 1>{});
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[sl]), "+v"(fb[sl]) : "n"(st + 1 < 8 ? 2 : 0));
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float b = b_src[(j * 16 + 4 * q) * WQ_VP];
-            const float a0 = a_src[(j * 16 + 4 * q) * WQ_VP];
-            const float a1 = a_src[(j * 16 + 4 * q) * WQ_VP + 16];
-            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[j][1], 0, 0, 0);
-          }
+              for (int d = 0; d < 2; ++d)
+                acc[jj][c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][c], fb[sl][d],
+                                                                     acc[jj][c][d], 0, 0, 0);
+          });
+        }
         if (have_next) {   // uniform
           if (nn != n_coef) { load_act(nn); n_coef = nn; }   // uniform, once per image
           store_patch();
@@ -1835,31 +1858,43 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino32_kernel(const WgradPa
     }
   }
 
-  // ---- epilogue: the halves of G (xi row / column 1 or 2), dW = A^T M A with
-  //      A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]: columns in registers, rows across the waves ----
-  const float si = (wi == 1 || wi == 2) ? 0.5f : 1.f;
-  float* const X = Vs;   // [xi row 4][v 3][ci 32][co 32]
+  // ---- epilogue: the halves of G (xi row / column 1 or 2), then dW = A^T M A with
+  //      A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]: every M[xi] goes to LDS once ([xi][ci][co], 64 KB in
+  //      the V / E stages - every wave is past its last fragment read behind the unit's second
+  //      barrier) and each thread combines the 16 values of two (ci, co) positions ----
+  float* const X = Vs;   // [xi 16][ci 32][co 32]
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int jj = 0; jj < 2; ++jj) {
+    const int xi = 2 * wave + jj, gi = xi >> 2, gj = xi & 3;
+    const float sc = ((gi == 1 || gi == 2) ? 0.5f : 1.f) * ((gj == 1 || gj == 2) ? 0.5f : 1.f);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float m0 = acc[0][c][r] * si, m1 = acc[1][c][r] * (0.5f * si), m2 = acc[2][c][r] * (0.5f * si),
-                  m3 = acc[3][c][r] * si;
-      float* o = X + (size_t)(wi * 3) * 1024 + (16 * c + 4 * fk + r) * 32 + 16 * wh + fn;
-      o[0] = m0 + m1 + m2;
-      o[1024] = m1 - m2;
-      o[2048] = m1 + m2 + m3;
-    }
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* o = X + (size_t)xi * 1024 + (2 * (4 * fk + r) + c) * 32 + 2 * fn;
+        *reinterpret_cast<f32x2v*>(o) = f32x2v{acc[jj][c][0][r] * sc, acc[jj][c][1][r] * sc};
+      }
+  }
   __syncthreads();
   float* const slab = p.partial + (size_t)blockIdx.x * 9 * 1024;
 #pragma unroll
-  for (int k = 0; k < 18; ++k) {
-    const int idx = tid + 512 * k;
-    const int uv = idx >> 10, rc = idx & 1023;
-    const int u = uv / 3, v = uv - 3 * u;
-    const float x0 = X[(0 * 3 + v) * 1024 + rc], x1 = X[(1 * 3 + v) * 1024 + rc];
-    const float x2 = X[(2 * 3 + v) * 1024 + rc], x3 = X[(3 * 3 + v) * 1024 + rc];
-    slab[idx] = u == 0 ? x0 + x1 + x2 : (u == 1 ? x1 - x2 : x1 + x2 + x3);
+  for (int h = 0; h < 2; ++h) {
+    const int rc = tid + 512 * h;
+    float t[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float m0 = X[(4 * i + 0) * 1024 + rc], m1 = X[(4 * i + 1) * 1024 + rc];
+      const float m2 = X[(4 * i + 2) * 1024 + rc], m3 = X[(4 * i + 3) * 1024 + rc];
+      t[i][0] = m0 + m1 + m2;
+      t[i][1] = m1 - m2;
+      t[i][2] = m1 + m2 + m3;
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      slab[(0 * 3 + v) * 1024 + rc] = t[0][v] + t[1][v] + t[2][v];
+      slab[(1 * 3 + v) * 1024 + rc] = t[1][v] - t[2][v];
+      slab[(2 * 3 + v) * 1024 + rc] = t[1][v] + t[2][v] + t[3][v];
+    }
   }
 }
 

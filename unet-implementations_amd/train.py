@@ -122,7 +122,14 @@ class GraphedTrainStep:
                            grad_sync=finish)
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, its watchdog thread polls the events of earlier collectives
+        # (hipEventQuery) while this thread captures: under the default "global" capture mode that
+        # query is an error ("operation not permitted when stream is capturing") and takes the
+        # process down.  "thread_local" confines the checks to the capturing thread.
+        mode = "thread_local" if grad_sync is not None else "global"
+        if grad_sync is not None:
+            torch.cuda.synchronize()      # the warm-up collectives have completed
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = train_step(model, optimizer, loss_function, self.images, self.masks,
                                    grad_sync=finish)
         # undo the throw-away steps (the captured step itself did not execute)
