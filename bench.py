@@ -168,6 +168,23 @@ def cpu_baseline(steps=8, hw=512, n=2):
                       f"after 1 warm-up step"}
 
 
+class stdout_to_stderr:
+    """fd 1 -> fd 2 for the duration of the block.  RCCL prints a version banner on the C-level
+    stdout when its communicator comes up; the contract of this script is ONE JSON line there."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def self_launch(n):
     """Run this command line under `python -m torch.distributed.run --nproc-per-node n` as a
     child process (never exec: the parent stays a plain launcher that has not touched the GPU)."""
@@ -253,10 +270,12 @@ def main():
                 os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
                 sock.close()
         kw = dict(rank=rank, world_size=world) if solo_rccl else {}
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev, **kw)
-        else:
-            dist.init_process_group(backend=backend, **kw)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev, **kw)
+            else:
+                dist.init_process_group(backend=backend, **kw)
+            dist.barrier()          # brings the communicator (and its banner) up here
 
     # the CPU baseline (the oracle on the host cores) runs BEFORE the GPU legs: the GPU phases
     # then form one contiguous stretch that a coarse utilisation sampler can see
