@@ -229,6 +229,20 @@ int unet_head1x1_bwd(const float* a, const float* dlogits_nchw, const float* w, 
                      float* dw, float* db, void* workspace, size_t workspace_bytes, int N, int HW,
                      int C, int K, unet_stream_t stream);
 
+/* ---- deferred slab reductions of the weight gradients ----------------------------------------
+ * Every *_bwd_weight* entry point ends with 2-3 small launches that sum its per-workgroup slabs
+ * in a fixed order and scatter the result into the OIHW gradient (44 such launches per train
+ * step).  Between unet_wgrad_defer_begin() and unet_wgrad_defer_end() (per calling thread) the
+ * entry points only QUEUE those reductions; unet_wgrad_defer_flush() launches everything queued
+ * so far as 2-3 batched launches (all layers side by side; the same arithmetic in the same
+ * order: bit-identical gradients).  While a reduction is queued its `workspace` must stay
+ * allocated and dw_oihw is NOT yet valid.  The stand-alone bias gradient (db != NULL) cannot be
+ * deferred.  No reference counterpart (aten::convolution_backward returns finished gradients). */
+int unet_wgrad_defer_begin(void);
+int unet_wgrad_defer_pending(void);
+int unet_wgrad_defer_flush(unet_stream_t stream);
+int unet_wgrad_defer_end(unet_stream_t stream);
+
 /* ---- SimpleLoss: dynamic-weighted CE + soft Dice, forward and gradient ----- */
 
 /* loss_out[0] = w_ce*CE + w_dice*Dice, loss_out[1] = CE, loss_out[2] = Dice,

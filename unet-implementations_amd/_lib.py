@@ -86,6 +86,10 @@ SIGNATURES = {
     "unet_dice_wce_loss_shard_stats": (_i, [_p, _p, _p, _p, _sz, _i, _i, _i, _f, _i, _p]),
     "unet_dice_wce_loss_shard_apply": (_i, [_p, _p, _p, _i, _p, _p, _p, _sz, _i, _i, _i, _f, _f, _f,
                                             _i, _i, _p, _f, _p]),
+    "unet_wgrad_defer_begin": (_i, []),
+    "unet_wgrad_defer_pending": (_i, []),
+    "unet_wgrad_defer_flush": (_i, [_p]),
+    "unet_wgrad_defer_end": (_i, [_p]),
     "unet_dice_wce_loss_grad": (_i, [_p, _p, _p, _sz, _p, _p, _i, _i, _i, _i, _p]),
     "unet_argmax_dice_counts": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "unet_preprocess_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _p]),

@@ -16,6 +16,7 @@
 // Replaces the weight-gradient half of aten::convolution_backward reached from
 // loss.backward() (Our_UNet/src/train.py:663).
 #include "conv_params.h"
+#include <vector>
 #include "lds_asm.h"
 #include <utility>
 
@@ -841,63 +842,86 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
 }
 
 
-// Stage A of the slab reduction: out[c][e] = sum of slabs [16c, 16c+16) of in[.][e]
-// (fixed order).  Applied until <= 8 slabs remain so the final kernel stays shallow.
+// ---------------------------------------------------------------------------
+// Reduction of the per-workgroup slabs into the OIHW gradient.  Every weight-gradient kernel
+// leaves `nslab` partial gradients [tap][ci][co]; they are summed in a FIXED order (no float
+// atomics: run-to-run determinism) in up to three stages - chunks of 16 slabs while more than 16
+// remain (SLAB jobs), then the final sum + scatter (the other kinds).
+//
+// All of it runs through ONE kernel that takes a TABLE of jobs in its kernel arguments
+// (wgrad_reduce_batched_kernel).  Called one job at a time it is what rounds 1-3 launched per
+// weight gradient (2-3 launches of 4-15 us each, 44 per train step); with deferral on
+// (unet_wgrad_defer_begin) the entry points only QUEUE their jobs and unet_wgrad_defer_flush
+// launches the queued stages of every layer together: 2-3 launches per flush, the jobs of all
+// layers running side by side.  The arithmetic and its order are those of the per-call form:
+// bit-identical results.
+// ---------------------------------------------------------------------------
 constexpr int kSlabChunk = 16;
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ in,
-                                                          float* __restrict__ out, int split,
-                                                          long long E4) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+enum ReduceKind { RK_SLAB = 0, RK_CENTER, RK_GENERIC, RK_WIDE8, RK_WIDE16, RK_TAP, RK_STEM };
+struct ReduceJob {
+  const float* src;
+  float* dst;
+  int nslab;                          // slabs to sum (SLAB: of the whole input)
+  int Cx, Cout, ci_off, Cin_total;    // SLAB: Cx = E / 4 (float4 elements of a slab)
+  int kind;
+  int gx, gy;                         // grid of the job: gx * gy * gz blocks
+  int block_begin;                    // first block of the job in the batched launch
+};
+constexpr int kReduceJobs = 56;       // 56 x 56 B + 8 = 3144 B of kernel arguments (limit 4 KB)
+struct ReduceTable {
+  int n, pad;
+  ReduceJob j[kReduceJobs];
+};
+
+// out[c][e] = sum of slabs [16c, 16c+16) of in[.][e] (fixed order)
+__device__ __forceinline__ void reduce_slab_body(const ReduceJob& J, int bx, int c) {
+  const long long E4 = J.Cx;
+  const long long e = (long long)bx * 256 + threadIdx.x;
   if (e >= E4) return;
-  const int c = blockIdx.y;
   const int s0 = c * kSlabChunk;
-  const int s1 = min(s0 + kSlabChunk, split);
-  const f32x4* src = reinterpret_cast<const f32x4*>(in) + e;
+  const int s1 = min(s0 + kSlabChunk, J.nslab);
+  const f32x4* src = reinterpret_cast<const f32x4*>(J.src) + e;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k = s0; k < s1; ++k) acc += src[(size_t)k * E4];
-  reinterpret_cast<f32x4*>(out)[(size_t)c * E4 + e] = acc;
+  reinterpret_cast<f32x4*>(J.dst)[(size_t)c * E4 + e] = acc;
 }
 
 // 1x1 weight gradient = centre tap of the 3x3 slabs: dw[co][ci_off+ci] = sum_s partial[s][4][ci][co]
-__global__ __launch_bounds__(256) void wgrad_reduce_center_kernel(const float* __restrict__ partial,
-                                                                  float* __restrict__ dw, int split,
-                                                                  int Cx, int Cout, int ci_off,
-                                                                  int Cin_total) {
-  __shared__ float tile[32][33];
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+__device__ __forceinline__ void reduce_center_body(const ReduceJob& J, float* sm, int bx, int by) {
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(sm);   // [32][33]
+  const int Cx = J.Cx, Cout = J.Cout;
+  const int co0 = bx * 32, ci0 = by * 32;
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const size_t slab = (size_t)9 * Cx * Cout;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int ci = r + 8 * k;
-    const float* src = partial + ((size_t)4 * Cx + ci0 + ci) * Cout + co0 + c;
+    const float* src = J.src + ((size_t)4 * Cx + ci0 + ci) * Cout + co0 + c;
     float s = 0.f;
-    for (int q = 0; q < split; ++q) s += src[(size_t)q * slab];
+    for (int q = 0; q < J.nslab; ++q) s += src[(size_t)q * slab];
     tile[ci][c] = s;
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int co = r + 8 * k;
-    dw[(size_t)(co0 + co) * Cin_total + ci_off + ci0 + c] = tile[c][co];
+    J.dst[(size_t)(co0 + co) * J.Cin_total + J.ci_off + ci0 + c] = tile[c][co];
   }
 }
 
 // dw_oihw[co][ci_off+ci][tap] = sum_s partial[s][tap][ci][co]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
-                                                           float* __restrict__ dw, int split,
-                                                           int Cx, int Cout, int ci_off,
-                                                           int Cin_total) {
-  // tile: 32 co x 8 ci per block, all 9 taps; LDS transpose so both sides coalesce-ish
-  __shared__ float tile[9][8][33];
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 8;
+// tile: 32 co x 8 ci per block, all 9 taps; LDS transpose so both sides coalesce-ish
+__device__ __forceinline__ void reduce_generic_body(const ReduceJob& J, float* sm, int bx, int by) {
+  float (*tile)[8][33] = reinterpret_cast<float (*)[8][33]>(sm);   // [9][8][33]
+  const int Cx = J.Cx, Cout = J.Cout;
+  const int co0 = bx * 32, ci0 = by * 8;
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;  // r in 0..7
   const size_t slab = (size_t)9 * Cx * Cout;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const float* src = partial + ((size_t)t * Cx + ci0 + r) * Cout + co0 + c;
+    const float* src = J.src + ((size_t)t * Cx + ci0 + r) * Cout + co0 + c;
     float s = 0.f;
-    for (int k = 0; k < split; ++k) s += src[(size_t)k * slab];
+    for (int k = 0; k < J.nslab; ++k) s += src[(size_t)k * slab];
     tile[t][r][c] = s;
   }
   __syncthreads();
@@ -905,7 +929,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int i = threadIdx.x; i < 32 * 72; i += 256) {
     const int co = i / 72, rem = i - co * 72;
     const int ci = rem / 9, t = rem - ci * 9;
-    dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[t][ci][co];
+    J.dst[((size_t)(co0 + co) * J.Cin_total + J.ci_off + ci0 + ci) * 9 + t] = tile[t][ci][co];
   }
 }
 
@@ -913,19 +937,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // with 16-byte loads along co (256-byte row segments instead of 128) and writes runs of CI * 9
 // contiguous floats per output channel.
 template <int CI>
-__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial,
-                                                                float* __restrict__ dw, int split,
-                                                                int Cx, int Cout, int ci_off,
-                                                                int Cin_total) {
-  __shared__ float tile[9 * CI][65];
-  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * CI;
+__device__ __forceinline__ void reduce_wide_body(const ReduceJob& J, float* sm, int bx, int by) {
+  float (*tile)[65] = reinterpret_cast<float (*)[65]>(sm);   // [9 * CI][65]
+  const int Cx = J.Cx, Cout = J.Cout;
+  const int co0 = bx * 64, ci0 = by * CI;
   const int c4 = threadIdx.x & 15, r = threadIdx.x >> 4;   // 16 rows x 16 float4 per pass
   const size_t slab = (size_t)9 * Cx * Cout;
   for (int rr = r; rr < 9 * CI; rr += 16) {
     const int t = rr / CI, ci = rr - t * CI;
-    const float* src = partial + ((size_t)t * Cx + ci0 + ci) * Cout + co0 + c4 * 4;
+    const float* src = J.src + ((size_t)t * Cx + ci0 + ci) * Cout + co0 + c4 * 4;
     f32x4 s = *reinterpret_cast<const f32x4*>(src);
-    for (int k = 1; k < split; ++k) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab);
+    for (int k = 1; k < J.nslab; ++k) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab);
     tile[rr][c4 * 4 + 0] = s[0]; tile[rr][c4 * 4 + 1] = s[1];
     tile[rr][c4 * 4 + 2] = s[2]; tile[rr][c4 * 4 + 3] = s[3];
   }
@@ -933,29 +955,60 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
   for (int i = threadIdx.x; i < 64 * CI * 9; i += 256) {
     const int co = i / (CI * 9), rem = i - co * (CI * 9);
     const int ci = rem / 9, t = rem - ci * 9;
-    dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[t * CI + ci][co];
+    J.dst[((size_t)(co0 + co) * J.Cin_total + J.ci_off + ci0 + ci) * 9 + t] = tile[t * CI + ci][co];
   }
 }
 
-// The same with one tap per block (grid.z = 9): 9x the workgroups for the layers whose
-// gradient is small (32 / 64 channels: 4 / 16 blocks of the kernel above, each thread walking
-// split x 9 dependent slab rows, would run for tens of microseconds on a near-idle chip).
-__global__ __launch_bounds__(256) void wgrad_reduce_tap_kernel(const float* __restrict__ partial,
-                                                               float* __restrict__ dw, int split,
-                                                               int Cx, int Cout, int ci_off,
-                                                               int Cin_total) {
-  __shared__ float tile[8][33];
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 8, t = blockIdx.z;
+// The same with one tap per block (gz = 9): 9x the workgroups for the layers whose gradient is
+// small (32 / 64 channels: 4 / 16 blocks of the forms above, each thread walking split x 9
+// dependent slab rows, would run for tens of microseconds on a near-idle chip).
+__device__ __forceinline__ void reduce_tap_body(const ReduceJob& J, float* sm, int bx, int by, int t) {
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(sm);   // [8][33]
+  const int Cx = J.Cx, Cout = J.Cout;
+  const int co0 = bx * 32, ci0 = by * 8;
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;  // r in 0..7
   const size_t slab = (size_t)9 * Cx * Cout;
-  const float* src = partial + ((size_t)t * Cx + ci0 + r) * Cout + co0 + c;
+  const float* src = J.src + ((size_t)t * Cx + ci0 + r) * Cout + co0 + c;
   float s = 0.f;
-  for (int k = 0; k < split; ++k) s += src[(size_t)k * slab];
+  for (int k = 0; k < J.nslab; ++k) s += src[(size_t)k * slab];
   tile[r][c] = s;
   __syncthreads();
   // thread (co = tid >> 3, ci = tid & 7)
   const int co = threadIdx.x >> 3, ci = threadIdx.x & 7;
-  dw[((size_t)(co0 + co) * Cin_total + ci_off + ci0 + ci) * 9 + t] = tile[ci][co];
+  J.dst[((size_t)(co0 + co) * J.Cin_total + J.ci_off + ci0 + ci) * 9 + t] = tile[ci][co];
+}
+
+// stem reduce: dw_oihw[co][ci][tap] (Cin_total = 3) = sum_b partial[b][tap*3+ci][co]
+__device__ __forceinline__ void reduce_stem_body(const ReduceJob& J, int bx) {
+  const int Cout = J.Cout;
+  const int i = bx * 256 + threadIdx.x;
+  if (i >= 27 * Cout) return;
+  const int k = i / Cout, co = i - k * Cout;
+  float s = 0.f;
+  for (int b = 0; b < J.nslab; ++b) s += J.src[((size_t)b * 27 + k) * Cout + co];
+  const int t = k / 3, ci = k - t * 3;
+  J.dst[((size_t)co * 3 + ci) * 9 + t] = s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const ReduceTable tab) {
+  __shared__ float sm[9 * 16 * 65];
+  // the job of this block: the table is sorted by block_begin (uniform scalar search)
+  int k = 0;
+  for (int q = 1; q < tab.n; ++q)
+    if (tab.j[q].block_begin <= (int)blockIdx.x) k = q;
+  const ReduceJob& J = tab.j[k];
+  const int b = (int)blockIdx.x - J.block_begin;
+  const int bx = b % J.gx, rest = b / J.gx;
+  const int by = rest % J.gy, bz = rest / J.gy;
+  switch (J.kind) {   // uniform
+    case RK_SLAB: reduce_slab_body(J, bx, by); break;
+    case RK_CENTER: reduce_center_body(J, sm, bx, by); break;
+    case RK_GENERIC: reduce_generic_body(J, sm, bx, by); break;
+    case RK_WIDE8: reduce_wide_body<8>(J, sm, bx, by); break;
+    case RK_WIDE16: reduce_wide_body<16>(J, sm, bx, by); break;
+    case RK_TAP: reduce_tap_body(J, sm, bx, by, bz); break;
+    default: reduce_stem_body(J, bx); break;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1121,16 +1174,85 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_rows_kernel(
   }
 }
 
-// stem reduce: dw_oihw[co][ci][tap] (Cin_total = 3) = sum_b partial[b][tap*3+ci][co]
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                         int nblocks, int Cout) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 27 * Cout) return;
-  const int k = i / Cout, co = i - k * Cout;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * 27 + k) * Cout + co];
-  const int t = k / 3, ci = k - t * 3;
-  dw[((size_t)co * 3 + ci) * 9 + t] = s;
+// ---- host side of the reductions: launch at once, or queue until unet_wgrad_defer_flush ----
+struct ReduceQueue {
+  bool on = false;
+  std::vector<std::vector<ReduceJob>> stage;   // stage k of every queued weight gradient
+  int pending = 0;
+};
+ReduceQueue& reduce_queue() {
+  static thread_local ReduceQueue q;
+  return q;
+}
+int launch_reduce_jobs(const ReduceJob* jobs, int n, hipStream_t stream) {
+  for (int i = 0; i < n; i += kReduceJobs) {
+    ReduceTable t{};
+    t.n = n - i < kReduceJobs ? n - i : kReduceJobs;
+    long long blocks = 0;
+    for (int k = 0; k < t.n; ++k) {
+      t.j[k] = jobs[i + k];
+      t.j[k].block_begin = (int)blocks;
+      blocks += (long long)t.j[k].gx * t.j[k].gy * (t.j[k].kind == RK_TAP ? 9 : 1);
+    }
+    UNET_REQUIRE(blocks > 0 && blocks < (1LL << 31), "wgrad_reduce: bad grid");
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    UNET_CHECK_LAUNCH("wgrad_reduce_batched");
+  }
+  return UNET_OK;
+}
+int emit_reduce(int stage, const ReduceJob& j, hipStream_t stream) {
+  ReduceQueue& q = reduce_queue();
+  if (!q.on) return launch_reduce_jobs(&j, 1, stream);
+  if ((int)q.stage.size() <= stage) q.stage.resize(stage + 1);
+  q.stage[stage].push_back(j);
+  ++q.pending;
+  return UNET_OK;
+}
+int flush_reduce_queue(hipStream_t stream) {
+  ReduceQueue& q = reduce_queue();
+  int rc = UNET_OK;
+  for (auto& st : q.stage) {
+    if (!st.empty() && rc == UNET_OK) rc = launch_reduce_jobs(st.data(), (int)st.size(), stream);
+    st.clear();
+  }
+  q.pending = 0;
+  return rc;
+}
+// The reduction of ONE weight gradient: `nslab` slabs of E floats at `ws` (scratch for the
+// chunked stages right behind them) summed into dw.  stem: slabs [27][Cout] -> dw[co][3][9].
+int emit_wgrad_reduction(float* ws, int nslab, size_t E, float* dw, int Cx, int Cout, int ci_off,
+                         int Cin_total, bool center_only, bool stem, hipStream_t stream) {
+  const float* cur = ws;
+  float* ping = ws + (size_t)nslab * E;
+  float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
+  int stage = 0;
+  while (nslab > 16) {
+    const int chunks = ceil_div(nslab, kSlabChunk);
+    ReduceJob j{};
+    j.src = cur; j.dst = ping; j.nslab = nslab; j.Cx = (int)(E / 4); j.kind = RK_SLAB;
+    j.gx = (int)ceil_div64((long long)(E / 4), 256); j.gy = chunks;
+    const int rc = emit_reduce(stage++, j, stream);
+    if (rc != UNET_OK) return rc;
+    cur = ping;
+    float* t = ping; ping = pong; pong = t;
+    nslab = chunks;
+  }
+  ReduceJob j{};
+  j.src = cur; j.dst = dw; j.nslab = nslab; j.Cx = Cx; j.Cout = Cout; j.ci_off = ci_off;
+  j.Cin_total = Cin_total;
+  if (stem) {
+    j.kind = RK_STEM; j.gx = ceil_div(27 * Cout, 256); j.gy = 1;
+  } else if (center_only) {
+    j.kind = RK_CENTER; j.gx = Cout / 32; j.gy = Cx / 32;
+  } else if ((long long)Cx * Cout <= 128 * 128) {   // few output tiles: one tap per block
+    j.kind = RK_TAP; j.gx = Cout / 32; j.gy = Cx / 8;
+  } else if (Cout % 64 == 0 && Cx % 16 == 0) {
+    if ((long long)Cx * Cout >= 512 * 512) { j.kind = RK_WIDE16; j.gx = Cout / 64; j.gy = Cx / 16; }
+    else { j.kind = RK_WIDE8; j.gx = Cout / 64; j.gy = Cx / 8; }
+  } else {
+    j.kind = RK_GENERIC; j.gx = Cout / 32; j.gy = Cx / 8;
+  }
+  return emit_reduce(stage, j, stream);
 }
 
 struct WgradPlan {
@@ -2356,24 +2478,11 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       hipLaunchKernelGGL(conv_stem_wgrad_kernel<float>, grid, dim3(256), 0, stream, x, dy, ws, N, H,
                          W, Cout, pl.stem_spb, pl.stem_stages);
     UNET_CHECK_LAUNCH("conv_stem_wgrad");
-    const int n = 27 * Cout;
-    const float* cur = ws;
-    int nslab = pl.stem_blocks;
-    float* ping = ws + (size_t)pl.stem_blocks * n;
-    float* pong = ping + (size_t)ceil_div(pl.stem_blocks, kSlabChunk) * n;
-    while (nslab > 16) {
-      const int chunks = ceil_div(nslab, kSlabChunk);
-      dim3 g((unsigned)ceil_div(n / 4, 256), chunks);
-      hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
-                         (long long)(n / 4));
-      UNET_CHECK_LAUNCH("slab_reduce(stem)");
-      cur = ping;
-      float* t = ping; ping = pong; pong = t;
-      nslab = chunks;
+    {
+      const int rc = emit_wgrad_reduction(ws, pl.stem_blocks, (size_t)27 * Cout, dw_oihw, 3, Cout, 0, 3,
+                                          false, true, stream);
+      if (rc != UNET_OK) return rc;
     }
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, cur,
-                       dw_oihw, nslab, Cout);
-    UNET_CHECK_LAUNCH("stem_wgrad_reduce");
   } else {
     UNET_REQUIRE(!act_alpha || (act_beta && (prec == 0 || prec == 3 || b16)),
                  "conv_bwd_weight: activation on load needs the fp32, split or bf16-storage path");
@@ -2410,43 +2519,16 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
       if (rc != UNET_OK) return rc;
       nslab += pc.split * pc.sps;
     }
-    const float* cur = ws;
-    float* ping = ws + (size_t)nslab * E;
-    float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
-    while (nslab > 16) {
-      const int chunks = ceil_div(nslab, kSlabChunk);
-      dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
-      hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
-                         (long long)(E / 4));
-      UNET_CHECK_LAUNCH("slab_reduce");
-      cur = ping;
-      float* t = ping; ping = pong; pong = t;
-      nslab = chunks;
+    {
+      const int rc = emit_wgrad_reduction(ws, nslab, E, dw_oihw, Cx, Cout, ci_offset, Cin_total,
+                                          center_only, false, stream);
+      if (rc != UNET_OK) return rc;
     }
-    if (center_only) {
-      dim3 rgrid(Cout / 32, Cx / 32);
-      hipLaunchKernelGGL(wgrad_reduce_center_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw,
-                         nslab, Cx, Cout, ci_offset, Cin_total);
-    } else if ((long long)Cx * Cout <= 128 * 128) {   // few output tiles: one tap per block
-      dim3 rgrid(Cout / 32, Cx / 8, 9);
-      hipLaunchKernelGGL(wgrad_reduce_tap_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab,
-                         Cx, Cout, ci_offset, Cin_total);
-    } else if (Cout % 64 == 0 && Cx % 16 == 0) {
-      if ((long long)Cx * Cout >= 512 * 512)
-        hipLaunchKernelGGL(wgrad_reduce_wide_kernel<16>, dim3(Cout / 64, Cx / 16), dim3(256), 0,
-                           stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
-      else
-        hipLaunchKernelGGL(wgrad_reduce_wide_kernel<8>, dim3(Cout / 64, Cx / 8), dim3(256), 0,
-                           stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
-    } else {
-      dim3 rgrid(Cout / 32, Cx / 8);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
-                         Cout, ci_offset, Cin_total);
-    }
-    UNET_CHECK_LAUNCH("wgrad_reduce");
   }
   UNET_REQUIRE(!(db && b16), "conv_bwd_weight: db is not produced on the bf16-storage path");
   if (db) {
+    UNET_REQUIRE(!reduce_queue().on, "conv_bwd_weight: the bias gradient reuses the slab workspace "
+                                     "and cannot be combined with deferred reductions");
     // the slab workspace is free again at this point of the stream; reuse its head as scratch
     const long long M = (long long)N * Ho * Wo;
     const int chunks = M >= 4096 ? 64 : 1;
@@ -2676,37 +2758,8 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
     if (rc != UNET_OK) return rc;
     nslab += pl.split * pl.sps;
   }
-  const float* cur = ws;
-  float* ping = ws + (size_t)nslab * E;
-  float* pong = ping + (size_t)ceil_div(nslab, kSlabChunk) * E;
-  while (nslab > 16) {
-    const int chunks = ceil_div(nslab, kSlabChunk);
-    dim3 g((unsigned)ceil_div64((long long)(E / 4), 256), chunks);
-    hipLaunchKernelGGL(slab_reduce_kernel, g, dim3(256), 0, stream, cur, ping, nslab,
-                       (long long)(E / 4));
-    UNET_CHECK_LAUNCH("slab_reduce");
-    cur = ping;
-    float* t = ping; ping = pong; pong = t;
-    nslab = chunks;
-  }
-  if ((long long)Cx * Cout <= 128 * 128) {
-    dim3 rgrid(Cout / 32, Cx / 8, 9);
-    hipLaunchKernelGGL(wgrad_reduce_tap_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab,
-                       Cx, Cout, ci_offset, Cin_total);
-  } else if (Cout % 64 == 0 && Cx % 16 == 0) {
-    if ((long long)Cx * Cout >= 512 * 512)
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel<16>, dim3(Cout / 64, Cx / 16), dim3(256), 0,
-                         stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
-    else
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel<8>, dim3(Cout / 64, Cx / 8), dim3(256), 0,
-                         stream, cur, dw_oihw, nslab, Cx, Cout, ci_offset, Cin_total);
-  } else {
-    dim3 rgrid(Cout / 32, Cx / 8);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, cur, dw_oihw, nslab, Cx,
-                       Cout, ci_offset, Cin_total);
-  }
-  UNET_CHECK_LAUNCH("wgrad_reduce");
-  return UNET_OK;
+  return emit_wgrad_reduction(ws, nslab, E, dw_oihw, Cx, Cout, ci_offset, Cin_total, false, false,
+                              stream);
 }
 
 // Mixed-precision pipeline: x (activated on load) and dy are bf16 tensors; stride-1 layers on the
@@ -2738,4 +2791,21 @@ extern "C" int unet_stem_u8_bwd_weight(const uint8_t* image_hwc, const float* me
   return conv_bwd_weight_impl(nullptr, 3, dy, dw_oihw, 0, 3, nullptr, workspace, workspace_bytes,
                               N, H, W, Cout, 1, false, (hipStream_t)stream, 0, nullptr, nullptr,
                               0.f, image_hwc, ms);
+}
+
+// ---- deferred reductions (include/unet_hip.h) ----
+extern "C" int unet_wgrad_defer_begin(void) {
+  ReduceQueue& q = reduce_queue();
+  UNET_REQUIRE(!q.on || q.pending == 0, "wgrad_defer_begin: reductions still pending (flush first)");
+  q.on = true;
+  return UNET_OK;
+}
+extern "C" int unet_wgrad_defer_pending(void) { return reduce_queue().pending; }
+extern "C" int unet_wgrad_defer_flush(unet_stream_t stream) {
+  return flush_reduce_queue((hipStream_t)stream);
+}
+extern "C" int unet_wgrad_defer_end(unet_stream_t stream) {
+  const int rc = flush_reduce_queue((hipStream_t)stream);
+  reduce_queue().on = false;
+  return rc;
 }

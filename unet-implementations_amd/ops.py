@@ -107,6 +107,54 @@ def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
 
+# ---- deferred weight-gradient reductions (unet_wgrad_defer_*) -----------------------------------
+import threading
+
+_defer = threading.local()
+
+
+def _wgrad_ws(nbytes, like):
+    """Workspace of a weight-gradient call: while its reduction is only queued (wgrad_deferral)
+    it must outlive the flush."""
+    ws = _ws(nbytes, like)
+    held = getattr(_defer, "held", None)
+    if held is not None:
+        held.append(ws)
+    return ws
+
+
+class wgrad_deferral:
+    """`with wgrad_deferral() as d:` - the weight-gradient entry points called inside only queue
+    the reductions of their slabs; `d.flush()` (and the end of the block) launches everything
+    queued so far as 2-3 batched launches instead of 2-3 per layer.  A weight gradient is valid
+    only after the flush that follows its call.  Per thread; not re-entrant."""
+
+    def __enter__(self):
+        if getattr(_defer, "held", None) is not None:
+            raise RuntimeError("wgrad_deferral is not re-entrant")
+        check(lib().unet_wgrad_defer_begin())
+        _defer.held = []
+        return self
+
+    def flush(self):
+        n = lib().unet_wgrad_defer_pending()
+        if n:
+            t0 = _timer.begin("wgrad") if _timer is not None else None
+            check(lib().unet_wgrad_defer_flush(_stream()))
+            if t0 is not None:
+                _timer.end("conv_wgrad_reduce", 0.0, 2, t0)
+        # (stream order: the allocator hands the blocks out again only behind the flush)
+        _defer.held.clear()
+        return n
+
+    def __exit__(self, *exc):
+        try:
+            check(lib().unet_wgrad_defer_end(_stream()))
+        finally:
+            _defer.held = None
+        return False
+
+
 # ---- layout -------------------------------------------------------------------
 def nchw_to_nhwc(x):
     N, C, H, W = x.shape
@@ -418,7 +466,7 @@ def conv3x3_bwd_weight(x, dy, dw_oihw, ci_offset, stride, db=None, bf16=False):
     cin_total = dw_oihw.shape[1]
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
     nbytes = lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride)
-    ws = _ws(nbytes, x)
+    ws = _wgrad_ws(nbytes, x)
     t0 = _timer.begin("wgrad") if _timer is not None else None
     pr = _prec(bf16)
     fn = getattr(lib(), "unet_conv3x3_bwd_weight" + _SUFFIX[pr])
@@ -465,7 +513,7 @@ def conv1x1_bwd_weight(x, dy, dw2d, ci_offset):
     N, H, W, Cx = x.shape
     Cout = dy.shape[3]
     assert dw2d.shape[0] == Cout and dw2d.is_contiguous()
-    ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1), x)
+    ws = _wgrad_ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1), x)
     check(lib().unet_conv1x1_bwd_weight(_ptr(x), Cx, _ptr(dy), _ptr(dw2d), ci_offset,
                                         dw2d.shape[1], _ptr(ws), ws.numel(), N, H, W, Cout,
                                         _stream()))
@@ -549,7 +597,7 @@ def conv_in_bwd_weight_dz(x, slope, g, y, coef5, sums, gamma, rstd, dz_slope, dg
     N, H, W, Cx = x.shape
     Cout = g.shape[3]
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous() and y.shape == g.shape
-    ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1), g)
+    ws = _wgrad_ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, 1), g)
     dz = g if in_place else _f32(tuple(g.shape), g)
     t0 = _timer.begin("wgrad") if _timer is not None else None
     check(lib().unet_conv_in_bwd_weight_dz(
@@ -794,7 +842,7 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride, x3=False
     if isinstance(x, U8Image):
         N, H, W, _ = x.shape
         Cout = dy.shape[3]
-        ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, 3, Cout, 1), dy)
+        ws = _wgrad_ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, 3, Cout, 1), dy)
         m3, s3 = x.c_mean_std()
         t0 = _timer.begin("wgrad") if _timer is not None else None
         check(lib().unet_stem_u8_bwd_weight(_ptr(x.x), m3, s3, _ptr(dy), _ptr(dw_oihw), _ptr(ws),
@@ -806,7 +854,7 @@ def conv_in_bwd_weight(x, slope, dy, dw_oihw, ci_offset, ksize, stride, x3=False
     N, H, W, Cx = x.shape
     Cout = dy.shape[3]
     assert dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
-    ws = _ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride), dy)
+    ws = _wgrad_ws(lib().unet_conv3x3_bwd_weight_workspace_bytes(N, H, W, Cx, Cout, stride), dy)
     b16 = _is_b16(dy)
     fn = lib().unet_conv_in_bwd_weight_b16 if b16 else \
         (lib().unet_conv_in_bwd_weight_bf16x3 if x3 else lib().unet_conv_in_bwd_weight)
@@ -857,7 +905,7 @@ def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
     N, h, w, Cx = x.shape
     Cout = D.shape[3] // 9
     assert D.shape[:3] == x.shape[:3] and dw_oihw.shape[0] == Cout and dw_oihw.is_contiguous()
-    ws = _ws(lib().unet_conv3x3_up_bwd_weight_workspace_bytes(N, h, w, Cx, Cout), D)
+    ws = _wgrad_ws(lib().unet_conv3x3_up_bwd_weight_workspace_bytes(N, h, w, Cx, Cout), D)
     fn = lib().unet_conv3x3_up_bwd_weight_b16 if _is_b16(D) else lib().unet_conv3x3_up_bwd_weight
     t0 = _timer.begin("wgrad") if _timer is not None else None
     check(fn(rx, slope, _ptr(D), _ptr(dw_oihw), ci_offset, dw_oihw.shape[1], _ptr(ws), ws.numel(),

@@ -605,8 +605,11 @@ class _UNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        with ops.c32_winograd_scope(ctx.c32_mode):       # the forward's decision
-            return _UNetFunction._backward(ctx, dlogits)
+        # The slab reductions of the weight gradients (2-3 small launches per gradient, 44 per
+        # step) are queued and launched together: at the end of the walk, or - with a
+        # data-parallel hook - whenever a stage's gradients are handed to the exchange.
+        with ops.c32_winograd_scope(ctx.c32_mode), ops.wgrad_deferral() as deferred:       # (the forward's decision)
+            return _UNetFunction._backward(ctx, dlogits, deferred)
 
     @staticmethod
     def _forward(ctx, model, x, extra, params):
@@ -813,7 +816,7 @@ class _UNetFunction(torch.autograd.Function):
         return logits
 
     @staticmethod
-    def _backward(ctx, dlogits):
+    def _backward(ctx, dlogits, deferred):
         model, saved, params = ctx.model, ctx.saved, ctx.params
         enc, dec = model._plan
         gv = model._grad_view
@@ -855,6 +858,7 @@ class _UNetFunction(torch.autograd.Function):
 
         def ready(module):
             if hook is not None:
+                deferred.flush()      # the gradients handed over must be final
                 first = next(module.parameters())     # (only with a data-parallel hook installed)
                 hook(model._offsets[model._param_index[id(first)]])
 
@@ -1056,6 +1060,7 @@ class _UNetFunction(torch.autograd.Function):
                 idx -= 1
             if not done:
                 ready(model.encoder_stages[bi])
+        deferred.flush()
         if hook is not None:
             # everything below the first trainable parameter is a frozen prefix: no gradient,
             # nothing to exchange
