@@ -28,15 +28,18 @@ PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E
 CONV_GROUPS = ("conv_igemm", "conv_igemm_bf16", "conv_igemm_bf16x3")
 
 
-def hbm_traffic(args):
+def hbm_traffic(args, matmul):
     """HBM bytes per launch of the forward / data-gradient convolution group from the PMC passes
     committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of
     this command, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950; tools/
-    pmc_traffic.py).  A committed measurement of the default workload, not of this run."""
-    if args.matmul != "fp32" or args.hw != 512 or args.batch != 8 or args.clip:
+    pmc_passes.sh, tools/pmc_traffic.py).  A committed measurement of the default workload (and
+    of `--matmul bf16`), not of this run."""
+    if args.hw != 512 or args.batch != 8 or args.clip:
         return None, None
-    for name in ("r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json", "r02_conv_hbm_traffic.json",
-                 "r01_igemm_hbm_traffic.json"):
+    names = {"fp32": ("r04_conv_hbm_traffic.json", "r03_conv_hbm_traffic.json",
+                      "r02_conv_hbm_traffic.json", "r01_igemm_hbm_traffic.json"),
+             "bf16": ("r04_bf16_conv_hbm_traffic.json",)}.get(matmul, ())
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -73,7 +76,7 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
     # bf16x3 issues 6 bf16 MFMA flops per algorithmic flop
     peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
             "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[matmul]
-    traffic, src = hbm_traffic(args) if matmul == "fp32" else (None, None)
+    traffic, src = hbm_traffic(args, matmul)
     exe = k["executed"] / sec * 1e-12
     roof = {
         # `achieved` / `frac`: the MFMA FLOPs the kernels actually ISSUE over their measured time
@@ -86,6 +89,10 @@ def roofline_of(summ, steps, matmul, args, gsumm=None, gsteps=None):
         "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s", "frac": exe / peak,
         "algorithmic": ach, "algorithmic_frac": ach / peak,
         "traffic": traffic, "traffic_source": src,
+        # HBM rate of the same launches: measured bytes per launch / measured launch time
+        "traffic_gbs": (traffic / (k["ms"] * 1e-3 / k["launches"]) * 1e-9) if traffic else None,
+        "traffic_frac_of_hbm_peak": (traffic / (k["ms"] * 1e-3 / k["launches"]) * 1e-9 / PEAK_HBM_GBS)
+        if traffic else None,
         "kernel": "convolution forward + data-gradient group ("
                   + {"fp32": "conv_wino_kernel, conv_wino32q_kernel, conv_wino_up32_kernel (Winograd F(2x2,3x3): 16/36 of the "
                              "direct MFMA FLOPs), conv_patch_f32_kernel, conv_patch_up_kernel, "

@@ -670,6 +670,12 @@ int unet_conv3x3_up_bwd_weight_b16(const unet_act_src* x, float slope, const uin
 int unet_conv3x3_up_bwd_data_b16(const uint16_t* D, const float* wd, int Cin_total, int ci_offset,
                                  uint16_t* g, int N, int h, int w, int Cout, int Ccols,
                                  int accumulate, unet_stream_t stream);
+/* ... with the BSTATS epilogue (g final for the layer bs describes; bs->y bf16), as
+ * unet_conv3x3_up_bwd_data_bs: removes that layer's stand-alone reduction pass. */
+int unet_conv3x3_up_bwd_data_bs_b16(const uint16_t* D, const float* wd, int Cin_total,
+                                    int ci_offset, uint16_t* g, int N, int h, int w, int Cout,
+                                    int Ccols, int accumulate, unet_bwd_stats* bs,
+                                    unet_stream_t stream);
 int unet_head1x1_in_fwd_b16(const unet_act_src* x, float slope, const float* w, const float* b,
                             float* logits_nchw, int N, int HW, int K, unet_stream_t stream);
 int unet_head1x1_in_bwd_b16(const unet_act_src* x, float slope, const float* dlogits_nchw,

@@ -80,6 +80,9 @@ FWD = [  # (N, H, W, C0, C1, Cout, stride, ksize)
     (3, 4, 4, 32, 32, 32, 1, 3),        # tiles span images, stand-alone statistics
     (2, 16, 16, 64, 0, 64, 1, 1),
     (1, 128, 128, 32, 32, 32, 1, 3),    # statistics epilogue, 128 x 32 tiles
+    (8, 16, 16, 512, 0, 512, 1, 3),     # 1/32-resolution layer at bs 8: K-group gather-GEMM (KG 4)
+    (8, 32, 32, 512, 0, 512, 2, 3),     # ... its stride-2 sibling (encoder_stages.5.block.0)
+    (2, 16, 16, 64, 64, 64, 1, 3),      # two sources through the K-group form (KG 4)
 ]
 
 
@@ -221,6 +224,28 @@ def test_up_backward_b16(ua, case):
     g = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx)
     assert g.dtype == BF
     check(from_nhwc(g), a.grad, 1e-2, "g low")
+    # the same with the BSTATS epilogue (unet_conv3x3_up_bwd_data_bs_b16): identical bits, and its
+    # summaries drive the InstanceNorm backward like the stand-alone reduction does
+    if (h * w) % 64 == 0:
+        yl = to_nhwc_b16(r16(rnd(N, Cx, h, w, seed=20) * 1.5 + 0.3))
+        gamma = (rnd(Cx, seed=21) * 0.2 + 1.0).to(DEV)
+        beta = (rnd(Cx, seed=22) * 0.2).to(DEV)
+        yf = yl.float()
+        mean = yf.mean(dim=(1, 2))
+        rstd = 1.0 / torch.sqrt(yf.var(dim=(1, 2), unbiased=False) + 1e-5)
+        st = torch.stack([mean, rstd, torch.zeros_like(mean), torch.zeros_like(mean)]).contiguous()
+        nn = ua.ops.NextNorm(yl, st, gamma, beta, None, SLOPE)
+        g2 = ua.ops.conv3x3_up_bwd_data(D, wd, 0, Cx, nxt=nn)
+        assert torch.equal(g2, g) and nn.tiles > 0
+        outs = []
+        for partials in ((nn.partial, nn.tiles), None):
+            dg, db, dbias = (torch.empty(Cx, device=DEV) for _ in range(3))
+            dz = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), yl, st[0], st[1], gamma, beta, None,
+                                                SLOPE, dg, db, dbias, partials=partials)
+            outs.append((dz.float(), dg, db))
+        check(outs[0][0], outs[1][0], 8e-3, "dz")
+        check(outs[0][1], outs[1][1], 3e-3, "dgamma")
+        check(outs[0][2], outs[1][2], 3e-3, "dbeta")
 
 
 # --------------------------------------------------------------------------- whole network
@@ -335,16 +360,20 @@ def test_bf16_full_size_layers_and_batch_split(ua):
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
-@pytest.mark.parametrize("case", [(1, 256, 256, 32, 128, False), (2, 256, 256, 64, 64, True),
-                                  (2, 256, 256, 32, 32, False), (2, 16, 16, 64, 64, False)])
+@pytest.mark.parametrize("case", [(1, 256, 256, 32, 128, False, 1), (2, 256, 256, 64, 64, True, 1),
+                                  (2, 256, 256, 32, 32, False, 1), (2, 16, 16, 64, 64, False, 1),
+                                  (8, 16, 16, 512, 512, False, 1), (2, 32, 32, 128, 64, True, 1),
+                                  (2, 256, 256, 64, 32, False, 2), (8, 64, 64, 256, 128, False, 2),
+                                  (2, 128, 128, 128, 64, True, 2)])
 def test_data_gradient_b16_emits_next_norm_reductions(ua, case):
-    """unet_conv3x3_bwd_data_bs_b16: the patch kernel's BSTATS epilogue on bf16 tensors (sums from
-    the fp32 accumulators and the bf16 raw outputs of the layer).  Same gradient bits as the plain
-    call; the InstanceNorm backward fed by the summaries agrees with the stand-alone reduction
-    (which reads the bf16-STORED gradient) to bf16 storage precision.  The last shape has no such
-    epilogue (gather-GEMM): tiles == 0."""
-    N, H, W, Cout, Ccols, acc = case
-    dy = to_nhwc_b16(r16(rnd(N, Cout, H, W, seed=1)))
+    """unet_conv3x3_bwd_data_bs_b16: the BSTATS epilogue on bf16 tensors (sums from the fp32
+    accumulators and the bf16 raw outputs of the layer) - the stride-1 patch kernel, and since
+    round 4 the gather-GEMM (incl. its K-group form for the 1/32-resolution layers: the 16 x 16
+    shapes) and the stride-2 patch kernel.  Same gradient bits as the plain call; the InstanceNorm
+    backward fed by the summaries agrees with the stand-alone reduction (which reads the
+    bf16-STORED gradient) to bf16 storage precision."""
+    N, H, W, Cout, Ccols, acc, stride = case
+    dy = to_nhwc_b16(r16(rnd(N, Cout, H // stride, W // stride, seed=1)))
     w = rnd(Cout, Ccols, 3, 3, seed=2, scale=0.1)
     _, wd = ua.ops.pack_conv3x3_weights(w.to(DEV))
     y = to_nhwc_b16(r16(rnd(N, Ccols, H, W, seed=10) * 1.5 + 0.3))
@@ -357,15 +386,12 @@ def test_data_gradient_b16_emits_next_norm_reductions(ua, case):
     mask = ((torch.rand(N, Ccols, generator=torch.Generator().manual_seed(13)) < 0.8).float()
             / 0.8).to(DEV)
     base = to_nhwc_b16(r16(rnd(N, Ccols, H, W, seed=3))) if acc else None
-    ref = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, 1, out=base.clone() if acc else None,
+    ref = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, stride, out=base.clone() if acc else None,
                                   accumulate=acc)
     nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
-    g = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, 1, out=base.clone() if acc else None,
+    g = ua.ops.conv3x3_bwd_data(dy, wd, 0, Ccols, H, W, stride, out=base.clone() if acc else None,
                                 accumulate=acc, nxt=nn)
     assert torch.equal(g, ref)
-    if H * W < 128 * 32:
-        assert nn.tiles == 0
-        return
     assert nn.tiles > 0
     outs = []
     for partials in ((nn.partial, nn.tiles), None):

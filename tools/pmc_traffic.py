@@ -14,7 +14,13 @@ import json
 import re
 import sys
 
-GROUP = re.compile(r"conv_wino_kernel|conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_wino32q_kernel|conv_wino_up32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel")
+GROUPS = {
+    "fp32": r"conv_wino_kernel|conv_patch_f32_kernel|conv_patch_up_kernel|conv_patch_s2_kernel|conv_c32_kernel|conv_wino32q_kernel|conv_wino_up32_kernel|conv_igemm_kernel|conv_igemm_rf_kernel|conv_dgrad_s2_kernel|conv_dgrad_s2_patch_kernel",
+    # BASELINE config 4 (`bench.py --matmul bf16`): the same launch group on bf16 tensors
+    "bf16": r"conv_patch_b16_kernel|conv_igemm_bf16_kernel|conv_dgrad_s2_patch_b16_kernel",
+}
+MODE = sys.argv[4] if len(sys.argv) > 4 else "fp32"
+GROUP = re.compile(GROUPS[MODE])
 
 
 def per_launch(path, counter):
@@ -33,8 +39,10 @@ out = {"kernel": GROUP.pattern.replace("|", " | ") + " (3x3 forward + data gradi
        "fetch_bytes_per_launch_corrected": 2.0 * fetch,
        "write_bytes_per_launch": write,
        "hbm_bytes_per_launch": 2.0 * fetch + write,
+       "mode": MODE,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                 "`bench.py --steps 2 --warmup 1 --no-alt --no-graph --no-cpu-baseline --no-kernel-timer`; "
+                 "`bench.py --steps 2 --warmup 1 --no-alt --no-graph --no-cpu-baseline --no-kernel-timer"
+                 + ("" if MODE == "fp32" else " --matmul " + MODE) + "`; "
                  "FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests "
                  "as 64 B for 16-B/lane coalesced reads); WRITE_SIZE (KiB) taken as is"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -1286,8 +1286,9 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
   // split mode with reductions (fused pipeline): only the stride-1 patch shapes have a split
   // kernel with that epilogue; everything else runs the fp32 kernels
   if (prec == 3 && bs && stride == 2) prec = 0;
-  // (b16: only the stride-1 patch kernel has the epilogue; other shapes report 0 tiles)
-  const bool use_bs = bs && (prec == 0 || prec == 3 || (b16 && stride == 1)) && bs->y && bs->mean &&
+  // (b16: the stride-1 patch kernel and the gather-GEMM have the epilogue; the stride-2 patch
+  // kernel reports 0 tiles)
+  const bool use_bs = bs && (prec == 0 || prec == 3 || b16) && bs->y && bs->mean &&
                       bs->rstd && bs->gamma &&
                       bs->beta && bs->partial &&
                       bs->partial_bytes >= (size_t)N * ceil_div(H * W, 64) * Ccols * sizeof(float2);
@@ -1383,8 +1384,15 @@ static int conv3x3_bwd_data_impl(const float* dy, const float* wd, int Cin_total
       }
     }
     if (b16) {   // mixed-precision pipeline: one launch instead of four per class
-      const int rc = launch_dgrad_s2_patch_b16_auto(p, stream);
-      if (rc != 1) return rc;
+      IgemmParams q = p;
+      if (!use_bs) q.bs_partial = nullptr;
+      int bt = 0;
+      const int rc = launch_dgrad_s2_patch_b16_auto(q, stream, use_bs ? &bt : nullptr);
+      if (rc != 1) {
+        if (rc == UNET_OK && use_bs && bt > 0) bs->tiles_out = bt;
+        return rc;
+      }
+      p.bs_partial = nullptr;   // (the per-class gather-GEMM launches below: no epilogue)
     }
     if (prec != 1 && !b16 && tiles >= 512) {
       p.py = p.px = 0; p.ntaps = 9;
@@ -1858,13 +1866,23 @@ extern "C" int unet_conv3x3_up_bwd_data_b16(const uint16_t* D, const float* wd, 
                                   stream, 1);
 }
 
+// the same with the BSTATS epilogue: g is final for the layer described by bs (bs->y bf16)
+extern "C" int unet_conv3x3_up_bwd_data_bs_b16(const uint16_t* D, const float* wd, int Cin_total,
+                                               int ci_offset, uint16_t* g, int N, int h, int w,
+                                               int Cout, int Ccols, int accumulate,
+                                               unet_bwd_stats* bs, unet_stream_t stream) {
+  return conv3x3_up_bwd_data_impl(reinterpret_cast<const float*>(D), wd, Cin_total, ci_offset,
+                                  reinterpret_cast<float*>(g), N, h, w, Cout, Ccols, accumulate,
+                                  stream, 1, bs);
+}
+
 static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
                                     float* g, int N, int h, int w, int Cout, int Ccols,
                                     int accumulate, unet_stream_t stream, int b16,
                                     unet_bwd_stats* bs) {
   const long long es = b16 ? 2 : 4;
   if (bs) bs->tiles_out = 0;
-  const bool use_bs = bs && !b16 && bs->y && bs->mean && bs->rstd && bs->gamma && bs->beta &&
+  const bool use_bs = bs && bs->y && bs->mean && bs->rstd && bs->gamma && bs->beta &&
                       bs->partial &&
                       bs->partial_bytes >= (size_t)N * ceil_div(h * w, 64) * Ccols * sizeof(float2);
   UNET_REQUIRE(D && wd && g, "conv3x3_up_bwd_data: null pointer");
@@ -1903,14 +1921,14 @@ static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_tot
   p.Ncols = Ccols; p.sin = 1; p.sout = 1; p.py = p.px = 0;
   p.ntaps = 9; p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
   for (int t = 0; t < 9; ++t) set_tap(p, t, 0, 0, t);
-  if (b16) return dispatch_igemm_b16(p, (hipStream_t)stream, nullptr);
   int bs_px = 0;
   if (use_bs) {
     p.bs_y = bs->y; p.bs_mean = bs->mean; p.bs_rstd = bs->rstd; p.bs_gamma = bs->gamma;
     p.bs_beta = bs->beta; p.bs_mask = bs->mask; p.slope = bs->slope;
     p.bs_partial = reinterpret_cast<float2*>(bs->partial);
   }
-  const int rc = dispatch_igemm(p, (hipStream_t)stream, nullptr, use_bs ? &bs_px : nullptr);
+  const int rc = b16 ? dispatch_igemm_b16(p, (hipStream_t)stream, nullptr, use_bs ? &bs_px : nullptr)
+                     : dispatch_igemm(p, (hipStream_t)stream, nullptr, use_bs ? &bs_px : nullptr);
   if (rc == UNET_OK && use_bs && bs_px > 0) bs->tiles_out = h * w / bs_px;
   return rc;
 }

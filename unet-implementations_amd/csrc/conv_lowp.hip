@@ -18,9 +18,18 @@ namespace {
 // TS / TO: storage type of the source / output activations (float, or __bf16 in the real
 // mixed-precision pipeline where the layer tensors live in HBM as bf16).  FUSED: activation on
 // load + statistics epilogue of the fused layer pipeline (IgemmParams), as conv_igemm_kernel.
+// KG > 1 (the 1/32-resolution layers, M = N*16*16 rows: one 64x64 tile per CU, and a lone 4-wave
+// block cannot hide the load latency of its 144-step K loop - round 3 measured this kernel at
+// 0.66 ms over those launches against 0.31 ms for its fp32 sibling, which has K groups): KG
+// groups of four waves share the tile, group g runs K steps [g, g+1) * KS / KG through its own
+// pair of LDS stages, the partial accumulators are summed through LDS in group order before
+// the common epilogue (deterministic) - as conv_igemm_kernel (conv_igemm.hip).
+// !FUSED with p.bs_partial: the BSTATS epilogue (the output is FINAL for the layer behind it:
+// per-tile sums of that layer's InstanceNorm backward, from the fp32 accumulators and the stored
+// raw outputs y) - as conv_igemm_kernel / conv_patch_b16_kernel.
 template <int BM, int BN, int WM, int WN, typename TS = float, typename TO = float,
-          bool FUSED = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmParams p) {
+          bool FUSED = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_kernel(const IgemmParams p) {
   constexpr int BK = 32;
   constexpr int LDA = BK + 8;  // bf16 elements per LDS row
   constexpr int SEGS = BK / 4;         // 16-B segments per tile row
@@ -32,10 +41,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
   constexpr int B_PASSES = BN / ROWS;
   constexpr int A_TILE = BM * LDA, B_TILE = BN * LDA;
   extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
-  __bf16* As = smem_h;
-  __bf16* Bs = smem_h + 2 * A_TILE;
+  // K group: uniform per wave, kept in an SGPR so the K-step bookkeeping stays scalar
+  const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  const bool lead = KG == 1 || grp == 0;
+  __bf16* As = smem_h + grp * 2 * (A_TILE + B_TILE);
+  __bf16* Bs = As + 2 * A_TILE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const int KS = p.ntaps * (Ktot / BK);
+  const int KS = p.ntaps * (Ktot / BK) / KG;   // K steps of this group (the launcher checks % KG)
   constexpr int CP = FUSED ? A_PASSES : 1;
   f32x4 ca[CP], cb[CP];
   float cs = 1.f;
@@ -163,6 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
   };
 
   int t_next = 0, chunk_next = 0;
+  if (KG > 1) {   // tap-fastest order: step = chunk * ntaps + t
+    chunk_next = grp * KS / p.ntaps;
+    t_next = grp * KS - chunk_next * p.ntaps;
+  }
   auto advance = [&](bool on) {  // branch-free: keeps the K step a single basic block
     const int tn = t_next + 1;
     const bool wrap = tn == p.ntaps;
@@ -215,47 +231,129 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const IgemmPara
     __syncthreads();
   }
 
+  // the K loop ended on a barrier: every LDS stage is free scratch from here on
+  float* fsm = reinterpret_cast<float*>(smem_h);
+  float* scratch = fsm;
+  if (KG > 1) {   // partial sums of groups 1.. in [group][wave][register][lane] order
+    constexpr int PART = 256 * 16 * TM * TN;
+    static_assert(((KG - 1) * PART + 2 * (BM / WM) * BN) * 4 <= KG * 2 * (A_TILE + B_TILE) * 2,
+                  "partial sums + reduction scratch fit in the stages");
+    if (!lead) {
+      float* dst = fsm + (grp - 1) * PART + wave * 64 * 16 * TM * TN + lane;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((m * TN + n) * 16 + r) * 64] = acc[m][n][r];
+    }
+    __syncthreads();
+    if (lead) {
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float* src = fsm + (g - 1) * PART + wave * 64 * 16 * TM * TN + lane;
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] += src[((m * TN + n) * 16 + r) * 64];
+      }
+    }
+    scratch = fsm + (KG - 1) * PART;
+  }
+
   // ---- epilogue: D row = (reg&3) + 8*(reg>>2) + 4*lh, column = li ----
+  // BSTATS (uniform `bs`): needs every tile inside one image and all rows valid (dispatcher check)
   const bool direct = (p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout);
+  const bool bs = !FUSED && p.bs_partial;
+  constexpr int WAVES_M_ = BM / WM;
+  float2* bred = reinterpret_cast<float2*>(scratch);
+  const int bimg = m0 / HlWl;
+  TO* const outp = reinterpret_cast<TO*>(p.out);
+  const TO* const ybase = reinterpret_cast<const TO*>(p.bs_y);
 #pragma unroll
   for (int n = 0; n < TN; ++n) {
     const int col = n0 + wn0 + n * 32 + li;
     const float bv = p.bias ? p.bias[col] : 0.f;
+    BwdCoef cf{};
+    if (bs) cf = bwd_coef(p, bimg, col);
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-      TO* o[16];
+      unsigned o[16];   // element offsets into p.out (the tensor stays below 2^29 elements)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int mg = m0 + row;
-        size_t opix = (size_t)mg;
+        const int mg = lead ? m0 + row : M;   // the other K groups store nothing
+        unsigned opix = (unsigned)mg;
         if (!direct) {
           const int nn = mg / HlWl;
           const int rr = mg - nn * HlWl;
           const int a = rr / p.Wl;
           const int b = rr - a * p.Wl;
-          opix = ((size_t)nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px);
+          opix = (unsigned)((nn * p.Hout + (a * p.sout + p.py)) * p.Wout + (b * p.sout + p.px));
         }
-        o[r] = mg < M ? reinterpret_cast<TO*>(p.out) + opix * p.ldo + col : nullptr;
+        o[r] = mg < M ? opix * (unsigned)p.ldo + (unsigned)col : kNoOut;
       }
-      store_block16(o, acc[m][n], bv, p.accumulate);
+      if (bs) {
+        if (p.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[m][n][r] += bv + (o[r] != kNoOut ? ld1(outp + o[r]) : 0.f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] += bv;
+        }
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          yv[r] = 0.f;
+          if (o[r] != kNoOut) {
+            st1(outp + o[r], acc[m][n][r]);
+            yv[r] = ld1(ybase + o[r]);
+          }
+        }
+        if (lead) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {   // the order of wave_bwd_stats (conv_params.h)
+            const float z = fmaf(yv[r], cf.A, cf.B0);
+            const float gz = acc[m][n][r] * cf.mk * (z > 0.f ? 1.f : p.slope);
+            s1 += gz;
+            s2 = fmaf(gz, (yv[r] - cf.mu) * cf.rs, s2);
+          }
+        }
+      } else {
+        store_block16_off(outp, o, acc[m][n], bv, p.accumulate);
+      }
     }
+    if (bs) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0 && lead) bred[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = float2{s1, s2};
+    }
+  }
+  if (bs) {
+    float2 out;
+    if (block_col_sums<BN, WAVES_M_>(bred, out))
+      p.bs_partial[((size_t)bimg * p.bs_tiles + p.bs_tile0 + (m0 - bimg * HlWl) / BM) * p.Ncols +
+                   n0 + threadIdx.x] = out;
   }
   if (FUSED && p.stats) {   // uniform; statistics of the fp32 accumulators (before any rounding)
     constexpr int WAVES_M = BM / WM;
-    float2* red = reinterpret_cast<float2*>(As);
+    float2* red = reinterpret_cast<float2*>(scratch);
     static_assert(WAVES_M * BN * 4 <= 2 * A_TILE, "stats scratch fits in the A tiles");
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int col = n0 + wn0 + n * 32 + li;
       const float bv = p.bias ? p.bias[col] : 0.f;
       const float2 mine = wave_col_stats<TM>([&](int m, int r) { return acc[m][n][r] + bv; });
-      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
+      if (lh == 0 && lead) red[(wave / WAVES_N) * BN + wn0 + n * 32 + li] = mine;
     }
     float2 out;
     if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out)) {
       const int img = m0 / HlWl;   // the whole tile lies in this image (dispatcher check)
-      p.stats[((size_t)img * p.stats_tiles + (m0 - img * HlWl) / BM) * p.Ncols + n0 + tid] = out;
+      p.stats[((size_t)img * p.stats_tiles + (m0 - img * HlWl) / BM) * p.Ncols + n0 + threadIdx.x] = out;
     }
   }
 }
@@ -490,25 +588,47 @@ int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-// bf16 STORAGE (the real mixed-precision pipeline): sources and output are bf16 tensors
-template <int BM, int BN, int WM, int WN>
-int launch_igemm_b16(IgemmParams p, hipStream_t stream, int* stats_px) {
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * 40 * sizeof(__bf16);
+// bf16 STORAGE (the real mixed-precision pipeline): sources and output are bf16 tensors.
+// stats_px: the fused-layer forward (statistics epilogue where every tile lies in one image);
+// bs_px: a data gradient whose output is final for a layer (BSTATS epilogue, same condition).
+template <int BM, int BN, int WM, int WN, int KG = 1>
+int launch_igemm_b16(IgemmParams p, hipStream_t stream, int* stats_px, int* bs_px = nullptr) {
+  constexpr size_t lds = KG * 2 * (size_t)(BM + BN) * 40 * sizeof(__bf16);
+  static_assert(lds <= 160 * 1024, "LDS stages of every K group fit one CU");
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
+  const int HlWl = p.Hl * p.Wl;
   if (stats_px) {   // fused layer forward
-    const int HlWl = p.Hl * p.Wl;
     const bool direct = p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout;
     if (direct && p.stats && HlWl % BM == 0) { *stats_px = BM; p.stats_tiles = HlWl / BM; }
     else { *stats_px = 0; p.stats = nullptr; }
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, true>),
-                       dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    p.bs_partial = nullptr;
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, true, KG>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KG), lds, stream, p);
   } else {
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, false>),
-                       dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    if (bs_px && p.bs_partial && HlWl % BM == 0 && M % BM == 0) {
+      *bs_px = BM; p.bs_tiles = HlWl / BM * (p.sout * p.sout);
+    } else {
+      if (bs_px) *bs_px = 0;
+      p.bs_partial = nullptr;
+    }
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, false, KG>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KG), lds, stream, p);
   }
   UNET_CHECK_LAUNCH("conv_igemm_b16");
   return UNET_OK;
+}
+
+// Deep layers (at most one 64x64 tile per CU): number of K groups per block (1 = no split)
+static int deep_k_groups_b16(const IgemmParams& p) {
+  const long long M = (long long)p.N * p.Hl * p.Wl;
+  if (p.Ncols % 64 != 0 || ceil_div64(M, 64) * (p.Ncols / 64) > 256) return 1;
+  const int ks = p.ntaps * ((p.C0 + p.C1) / 32);
+  int kg = 4;
+  while (kg > 1 && (ks % kg != 0 || ks / kg < 4)) kg >>= 1;
+  return kg;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -548,11 +668,16 @@ int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px, 
     if (bs_px) *bs_px = 0;
   }
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
-    return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px);
+    return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px, bs_px);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
-    return launch_igemm_b16<128, 64, 64, 32>(p, stream, stats_px);
-  if (nc % 64 == 0 && M <= 128 * 256) return launch_igemm_b16<64, 64, 32, 32>(p, stream, stats_px);
-  return launch_igemm_b16<128, 32, 32, 32>(p, stream, stats_px);
+    return launch_igemm_b16<128, 64, 64, 32>(p, stream, stats_px, bs_px);
+  if (nc % 64 == 0 && M <= 128 * 256) {
+    const int kg = deep_k_groups_b16(p);
+    return kg == 4   ? launch_igemm_b16<64, 64, 32, 32, 4>(p, stream, stats_px, bs_px)
+           : kg == 2 ? launch_igemm_b16<64, 64, 32, 32, 2>(p, stream, stats_px, bs_px)
+                     : launch_igemm_b16<64, 64, 32, 32>(p, stream, stats_px, bs_px);
+  }
+  return launch_igemm_b16<128, 32, 32, 32>(p, stream, stats_px, bs_px);
 }
 
 int dispatch_igemm_split(const IgemmParams& p, hipStream_t stream) {

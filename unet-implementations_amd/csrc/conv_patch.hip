@@ -1494,11 +1494,19 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
     });
   }
 
-  // ---- epilogue: class c -> dx pixel (2a + c/2, 2b + c%2), column li ----
+  // ---- epilogue: class c -> dx pixel (2a + c/2, 2b + c%2), column li; BSTATS (uniform
+  // p.bs_partial) as in conv_dgrad_s2_patch_kernel: the sums of the next backward stage from the
+  // fp32 accumulators and that layer's stored (bf16) raw outputs ----
   __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+  const __bf16* ybase = reinterpret_cast<const __bf16*>(p.bs_y);
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
 #pragma unroll
   for (int nb = 0; nb < TN; ++nb) {
     const int col = n0 + wn0 + nb * 32 + li;
+    BwdCoef cf{};
+    if (p.bs_partial) cf = bwd_coef(p, n, col);   // uniform
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -1517,7 +1525,40 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           o[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo] = (__bf16)acc[c][m][nb][r];
+        if (p.bs_partial) {   // uniform
+          // (two halves of eight values, fenced: with all sixteen y loads of a block in flight on
+          // top of the 128 accumulator registers the 64-column instantiation spilled)
+          const __bf16* yb = ybase + pix * p.ldo + col;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = 8 * h + q;
+              const float y = (float)yb[(size_t)(2 * ((r & 3) + 8 * (r >> 2))) * p.ldo];
+              const float z = fmaf(y, cf.A, cf.B0);
+              const float gz = acc[c][m][nb][r] * cf.mk * (z > 0.f ? 1.f : p.slope);
+              s1[nb] += gz;
+              s2[nb] = fmaf(gz, (y - cf.mu) * cf.rs, s2[nb]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+  }
+  if (p.bs_partial) {   // uniform; the K loop ended on a barrier: the patch area is free scratch
+    constexpr int WAVES_M = 4 / WAVES_N;
+    float2* red = reinterpret_cast<float2*>(Ps);
+    static_assert(WAVES_M * BN * 8 <= PPIX * LDA * 2, "reduction scratch fits in the patch area");
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const float a = s1[nb] + __shfl_xor(s1[nb], 32, 64);
+      const float b = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+      if (lh == 0) red[(wave / WAVES_N) * BN + wn0 + nb * 32 + li] = float2{a, b};
+    }
+    float2 out;
+    if (block_col_sums<BN, WAVES_M>(red, out))
+      p.bs_partial[((size_t)n * p.bs_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
   }
 }
 
@@ -1881,15 +1922,25 @@ int launch_dgrad_s2_patch_b16(const IgemmParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
-// The same for the mixed-precision pipeline (bf16 dy / dx); no BSTATS epilogue.
-int launch_dgrad_s2_patch_b16_auto(const IgemmParams& p, hipStream_t stream) {
+// The same for the mixed-precision pipeline (bf16 dy / dx / bs_y); BSTATS as the fp32 form.
+int launch_dgrad_s2_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* bs_tiles_out) {
+  IgemmParams p = p0;
+  if (bs_tiles_out) *bs_tiles_out = 0;
   if (p.Wl % 32 != 0 || p.C0 % 32 != 0 || p.Hout != 2 * p.Hl || p.Wout != 2 * p.Wl) return 1;
   const long long pos = (long long)p.N * p.Hl * p.Wl;
   const int nc = p.Ncols;
-  if (nc % 64 == 0 && p.Hl % 4 == 0 && pos / 128 * (nc / 64) >= 256)
+  p.bs_tile0 = 0;
+  if (!bs_tiles_out) p.bs_partial = nullptr;
+  if (nc % 64 == 0 && p.Hl % 4 == 0 && pos / 128 * (nc / 64) >= 256) {
+    p.bs_tiles = p.Hl * p.Wl / 128;
+    if (bs_tiles_out) *bs_tiles_out = p.bs_partial ? p.bs_tiles : 0;
     return launch_dgrad_s2_patch_b16<64, 32, 64, 4>(p, stream);
-  if (nc == 32 && p.Hl % 8 == 0 && pos / 256 >= 256)
+  }
+  if (nc == 32 && p.Hl % 8 == 0 && pos / 256 >= 256) {
+    p.bs_tiles = p.Hl * p.Wl / 256;
+    if (bs_tiles_out) *bs_tiles_out = p.bs_partial ? p.bs_tiles : 0;
     return launch_dgrad_s2_patch_b16<32, 64, 32, 8>(p, stream);
+  }
   return 1;
 }
 

@@ -928,11 +928,11 @@ def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False, nxt
     g = out if out is not None else (_b16 if b16 else _f32)((N, h, w, ccols), D)
     fn = lib().unet_conv3x3_up_bwd_data_b16 if b16 else lib().unet_conv3x3_up_bwd_data
     t0 = _timer.begin("conv") if _timer is not None else None
-    if nxt is not None and not b16:
+    if nxt is not None:
         bs = nxt.c_struct()
-        check(lib().unet_conv3x3_up_bwd_data_bs(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N,
-                                                h, w, Cout, ccols, 1 if accumulate else 0,
-                                                ctypes.byref(bs), _stream()))
+        fbs = lib().unet_conv3x3_up_bwd_data_bs_b16 if b16 else lib().unet_conv3x3_up_bwd_data_bs
+        check(fbs(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,
+                  1 if accumulate else 0, ctypes.byref(bs), _stream()))
         nxt.tiles = bs.tiles_out
     else:
         check(fn(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,
