@@ -377,12 +377,92 @@ def main():
 
     enqueue = enqueue_ms()
 
+    # ---- the line as it stands after the EAGER timed region (rank 0 only) ----
+    result = None
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / dt
+        result = {
+            "metric": "images/sec (512x512, bs/GPU=8) Our_UNet train step",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16 (layer tensors and MFMA operands bf16; f32 "
+                                            "accumulate, statistics, weights, optimizer)",
+                      "bf16x3": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMA products per "
+                                "multiply, f32 accumulate + storage)"}[args.matmul],
+            "data": "synthetic",
+            "config": {"workload": ("CLIP_UNet (synthetic CLIP features [N,512,16,16]) " if args.clip else "") +
+                                   f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
+                                   "fp32 train step (fwd + Dice/wCE loss + bwd + SGD-Nesterov), "
+                                   "train mode, HIP conv/IN/upsample kernels",
+                       "global_batch": args.batch * world, "image": [args.hw, args.hw],
+                       "parallelism": f"dp{world}", "world": world,
+                       "dist_backend": backend_used},
+            # which of the two timed forms of the SAME step `value` is: "eager" (one host call
+            # per kernel) or "hip_graph_replay" (the step captured once, one host call per
+            # step); the other one is reported under its own key
+            "value_path": "eager",
+            "final_loss": final_loss,
+            # host time to enqueue one step (Python + ctypes, idle stream); the step is
+            # launch-bound when this approaches ms_per_step
+            "enqueue_ms_per_step": enqueue,
+        }
+        if timer is not None:
+            roof, groups = roofline_of(timer.summary(), args.steps, args.matmul, args, gsumm, gsteps)
+            if roof:
+                result["roofline"] = roof
+            result["kernel_groups"] = groups
+            result["kernel_groups_pass"] = (f"{gsteps} extra steps after the timed region with every "
+                                            "entry point bracketed by HIP events (the timed region "
+                                            "brackets only the roofline group)")
+        if cpu_base is not None:
+            result["cpu_baseline"] = cpu_base
+
+    emitted = []
+
+    def emit():
+        """rank 0 prints THE line (once)."""
+        if rank == 0 and not emitted:
+            emitted.append(True)
+            v = result["value"]
+            result["step_tflops"] = v / world * GFLOP_PER_IMAGE * 1e-3
+            result["step_frac_of_f32_mfma_peak"] = result["step_tflops"] / PEAK_F32_MFMA_TFLOPS
+            print(json.dumps(result), flush=True)
+
+    class Bailout:
+        """N > 1 only: a leg that captures RCCL collectives in a HIP graph has never run on more
+        than one rank (no multi-GPU node was ever available to rehearse it).  If it has not
+        finished after `seconds`, every rank gives up on it: rank 0 prints the line as it stands
+        (the eager measurement, which is complete at this point) and the process exits."""
+
+        def __init__(self, seconds, what):
+            import threading
+            self.timer = threading.Timer(seconds, self.fire)
+            self.timer.daemon = True
+            self.what = what
+
+        def fire(self):
+            if result is not None:
+                result.setdefault("notes", []).append(f"{self.what}: no result after the time "
+                                                      "limit; the line carries the eager figures")
+            emit()
+            os._exit(0)
+
+        def __enter__(self):
+            if world > 1:
+                self.timer.start()
+            return self
+
+        def __exit__(self, *exc):
+            self.timer.cancel()
+            return False
+
     # The data-parallel step is capturable too (RCCL's collectives become graph nodes on RCCL's
     # stream).  At N = 1 the leg always runs (with UNET_BENCH_RCCL=1 through the one-rank RCCL
-    # group, collectives captured); at N > 1 it is opt-in (UNET_BENCH_DDP_GRAPH=1): no multi-GPU
-    # node was ever available to rehearse it, and a hang there would cost the whole bench line.
-    ddp_graph = use_dist and backend == "nccl" and \
-        (solo_rccl or bool(os.environ.get("UNET_BENCH_DDP_GRAPH")))
+    # group, collectives captured); at N > 1 it runs under a time limit (Bailout above) and can be
+    # switched off with UNET_BENCH_DDP_GRAPH=0.
+    ddp_graph = use_dist and backend == "nccl" and os.environ.get("UNET_BENCH_DDP_GRAPH", "1") != "0"
 
     def graph_leg():
         """The same K steps replayed from ONE HIP graph (ua.GraphedTrainStep): what the step
@@ -412,7 +492,27 @@ def main():
                 "note": "train step captured once in a HIP graph and replayed (same kernels, "
                         "same order; dropout masks drawn inside the graph)"}
 
-    graph = graph_leg()
+    def guarded_graph_leg(what):
+        try:
+            with Bailout(240.0, what):
+                return graph_leg()
+        except Exception as e:   # capture refused: keep the eager figures
+            if world > 1:        # (a half-captured collective leaves the group unusable: stop here)
+                if result is not None:
+                    result.setdefault("notes", []).append(f"{what}: {type(e).__name__}: {e}"[:300])
+                emit()
+                os._exit(0)
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    graph = guarded_graph_leg("graph replay of the data-parallel step")
+    if rank == 0 and graph is not None:
+        result["graph_replay"] = graph
+        if graph.get("value", 0.0) > result["value"]:
+            # the same step, replayed: what a training loop runs (train.GraphedTrainStep)
+            result["eager"] = {"value": result["value"], "unit": "images/s",
+                               "ms_per_step": result["ms_per_step"]}
+            result["value"], result["ms_per_step"] = graph["value"], graph["ms_per_step"]
+            result["value_path"] = "hip_graph_replay"
 
     # Beside the fp32-matrix-core headline, the same K steps in the two other operand modes
     # (reported, never `value`): the split-bf16 ("bf16x3") mode, which holds the same reference
@@ -458,7 +558,7 @@ def main():
                          "ms_per_step": 1e3 * dt_alt / args.steps,
                          "enqueue_ms_per_step": enqueue_ms(), "dtype": ALT[mode]["dtype"],
                          "parity": ALT[mode]["parity"]}
-            g_alt = graph_leg()
+            g_alt = guarded_graph_leg(f"graph replay ({mode})")
             if g_alt is not None:
                 alt[mode]["graph_replay"] = g_alt
             if alt_timer is not None:
@@ -471,48 +571,9 @@ def main():
                 alt[mode]["kernel_groups"] = groups
         model.matmul_precision = args.matmul
 
-    if rank == 0:
-        images = args.batch * world * args.steps
-        value = images / dt
-        result = {
-            "metric": "images/sec (512x512, bs/GPU=8) Our_UNet train step",
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 (layer tensors and MFMA operands bf16; f32 "
-                                            "accumulate, statistics, weights, optimizer)",
-                      "bf16x3": "f32 (operands split into 3 bf16 terms, 6 bf16 MFMA products per "
-                                "multiply, f32 accumulate + storage)"}[args.matmul],
-            "data": "synthetic",
-            "config": {"workload": ("CLIP_UNet (synthetic CLIP features [N,512,16,16]) " if args.clip else "") +
-                                   f"Our_UNet 6-stage 3-class {args.hw}x{args.hw} bs={args.batch}/GPU "
-                                   "fp32 train step (fwd + Dice/wCE loss + bwd + SGD-Nesterov), "
-                                   "train mode, HIP conv/IN/upsample kernels",
-                       "global_batch": args.batch * world, "image": [args.hw, args.hw],
-                       "parallelism": f"dp{world}", "world": world,
-                       "dist_backend": backend_used},
-            "final_loss": final_loss,
-            # host time to enqueue one step (Python + ctypes, idle stream); the step is
-            # launch-bound when this approaches ms_per_step
-            "enqueue_ms_per_step": enqueue,
-            "step_tflops": value / world * GFLOP_PER_IMAGE * 1e-3,
-            "step_frac_of_f32_mfma_peak": value / world * GFLOP_PER_IMAGE * 1e-3 / PEAK_F32_MFMA_TFLOPS,
-        }
-        if timer is not None:
-            roof, groups = roofline_of(timer.summary(), args.steps, args.matmul, args, gsumm, gsteps)
-            if roof:
-                result["roofline"] = roof
-            result["kernel_groups"] = groups
-            result["kernel_groups_pass"] = (f"{gsteps} extra steps after the timed region with every "
-                                            "entry point bracketed by HIP events (the timed region "
-                                            "brackets only the roofline group)")
-        if graph is not None:
-            result["graph_replay"] = graph
-        if alt is not None:
-            result["alt_modes"] = alt
-        if cpu_base is not None:
-            result["cpu_baseline"] = cpu_base
-        print(json.dumps(result), flush=True)
+    if rank == 0 and alt is not None:
+        result["alt_modes"] = alt
+    emit()
     if use_dist:
         dist.destroy_process_group()
 

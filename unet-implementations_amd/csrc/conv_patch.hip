@@ -936,9 +936,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
 #pragma unroll
   for (int i = 0; i < P_PASSES; ++i) {
     const int slot = (tid + 256 * i) % P_SLOTS;
-    const int pix = slot / SEG, seg = slot % SEG;
-    // slots walk the LDS order (linear, conflict-free writes); the 64-B global segments of
-    // neighbouring slots then lie two pixels apart, which costs nothing (a segment is the unit)
+    // slots walk the LDS order, except that the two pixels of an 8-lane group (the unit a
+    // ds_write_b128 is served in, over 32 banks) lie FOUR rows of 80 bytes apart: rows p and
+    // p + 1 overlap in four banks (the 0.31 conflict cycles per active LDS cycle of the round-2/3
+    // PMC tables), rows p and p + 4 are 320 B = 16 banks apart and do not.  The 64-B global
+    // segments of neighbouring lanes then lie a few pixels apart, which costs nothing (a
+    // segment is the unit)
+    const int seg = slot % SEG;
+    int pix = slot / SEG;
+    if (pix < PPIX / 8 * 8) pix = (pix & ~7) + ((pix & 7) >> 1) + 4 * (pix & 1);
     const int prow = pix / PWC, idx = pix - prow * PWC;
     const int pcol = idx < ODD0 ? 2 * idx : 2 * (idx - ODD0) + 1;
     const int iy = 2 * y0 - 1 + prow, ix = 2 * x0 - 1 + pcol;
@@ -952,7 +958,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
     const int slot = (tid + 256 * j) % B_SLOTS;
-    const int row = slot / SEG, seg = slot % SEG;
+    const int seg = slot % SEG;
+    int row = slot / SEG;
+    row = (row & ~7) + ((row & 7) >> 1) + 4 * (row & 1);   // (as the patch slots: BN % 8 == 0)
     wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
     wslot_lds[j] = row * LDA + seg * 4;
   }
