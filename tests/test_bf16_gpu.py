@@ -363,8 +363,8 @@ def test_bf16_full_size_layers_and_batch_split(ua):
 @pytest.mark.parametrize("case", [(1, 256, 256, 32, 128, False, 1), (2, 256, 256, 64, 64, True, 1),
                                   (2, 256, 256, 32, 32, False, 1), (2, 16, 16, 64, 64, False, 1),
                                   (8, 16, 16, 512, 512, False, 1), (2, 32, 32, 128, 64, True, 1),
-                                  (4, 256, 256, 64, 32, False, 2), (8, 64, 64, 256, 128, False, 2),
-                                  (2, 128, 128, 128, 64, True, 2)])
+                                  (4, 256, 256, 64, 32, False, 2), (8, 128, 128, 256, 128, False, 2),
+                                  (8, 128, 128, 128, 64, True, 2)])
 def test_data_gradient_b16_emits_next_norm_reductions(ua, case):
     """unet_conv3x3_bwd_data_bs_b16: the BSTATS epilogue on bf16 tensors (sums from the fp32
     accumulators and the bf16 raw outputs of the layer) - the stride-1 patch kernel, and since

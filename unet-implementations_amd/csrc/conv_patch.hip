@@ -2014,8 +2014,18 @@ int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_
   const int nc = p.Ncols;
   const long long mt = M / 128;
   const bool fused = stats_px != nullptr;
+#ifdef UNET_EXP_B16_TH8
+  // experiment: 8 x 32-pixel tiles of 64 columns (half the weight-panel traffic per output)
+  const bool th8 = nc % 64 == 0 && p.Hin % 8 == 0 && (M / 256) * (nc / 64) >= 512;
+#else
+  const bool th8 = false;
+#endif
   if (!fused && bs_px && p.bs_partial) {   // data gradient with the BSTATS epilogue
     p.bs_tile0 = 0;
+    if (th8) {
+      *bs_px = 256; p.bs_tiles = p.Hin * p.Win / 256;
+      return launch_patch_b16_t<64, 64, 64, 8, false, false, true>(p, stream);
+    }
     if (nc % 128 == 0 && mt * (nc / 128) >= 256) {
       *bs_px = 128; p.bs_tiles = p.Hin * p.Win / 128;
       return launch_patch_b16_t<128, 64, 64, 4, false, false, true>(p, stream);
@@ -2031,6 +2041,11 @@ int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_
     return 1;
   }
   p.bs_partial = nullptr;
+  if (th8) {
+    if (!fused) return launch_patch_b16_t<64, 64, 64, 8, false, false>(p, stream);
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_patch_b16_t<64, 64, 64, 8, true, true>(p, stream);
+  }
   if (nc % 128 == 0 && mt * (nc / 128) >= 256) {
     if (!fused) return launch_patch_b16_t<128, 64, 64, 4, false, false>(p, stream);
     *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;

@@ -1315,6 +1315,15 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
     else if (pl.ci_t == 64) pl.S = (stride == 2 || prec == 3) ? 16 : 32;  // bf16x3: 3 planes in LDS
     else if (pl.co_t == 64) pl.S = 32;                       // 32x64 tile
     else pl.S = (stride == 1 && Wo >= 64) ? 64 : 32;         // 32x32 tile
+    // bf16 operands, stride 1 (one bf16 plane per stage: half the LDS of the fp32 stages): twice
+    // the segment.  At the bf16 matrix rate a segment's MFMAs are over in a few hundred cycles and
+    // every segment exposes a global-load round trip (one stage of prefetch), so the kernel is
+    // bound by segments per second, not by FLOPs or bytes: 2.75 us per 32-pixel segment measured
+    // on the 64-channel layers (round 3 profile: 88 us for 32 segments per workgroup).
+    if (prec == 1 && stride == 1) {
+      if (pl.ci_t == 64 && Wo >= 64) pl.S = 64;                          // 67 KB: two workgroups per CU
+      else if (pl.ci_t == 32 && pl.co_t == 32 && Wo >= 128) pl.S = 128;  // 66 KB
+    }
   }
   pl.segs_per_row = ceil_div(Wo, pl.S);
   pl.total_segs = N * Ho * pl.segs_per_row;
@@ -2305,10 +2314,13 @@ int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int
     if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_s2<32, 64, 32>(p, stream);
   }
   if (use_bf16 && prec == 1) {
-    if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64>(p, stream);
+    if (pl.ci_t == 32 && pl.co_t == 32)
+      return pl.S == 128 ? launch_wgrad_bf16<32, 32, 128>(p, stream)
+                         : launch_wgrad_bf16<32, 32, 64>(p, stream);
     if (pl.ci_t == 32) return launch_wgrad_bf16<32, 64, 32>(p, stream);
-    return pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
-                      : launch_wgrad_bf16<64, 64, 16>(p, stream);
+    return pl.S == 64   ? launch_wgrad_bf16<64, 64, 64>(p, stream)
+           : pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
+                        : launch_wgrad_bf16<64, 64, 16>(p, stream);
   }
   if (pl.ci_t == 32 && pl.co_t == 32) {
     if (stride == 1)
@@ -2385,8 +2397,10 @@ extern "C" size_t unet_conv3x3_bwd_weight_workspace_bytes(int N, int H, int W, i
   const size_t a = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0);
   const size_t b = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 3);
   const size_t c = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 0, true);
+  const size_t e = wgrad_ws_floats(N, H, W, Cx, Cout, stride, 1);   // bf16: longer segments
   size_t m = a > b ? a : b;
   if (c > m) m = c;
+  if (e > m) m = e;
   if (Cx != 3 && wgrad_wino_ok(N, H, W, Cx, Cout, stride)) {
     const size_t d = make_plan_wino(N, H, W, Cx, Cout).ws_floats;
     if (d > m) m = d;
@@ -2423,7 +2437,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   UNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "conv3x3_bwd_weight: Cout %d not a multiple of 32", Cout);
   UNET_REQUIRE(Cx == 3 || (Cx > 0 && Cx % 32 == 0), "conv3x3_bwd_weight: Cx %d unsupported", Cx);
   UNET_REQUIRE(ci_offset >= 0 && ci_offset + Cx <= Cin_total, "conv3x3_bwd_weight: bad ci slice");
-  const int pprec = (prec == 3 && stride == 1) ? 3 : 0;
+  const int pprec = (prec == 3 && stride == 1) ? 3 : ((prec == 1 && stride == 1) ? 1 : 0);
   // fp32 tensors on the fp32 matrix cores: the 8-wave kernel (parts merged in LDS)
   // fp32 tensors on the fp32 matrix cores: with >= 4 channel tiles the 8-wave kernel (one
   // workgroup per CU, <= 64 pixel splits, 16 pixel pairs per barrier); the 32 / 64-channel layers
