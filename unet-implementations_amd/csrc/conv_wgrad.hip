@@ -1315,15 +1315,9 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
     else if (pl.ci_t == 64) pl.S = (stride == 2 || prec == 3) ? 16 : 32;  // bf16x3: 3 planes in LDS
     else if (pl.co_t == 64) pl.S = 32;                       // 32x64 tile
     else pl.S = (stride == 1 && Wo >= 64) ? 64 : 32;         // 32x32 tile
-    // bf16 operands, stride 1 (one bf16 plane per stage: half the LDS of the fp32 stages): twice
-    // the segment.  At the bf16 matrix rate a segment's MFMAs are over in a few hundred cycles and
-    // every segment exposes a global-load round trip (one stage of prefetch), so the kernel is
-    // bound by segments per second, not by FLOPs or bytes: 2.75 us per 32-pixel segment measured
-    // on the 64-channel layers (round 3 profile: 88 us for 32 segments per workgroup).
-    if (prec == 1 && stride == 1) {
-      if (pl.ci_t == 64 && Wo >= 64) pl.S = 64;                          // 67 KB: two workgroups per CU
-      else if (pl.ci_t == 32 && pl.co_t == 32 && Wo >= 128) pl.S = 128;  // 66 KB
-    }
+    // (tried for the bf16 operands, whose stages are half as large: segments of 64 / 128 pixels
+    // on the 64 x 64 / 32 x 32 tiles - the bf16 weight-gradient group went from 2.40 to 2.74 ms
+    // per step, profiles/r04_bf16_experiments.txt: kept at 32 / 64)
   }
   pl.segs_per_row = ceil_div(Wo, pl.S);
   pl.total_segs = N * Ho * pl.segs_per_row;
@@ -2314,13 +2308,10 @@ int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int
     if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_s2<32, 64, 32>(p, stream);
   }
   if (use_bf16 && prec == 1) {
-    if (pl.ci_t == 32 && pl.co_t == 32)
-      return pl.S == 128 ? launch_wgrad_bf16<32, 32, 128>(p, stream)
-                         : launch_wgrad_bf16<32, 32, 64>(p, stream);
+    if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64>(p, stream);
     if (pl.ci_t == 32) return launch_wgrad_bf16<32, 64, 32>(p, stream);
-    return pl.S == 64   ? launch_wgrad_bf16<64, 64, 64>(p, stream)
-           : pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
-                        : launch_wgrad_bf16<64, 64, 16>(p, stream);
+    return pl.S == 32 ? launch_wgrad_bf16<64, 64, 32>(p, stream)
+                      : launch_wgrad_bf16<64, 64, 16>(p, stream);
   }
   if (pl.ci_t == 32 && pl.co_t == 32) {
     if (stride == 1)
