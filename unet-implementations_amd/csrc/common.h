@@ -145,6 +145,18 @@ __device__ __forceinline__ f32x4 buf_ld4(const __amdgpu_buffer_rsrc_t rs, unsign
   }
 }
 
+// the two halves of buf_ld4<__bf16>: the raw 8 bytes (two registers - a loader that keeps many
+// slots in flight holds half the registers until it converts) and the widening
+typedef int i32x2r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i32x2r buf_ld4_raw16(const __amdgpu_buffer_rsrc_t rs, unsigned off,
+                                                unsigned oob) {
+  return __builtin_amdgcn_raw_buffer_load_b64(rs, (off * 2u) | oob, 0, 0);
+}
+__device__ __forceinline__ f32x4 widen16(const i32x2r v) {
+  return f32x4{__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xffff0000),
+               __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xffff0000)};
+}
+
 // Chan/Welford merge of (count, mean, M2) pairs.
 __device__ __forceinline__ void wf_merge(float& n, float& mean, float& m2, float nb, float mb,
                                          float m2b) {

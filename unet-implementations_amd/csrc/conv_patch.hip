@@ -635,7 +635,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   // LDS stage (a full step of flight; with one set the loads of s + 1 were stored at the end of
   // the step that issued them)
   constexpr int B_SETS = WB ? 2 : 1;
-  f32x4 pr[P_PASSES], rb[B_SETS][B_PASSES];
+  i32x2r pr[P_PASSES];      // the patch slots in flight, raw (8 bytes = 4 bf16: two registers)
+  f32x4 rb[B_SETS][B_PASSES];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
     const int cc = (first ? c : c - p.C0) + seg4;
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i)
-      pr[i] = buf_ld4<__bf16>(rs, (unsigned)(pp_lin[i] * Cs + cc), pp_oob[i]);
+      pr[i] = buf_ld4_raw16(rs, (unsigned)(pp_lin[i] * Cs + cc), pp_oob[i]);
     if (ACT) {
       const float* al = first ? p.act0_alpha : p.act1_alpha;
       const float* be = first ? p.act0_beta : p.act1_beta;
@@ -683,8 +684,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i) {
-      if (ACT) pr[i] = act4(pr[i], ca, cb, cs, pp_oob[i] == 0u);
-      *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(pr[i]);
+      if (ACT) {
+        const f32x4 v = act4(widen16(pr[i]), ca, cb, cs, pp_oob[i] == 0u);
+        *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(v);
+      } else {   // a plain bf16 operand goes to LDS as it came (bf16 -> fp32 -> bf16 is the identity)
+        *reinterpret_cast<i32x2r*>(Ps + pp_lds[i]) = pr[i];
+      }
     }
   };
   auto load_b = [&](int row, int chunk, auto setc) {   // the three taps 3*row .. 3*row+2
