@@ -138,10 +138,12 @@ typedef struct unet_pack_entry {
   const float* w;   /* OIHW source [Cout][Cin][3][3] */
   float* wf;        /* [9][Cout][Cin] */
   float* wd;        /* [9][Cin][Cout] */
-  uint16_t* wf3;    /* [3][9][Cout][Cin] bf16 planes */
+  uint16_t* wf3;    /* [3][9][Cout][Cin] bf16 planes ([1][9][Cout][Cin] when planes == 1) */
   uint16_t* wd3;    /* [3][9][Cin][Cout] bf16 planes */
   int Cout, Cin;
-  int tile_begin, reserved;
+  int tile_begin;
+  int reserved;     /* planes: 0 or 3 = the three planes of the split-bf16 form; 1 = only plane 0,
+                       the bf16-rounded weight (what the mixed-precision kernels stage) */
 } unet_pack_entry;
 int unet_pack_conv3x3_weights_batched(const unet_pack_entry* table_device, int n, int total_tiles,
                                       unet_stream_t stream);

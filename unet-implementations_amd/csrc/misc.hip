@@ -180,13 +180,17 @@ __global__ __launch_bounds__(256) void pack_w_batched_kernel(const unet_pack_ent
   __syncthreads();
   __bf16* wf3 = reinterpret_cast<__bf16*>(e.wf3);
   __bf16* wd3 = reinterpret_cast<__bf16*>(e.wd3);
+  const bool one_plane = e.reserved == 1;   // (uniform) mixed precision: the rounded weight only
   auto put = [&](float* d, __bf16* d3, size_t i, float v) {
     if (d) d[i] = v;
     if (d3) {
       const __bf16 h = (__bf16)v;
-      const float r1 = v - (float)h;
-      const __bf16 md = (__bf16)r1;
-      d3[i] = h; d3[total + i] = md; d3[2 * total + i] = (__bf16)(r1 - (float)md);
+      d3[i] = h;
+      if (!one_plane) {
+        const float r1 = v - (float)h;
+        const __bf16 md = (__bf16)r1;
+        d3[total + i] = md; d3[2 * total + i] = (__bf16)(r1 - (float)md);
+      }
     }
   };
   if (e.wf || wf3)     // [t][co][ci]: consecutive lanes = consecutive ci

@@ -237,12 +237,15 @@ class PackTable:
             wd = _f32((9, cin, cout), w)
             wf3 = wd3 = None
             if planes and cin != 3:
-                wf3 = torch.empty((3, 9, cout, cin), dtype=torch.bfloat16, device=w.device)
-                wd3 = torch.empty((3, 9, cin, cout), dtype=torch.bfloat16, device=w.device)
+                # planes: True / 3 = the three split planes, 1 = the bf16-rounded weight alone
+                npl = 1 if planes == 1 and planes is not True else 3
+                wf3 = torch.empty((npl, 9, cout, cin), dtype=torch.bfloat16, device=w.device)
+                wd3 = torch.empty((npl, 9, cin, cout), dtype=torch.bfloat16, device=w.device)
             self.wf.append(wf); self.wd.append(wd); self.wf3.append(wf3); self.wd3.append(wd3)
             raw += struct.pack("<5Q4i", w.data_ptr(), wf.data_ptr(), wd.data_ptr(),
                                0 if wf3 is None else wf3.data_ptr(),
-                               0 if wd3 is None else wd3.data_ptr(), cout, cin, tiles, 0)
+                               0 if wd3 is None else wd3.data_ptr(), cout, cin, tiles,
+                               1 if (wf3 is not None and wf3.shape[0] == 1) else 0)
             tiles += (cout // 32) * ((cin + 31) // 32)
         self.n, self.tiles = len(weights), tiles
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(weights[0].device)

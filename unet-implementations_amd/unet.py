@@ -648,7 +648,7 @@ class _UNetFunction(torch.autograd.Function):
         table = model.__dict__.get("_pack_table")
         # (the bf16 planes: all three terms in the split mode; in the mixed-precision mode their
         # first plane is the bf16-rounded weight the patch kernels stage without a conversion)
-        planes = bf16 == "bf16x3" or (bf16 == "bf16" and model.fused_pipeline)
+        planes = 3 if bf16 == "bf16x3" else (1 if (bf16 == "bf16" and model.fused_pipeline) else False)
         if table is None or not table.matches(convs, planes, wino):
             table = model.__dict__["_pack_table"] = ops.PackTable(convs, planes, wino)
         table.run()
