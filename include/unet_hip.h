@@ -663,6 +663,17 @@ int unet_instnorm_lrelu_drop_bwd_b16(const uint16_t* ga, const uint16_t* y, cons
                                      unet_stream_t stream);
 int unet_upsample2x_in_fwd_b16(const unet_act_src* x, float slope, uint16_t* up, int N, int h,
                                int w, unet_stream_t stream);
+/* unet_conv_up_in_fwd on bf16 tensors: the first convolution of a decoder stage with the bilinear
+ * 2x up-sampling of the (activated) low-resolution source done in the loader - no up-sampled
+ * tensor (round 4; bit-identical to unet_upsample2x_in_fwd_b16 + unet_conv_in_fwd_b16_wb).
+ * low [N][H/2][W/2][C0], skip [N][H][W][C1] (both activated on load), y [N][H][W][Cout] bf16;
+ * w3 = the bf16-rounded plane of the packed weights (required).  Replaces UpBlock.forward
+ * (Our_UNet/models/unet.py:215-231) under autocast. */
+int unet_conv_up_in_fwd_b16_supported(int N, int H, int W, int C0, int C1, int Cout);
+int unet_conv_up_in_fwd_b16(const unet_act_src* low, const unet_act_src* skip, float slope,
+                            const float* wf, const uint16_t* w3, const float* bias, uint16_t* y,
+                            void* workspace, size_t workspace_bytes, int* stats_px_out, int N,
+                            int H, int W, int Cout, unet_stream_t stream);
 int unet_upsample2x_bwd_taps_b16(const uint16_t* dy, uint16_t* D, int N, int h, int w, int C,
                                  unet_stream_t stream);
 int unet_conv3x3_up_bwd_weight_b16(const unet_act_src* x, float slope, const uint16_t* D,

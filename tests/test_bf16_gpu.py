@@ -248,6 +248,43 @@ def test_up_backward_b16(ua, case):
         check(outs[0][2], outs[1][2], 3e-3, "dbeta")
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, 64, 32, 32, True), (8, 32, 32, 512, 512, 512, True),
+                                  (2, 128, 128, 256, 128, 128, True), (4, 256, 256, 128, 64, 64, True),
+                                  (1, 256, 256, 128, 64, 64, True), (2, 16, 32, 64, 64, 64, False)])
+def test_conv_up_in_fwd_b16_is_the_materialised_form_bit_for_bit(ua, case):
+    """unet_conv_up_in_fwd_b16 (round 4): the first convolution of a decoder stage on bf16 tensors
+    with the bilinear up-sampling in the patch loader.  The loader blends the ACTIVATED fp32 taps
+    in PyTorch's order and rounds once - exactly what unet_upsample2x_in_fwd_b16 stores - so y and
+    the statistics must be IDENTICAL to the materialised form (up-sampled bf16 tensor + the
+    two-source convolution), which test_conv_in_fwd_b16 / the network tests hold to the oracle;
+    and y is checked against fp64 directly."""
+    N, H, W, C0, C1, Cout, tiled = case
+    low, skip = r16(rnd(N, C0, H // 2, W // 2, seed=1)), r16(rnd(N, C1, H, W, seed=2))
+    cl, cs = coeffs(N, C0, 10), coeffs(N, C1, 20)
+    w = rnd(Cout, C0 + C1, 3, 3, seed=3, scale=(2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.3)
+    gamma, beta = (rnd(Cout, seed=5) * 0.2 + 1.0).to(DEV), (rnd(Cout, seed=6) * 0.2).to(DEV)
+    table = ua.ops.PackTable([w.to(DEV)], 1, None)
+    table.run()
+    wf, w3 = table.wf[0], table.wf3[0]
+    s_low, s_skip = src(ua, low, cl), src(ua, skip, cs)
+    assert ua.ops.conv_up_in_fwd_supported(s_low, s_skip, Cout) == tiled
+    if not tiled:      # (too few tiles: UNet.forward materialises the up-sampled tensor)
+        return
+    y, st = ua.ops.conv_up_in_fwd(s_low, s_skip, SLOPE, wf, b.to(DEV), gamma, beta, 1e-5, None, w3=w3)
+    up = ua.ops.upsample2x_in_fwd(s_low, SLOPE)
+    y2, st2 = ua.ops.conv_in_fwd(ua.ops.Act(up), s_skip, SLOPE, wf, b.to(DEV), 3, 1, gamma, beta,
+                                 1e-5, None, b16=True, w3=w3)
+    assert y.dtype == BF and torch.equal(y, y2), "the loader form differs from the materialised form"
+    assert torch.equal(st, st2)
+    z_low = low.float() * cl[0][:, :, None, None] + cl[1][:, :, None, None]
+    a_up = r16(F.interpolate(F.leaky_relu(z_low, SLOPE), scale_factor=2, mode="bilinear",
+                             align_corners=False)).double()      # fp32 blend, ONE rounding
+    y_ref = F.conv2d(torch.cat([a_up, r16(act_ref(skip, *cs).float()).double()], 1), r16(w).double(),
+                     b.double(), padding=1)
+    check(from_nhwc(y), y_ref, 6e-3, "y (stored as bf16)")
+
+
 # --------------------------------------------------------------------------- whole network
 def _hip_run(ua, sd0, img, tgt, masks, mode, fused=True):
     model = ua.UNet()

@@ -159,6 +159,9 @@ SIGNATURES = {
     "unet_upsample2x_in_fwd_b16": (_i, [_ps, _f, _p, _i, _i, _i, _p]),
     "unet_upsample2x_bwd_taps_b16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "unet_conv3x3_up_bwd_weight_b16": (_i, [_ps, _f, _p, _p, _i, _i, _p, _sz, _i, _i, _i, _i, _p]),
+    "unet_conv_up_in_fwd_b16_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "unet_conv_up_in_fwd_b16": (_i, [_ps, _ps, _f, _p, _p, _p, _p, _p, _sz, _c.POINTER(_i), _i, _i, _i,
+                                     _i, _p]),
     "unet_conv3x3_up_bwd_data_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_up_bwd_data_bs_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _pbs, _p]),
     "unet_head1x1_in_fwd_b16": (_i, [_ps, _f, _p, _p, _p, _i, _i, _i, _p]),

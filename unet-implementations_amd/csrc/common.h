@@ -157,6 +157,22 @@ __device__ __forceinline__ f32x4 widen16(const i32x2r v) {
                __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xffff0000)};
 }
 
+// Bilinear blend of a 2 x 2 neighbourhood with the fused multiply-adds SPELLED OUT (the compiler's
+// own contraction differs from kernel to kernel): the bf16 up-sampling kernel and the up-sampling
+// loader of conv_patch_b16_kernel both call this, which is what makes the two bit-identical.
+__device__ __forceinline__ f32x4 blend2x2(const f32x4 p00, const f32x4 p01, const f32x4 p10,
+                                          const f32x4 p11, float wx0, float wx1, float wy0,
+                                          float wy1) {
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t0 = __builtin_fmaf(p01[k], wx1, p00[k] * wx0);
+    const float t1 = __builtin_fmaf(p11[k], wx1, p10[k] * wx0);
+    v[k] = __builtin_fmaf(t1, wy1, t0 * wy0);
+  }
+  return v;
+}
+
 // Chan/Welford merge of (count, mean, M2) pairs.
 __device__ __forceinline__ void wf_merge(float& n, float& mean, float& m2, float nb, float mb,
                                          float m2b) {

@@ -1933,6 +1933,68 @@ static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_tot
   return rc;
 }
 
+// unet_conv_up_in_fwd on bf16 tensors (mixed-precision pipeline): low [N][H/2][W/2][C0] and
+// skip [N][H][W][C1] are bf16 and activated on load, y [N][H][W][Cout] is bf16; wf fp32 packed
+// weights, w3 (may be null) their bf16-rounded plane.  1 from _supported = a tile shape exists.
+extern "C" int unet_conv_up_in_fwd_b16_supported(int N, int H, int W, int C0, int C1, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 32 || C0 < 32 || C0 % 32 || C1 < 0 || C1 % 32 ||
+      Cout % 32)
+    return 0;
+  const long long M = (long long)N * H * W, mt = M / 128;
+  if ((long long)H * W * (C0 > 4 * C1 ? C0 / 4 : C1) * 2 * N >= (1LL << 31)) return 0;
+  if (Cout % 64 == 0 && mt * (Cout / 64) >= 256) return 1;
+  if (Cout == 32 && H % 8 == 0 && M / 256 >= 256) return 1;
+  return 0;
+}
+
+extern "C" int unet_conv_up_in_fwd_b16(const unet_act_src* low, const unet_act_src* skip,
+                                       float slope, const float* wf, const uint16_t* w3,
+                                       const float* bias, uint16_t* y, void* workspace,
+                                       size_t workspace_bytes, int* stats_px_out, int N, int H,
+                                       int W, int Cout, unet_stream_t stream) {
+  UNET_REQUIRE(low && low->x && wf && w3 && y && workspace && stats_px_out,
+               "conv_up_in_fwd_b16: null pointer (w3, the bf16 weight plane of unet_pack_w_batched, "
+               "is required here)");
+  const int C0 = low->C, C1 = skip ? skip->C : 0;
+  UNET_REQUIRE(C1 == 0 || skip->x, "conv_up_in_fwd_b16: skip source is null");
+  UNET_REQUIRE(low->alpha && low->beta && (!skip || (skip->alpha && skip->beta)),
+               "conv_up_in_fwd_b16: the loader takes activated sources (alpha / beta set)");
+  UNET_REQUIRE(H % 2 == 0 && W % 2 == 0 && unet_conv_up_in_fwd_b16_supported(N, H, W, C0, C1, Cout),
+               "conv_up_in_fwd_b16: shape N=%d %dx%d (%d+%d)->%d has no fused-upsample tile (query "
+               "unet_conv_up_in_fwd_b16_supported and fall back to unet_upsample2x_in_fwd_b16)",
+               N, H, W, C0, C1, Cout);
+  if (workspace_bytes < unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1)) {
+    unet_set_error("conv_up_in_fwd_b16: workspace too small");
+    return UNET_E_WORKSPACE;
+  }
+  IgemmParams p{};
+  p.src0 = low->x; p.src1 = skip ? skip->x : nullptr; p.C0 = C0; p.C1 = C1;
+  p.act0_alpha = low->alpha; p.act0_beta = low->beta;
+  p.act1_alpha = skip ? skip->alpha : nullptr;
+  p.act1_beta = skip ? skip->beta : nullptr;
+  p.slope = slope;
+  p.w = wf; p.tap_stride = Cout * (C0 + C1); p.n_off = 0; p.bias = bias;
+  if (w3) {
+    p.w3 = reinterpret_cast<const __bf16*>(w3);
+    p.w3_plane = 9 * Cout * (C0 + C1);
+    p.w3_bytes = (unsigned)((long long)p.w3_plane * 2);
+  }
+  p.src0_bytes = (unsigned)((long long)N * (H / 2) * (W / 2) * C0 * 2);
+  p.src1_bytes = (unsigned)((long long)N * H * W * C1 * 2);
+  p.w_bytes = (unsigned)((long long)9 * Cout * (C0 + C1) * 4);
+  p.out = reinterpret_cast<float*>(y); p.ldo = Cout; p.accumulate = 0;
+  p.N = N; p.Hin = H; p.Win = W; p.Hl = p.Hout = H; p.Wl = p.Wout = W;
+  p.Ncols = Cout;
+  p.stats = reinterpret_cast<float2*>(workspace);
+  fill_fwd_taps(p, 1);
+  int px = 0;
+  const int rc = launch_patch_b16_up_auto(p, (hipStream_t)stream, &px);
+  UNET_REQUIRE(rc != 1, "conv_up_in_fwd_b16: no tile fits");
+  if (rc != UNET_OK) return rc;
+  *stats_px_out = px;
+  return UNET_OK;
+}
+
 // RGB stem straight from the dataset's uint8 HWC image: normalisation fused into the loader
 // (Our_UNet/src/train.py:303-308 + the first Conv2d of encoder_stages.0), statistics epilogue as
 // unet_conv_in_fwd.  Needs W % 128 == 0 (the raw-row form); other widths: unet_preprocess_u8.

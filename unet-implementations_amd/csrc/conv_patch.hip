@@ -561,12 +561,26 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 // MFMAs per wave between barriers at 128 columns.  Weights stay fp32 in HBM (master copy) and
 // are rounded while staged.  LDS 16 KB patch + 61 KB weights at 128 columns (two per CU).
 // ---------------------------------------------------------------------------
+// UP (fused forward of a decoder stage's first convolution, round 4): source 0 is the
+// LOW-resolution tensor [N][H/2][W/2][C0]; per 32-channel chunk of it the (TH/2 + 2) x 18
+// low-resolution pixels under the tile's patch are activated (fp32) and staged into an fp32 LDS
+// scratch, and every patch pixel is blended from its 2 x 2 neighbours in PyTorch's operation
+// order and rounded to bf16 ONCE - the value the materialised form (upsample2x_fwd_b16x8_kernel
+// + this kernel on its output) stages, so the two are bit-identical and the up-sampled tensor
+// (268 MB at 512 x 512) is neither written nor read.  As conv_patch_up_kernel (fp32).
 template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false,
-          bool WB = false>
-__global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParams p) {
+          bool WB = false, bool UP = false>
+// (32-accumulator tiles without the up-sampling loader - and, when fused, with the pre-rounded
+// weight panels - stay under 170 registers and 48 KB of LDS: three workgroups per CU - the short K loops of the 32- and 64-channel layers expose one
+// HBM latency per chunk, and the third workgroup is what covers it)
+__global__ __launch_bounds__(256, ((WM / 32) * (WN / 32) <= 2 && !UP && (WB || !ACT)) ? 3 : 2)
+void conv_patch_b16_kernel(const IgemmParams p) {
+  static_assert(!UP || (ACT && STATS && !BSTATS), "UP is a fused-forward loader");
   constexpr int BK = 32, LDA = BK + 8;       // bf16 elements per LDS row
   constexpr int TW = 32, PW = TW + 2;
   constexpr int PPIX = (TH + 2) * PW;
+  constexpr int LW = TW / 2 + 2, LPIX = (TH / 2 + 2) * LW;   // UP: low-resolution scratch pixels
+  constexpr int L_PASSES = (LPIX * 8 + 255) / 256, LLD = 36;  // fp32 scratch rows of 36 floats
   constexpr int P_SLOTS = PPIX * 8;          // 4-channel slots: 32 channels per pixel
   constexpr int P_PASSES = (P_SLOTS + 255) / 256;
   // weight slots of a K step (three taps x BN rows x 32 channels): 4 fp32 channels per slot, or
@@ -580,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
   __bf16* Ps = smem_h;                       // [pixel][LDA]
   __bf16* Bs = smem_h + PPIX * LDA;          // [buf][tap in row][BN][LDA]
+  float* Ls = reinterpret_cast<float*>(Bs + 2 * B_TILE);   // UP: [low pixel][LLD] activated fp32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -604,20 +619,59 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
                                         : __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
-  int pp_lin[P_PASSES], pp_lds[P_PASSES];
-  unsigned pp_oob[P_PASSES];
+  // Per patch slot ONE register: the pixel index, bit 31 set for a zero-padding slot.  The LDS
+  // address is affine in the pass (32 pixels a pass); in the last pass the threads past the patch
+  // repeat their pass-0 slot (the same bytes to the same place) instead of wrapping around, which
+  // keeps it so.  (Three arrays of P_PASSES registers here were what held the fused forms of the
+  // 32-accumulator tiles at two workgroups per CU.)
+  constexpr int LAST = P_PASSES - 1;
+  const bool last_ok = tid + 256 * LAST < P_SLOTS;
+  auto slot_of = [&](int i) __attribute__((always_inline)) {
+    return (i == LAST && !last_ok) ? tid : tid + 256 * i;
+  };
+  int pp_lin[P_PASSES];
 #pragma unroll
   for (int i = 0; i < P_PASSES; ++i) {
-    const int slot = (tid + 256 * i) % P_SLOTS;
-    const int pix = slot >> 3, seg = slot & 7;
+    const int pix = slot_of(i) >> 3;
     const int prow = pix / PW, pcol = pix - prow * PW;
     const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    pp_lin[i] = ok ? (n * H + iy) * W + ix : 0;            // pixel index
-    pp_oob[i] = ok ? 0u : 0x80000000u;
-    pp_lds[i] = pix * LDA + seg * 4;
+    pp_lin[i] = ok ? (n * H + iy) * W + ix : (int)0x80000000;
   }
+  const int pp_lds0 = (tid >> 3) * LDA + (tid & 7) * 4;
+  auto pp_lds = [&](int i) __attribute__((always_inline)) {
+    return (i == LAST && !last_ok) ? pp_lds0 : pp_lds0 + i * 32 * LDA;
+  };
+  auto pp_oob = [&](int i) __attribute__((always_inline)) {
+    return (unsigned)pp_lin[i] & 0x80000000u;
+  };
   const int seg4 = (tid & 7) * 4;            // this thread's four channels within a chunk
+  // UP: low-resolution scratch slots (clamped pixel index of the source; a pass = 32 pixels) and,
+  // per patch slot, its top-left scratch pixel (bits 4..) + the parities that pick the 0.75 / 0.25
+  // weights (bits 0, 1)
+  int lp_lin[UP ? L_PASSES : 1], pp_low[UP ? P_PASSES : 1];
+  if constexpr (UP) {
+    const int h = H >> 1, w = W >> 1;
+#pragma unroll
+    for (int j = 0; j < L_PASSES; ++j) {
+      const int lpix = (tid >> 3) + 32 * j;
+      const int lp = lpix < LPIX ? lpix : LPIX - 1;
+      const int lr = lp / LW, lc = lp - lr * LW;
+      int gy = (y0 >> 1) - 1 + lr, gx = (x0 >> 1) - 1 + lc;
+      gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+      lp_lin[j] = (n * h + gy) * w + gx;
+    }
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      const int pix = slot_of(i) >> 3;
+      const int prow = pix / PW, pcol = pix - prow * PW;
+      // (image row / column 0: PyTorch clamps the source coordinate to 0, weights (0, 1) on the
+      // clamped pair - bits 2, 3)
+      pp_low[i] = (((prow >> 1) * LW + (pcol >> 1)) << 4) | ((prow & 1) << 1) | (pcol & 1) |
+                  ((y0 - 1 + prow == 0) ? 8 : 0) | ((x0 - 1 + pcol == 0) ? 4 : 0);
+    }
+  }
   // weight slot j: (tap in row, column row, segment)
   unsigned wslot_off[B_PASSES];
   int wslot_lds[B_PASSES], wslot_tap[B_PASSES];
@@ -634,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   // WB: two register sets - the panel of step s + 2 is loaded while that of s + 1 waits for its
   // LDS stage (a full step of flight; with one set the loads of s + 1 were stored at the end of
   // the step that issued them)
-  constexpr int B_SETS = WB ? 2 : 1;
+  constexpr int B_SETS = (WB && !(BN == 32 && ACT)) ? 2 : 1;   // (32 fused columns: one set - registers for the third workgroup)
   i32x2r pr[P_PASSES];      // the patch slots in flight, raw (8 bytes = 4 bf16: two registers)
   f32x4 rb[B_SETS][B_PASSES];
   f32x16 acc[TM][TN];
@@ -645,22 +699,40 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
 
-  auto tap_of = [&](int t, int& oy, int& ox, int& wt) {
+  auto tap_of = [&](int t, int& oy, int& ox, int& wt) __attribute__((always_inline)) {
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
     oy = (int)(e & 3u) - 1; ox = (int)((e >> 2) & 3u) - 1; wt = (int)(e >> 4);
   };
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
   float cs = 1.f;
-  auto load_patch = [&](int chunk) {
+  static_assert(L_PASSES <= P_PASSES, "the low-resolution slots travel in pr[]");
+  bool up_chunk = false;           // UP: the chunk in the registers comes from source 0 (uniform)
+  // (opaque: the pixel index times the channel count of BOTH sources would otherwise be kept per
+  // pass across the K loop - 2 x P_PASSES registers that decide two or three workgroups per CU)
+  auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+  auto load_patch = [&](int chunk) __attribute__((always_inline)) {
     const int c = chunk * BK;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int Cs = first ? p.C0 : p.C1;
     const int cc = (first ? c : c - p.C0) + seg4;
+    if constexpr (UP) {
+      up_chunk = first;
+      if (first) {   // uniform: the low-resolution pixels under the patch (clamped, all valid)
 #pragma unroll
-    for (int i = 0; i < P_PASSES; ++i)
-      pr[i] = buf_ld4_raw16(rs, (unsigned)(pp_lin[i] * Cs + cc), pp_oob[i]);
+        for (int j = 0; j < L_PASSES; ++j)
+          pr[j] = buf_ld4_raw16(rs0, (unsigned)(lp_lin[j] * Cs + cc), 0u);
+      } else {
+#pragma unroll
+        for (int i = 0; i < P_PASSES; ++i)
+          pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < P_PASSES; ++i)
+        pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i));
+    }
     if (ACT) {
       const float* al = first ? p.act0_alpha : p.act1_alpha;
       const float* be = first ? p.act0_beta : p.act1_beta;
@@ -681,18 +753,62 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     return h;
   };
-  auto store_patch = [&]() {
+  // UP: activate the low-resolution slots (fp32) into the scratch; a barrier later every patch
+  // slot blends its 2 x 2 neighbours (PyTorch's order, as upsample2x_fwd_b16x8_kernel) and the
+  // result is rounded to bf16 once; zero padding after the blend
+  auto store_low = [&]() __attribute__((always_inline)) {
+    if constexpr (UP) {
 #pragma unroll
-    for (int i = 0; i < P_PASSES; ++i) {
-      if (ACT) {
-        const f32x4 v = act4(widen16(pr[i]), ca, cb, cs, pp_oob[i] == 0u);
-        *reinterpret_cast<bf16x4*>(Ps + pp_lds[i]) = to_bf16(v);
-      } else {   // a plain bf16 operand goes to LDS as it came (bf16 -> fp32 -> bf16 is the identity)
-        *reinterpret_cast<i32x2r*>(Ps + pp_lds[i]) = pr[i];
+      for (int j = 0; j < L_PASSES; ++j) {
+        const int lpix = (tid >> 3) + 32 * j;
+        if (lpix < LPIX)
+          *reinterpret_cast<f32x4*>(Ls + lpix * LLD + seg4) = act4(widen16(pr[j]), ca, cb, cs, true);
       }
     }
   };
-  auto load_b = [&](int row, int chunk, auto setc) {   // the three taps 3*row .. 3*row+2
+  auto blend_patch = [&]() __attribute__((always_inline)) {
+    if constexpr (UP) {
+#pragma unroll
+      for (int i = 0; i < P_PASSES; ++i) {
+        // (opaque per use: the scheduler would otherwise keep the scratch address, the four
+        // weights and the padding factor of EVERY pass in registers across the K loop)
+        int lw = pp_low[i];
+        unsigned oob = pp_oob(i);
+        asm volatile("" : "+v"(lw), "+v"(oob));
+        const float* L = Ls + (lw >> 4) * LLD + seg4;
+        const f32x4 p00 = *reinterpret_cast<const f32x4*>(L);
+        const f32x4 p01 = *reinterpret_cast<const f32x4*>(L + LLD);
+        const f32x4 p10 = *reinterpret_cast<const f32x4*>(L + LW * LLD);
+        const f32x4 p11 = *reinterpret_cast<const f32x4*>(L + LW * LLD + LLD);
+        // odd patch row = even image row 2k: taps (k-1, k) weigh (0.25, 0.75); even patch row =
+        // odd image row: (0.75, 0.25); columns alike (y0, x0 are even)
+        const float wy1 = (lw & 8) ? 1.f : ((lw & 2) ? 0.75f : 0.25f), wy0 = 1.f - wy1;
+        const float wx1 = (lw & 4) ? 1.f : ((lw & 1) ? 0.75f : 0.25f), wx0 = 1.f - wx1;
+        const float okf = oob == 0u ? 1.f : 0.f;
+        const f32x4 v = blend2x2(p00, p01, p10, p11, wx0, wx1, wy0, wy1) * okf;
+        *reinterpret_cast<bf16x4*>(Ps + pp_lds(i)) = to_bf16(v);
+        // two passes (eight ds_read_b128) in flight, no more: hoisting all 4 * P_PASSES reads
+        // ahead of the first blend is what the scheduler does otherwise (176 registers at TH = 8)
+        if (i & 1) asm volatile("" ::: "memory");
+      }
+    }
+  };
+  auto store_patch = [&]() __attribute__((always_inline)) {
+    if constexpr (UP) {
+      if (up_chunk) { blend_patch(); return; }   // uniform
+    }
+#pragma unroll
+    for (int i = 0; i < P_PASSES; ++i) {
+      if (ACT) {
+        const f32x4 v = act4(widen16(pr[i]), ca, cb, cs, pp_oob(i) == 0u);
+        *reinterpret_cast<bf16x4*>(Ps + pp_lds(i)) = to_bf16(v);
+        asm volatile("" ::: "memory");   // one slot's temporaries at a time
+      } else {   // a plain bf16 operand goes to LDS as it came (bf16 -> fp32 -> bf16 is the identity)
+        *reinterpret_cast<i32x2r*>(Ps + pp_lds(i)) = pr[i];
+      }
+    }
+  };
+  auto load_b = [&](int row, int chunk, auto setc) __attribute__((always_inline)) {   // the three taps 3*row .. 3*row+2
     constexpr int SET = decltype(setc)::value;
     int oy, ox, wt0, wt1, wt2;
     tap_of(3 * row, oy, ox, wt0);
@@ -706,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
                                                  rsw, wslot_off[j] + woff, 0, 0));
     }
   };
-  auto store_b = [&](int buf, auto setc) {
+  auto store_b = [&](int buf, auto setc) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
     __bf16* Bb = Bs + buf * B_TILE;
 #pragma unroll
@@ -723,7 +839,11 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   using S1 = std::integral_constant<int, B_SETS - 1>;
   load_patch(0);
   load_b(0, 0, S0{});
-  if constexpr (WB) load_b(steps > 1 ? 1 : 0, 0, S1{});   // (chunks >= 1: step 1 = row 1 of chunk 0)
+  if constexpr (B_SETS == 2) load_b(steps > 1 ? 1 : 0, 0, S1{});   // (chunks >= 1: step 1 = row 1 of chunk 0)
+  if constexpr (UP) {      // chunk 0 is a low-resolution one (C0 >= 32): scratch, barrier, blend
+    store_low();
+    __syncthreads();
+  }
   store_patch();
   store_b(0, S0{});
   __syncthreads();
@@ -733,13 +853,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
   int row = 0, chunk = 0;
   // one K step on LDS stage `buf` (SET: the register set that receives this step's load)
-  auto k_step = [&](int s, auto setc) {
+  auto k_step = [&](int s, auto setc) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
     using OTHER = std::integral_constant<int, (B_SETS - 1) - SET>;
     const int buf = s & 1;
     const int row1 = (row == 2) ? 0 : row + 1;
     const int chunk1 = (row == 2) ? chunk + 1 : chunk;
-    if constexpr (WB) {          // the panel of step s + 2 (the tail re-loads the last one)
+    if constexpr (B_SETS == 2) {          // the panel of step s + 2 (the tail re-loads the last one)
       const int row2 = (row1 == 2) ? 0 : row1 + 1;
       const int chunk2 = (row1 == 2) ? chunk1 + 1 : chunk1;
       const bool more2 = s + 2 < steps;
@@ -748,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
       const bool more = s + 1 < steps;
       load_b(more ? row1 : row, more ? chunk1 : chunk, setc);
     }
-    if (row == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+    if (row == 0 && chunk + 1 < chunks) load_patch(chunk + 1);   // (uniform; the last chunk stages nothing)
 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -772,9 +892,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
             acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[m][nb], 0, 0, 0);
       }
     }
-    if constexpr (WB) store_b(buf ^ 1, OTHER{});   // step s + 1's panel, loaded a step ago
+    if constexpr (B_SETS == 2) store_b(buf ^ 1, OTHER{});   // step s + 1's panel, loaded a step ago
     else store_b(buf ^ 1, setc);
-    if (row == 2) {            // every wave is done with this chunk's patch
+    if constexpr (UP) {        // the next chunk's low-resolution pixels: a barrier ahead of the blend
+      if (row == 1 && up_chunk && chunk + 1 < chunks) store_low();   // uniform
+    }
+    if (row == 2 && chunk + 1 < chunks) {   // every wave is done with this chunk's patch
       __syncthreads();
       store_patch();
     }
@@ -782,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
     row = row1;
     chunk = chunk1;
   };
-  if constexpr (WB) {
+  if constexpr (B_SETS == 2) {
     for (int s = 0; s < steps; s += 2) {
       k_step(s, S0{});
       if (s + 1 < steps) k_step(s + 1, S1{});
@@ -796,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
       const int chunk1 = (row == 2) ? chunk + 1 : chunk;
       const bool more = s + 1 < steps;
       load_b(more ? row1 : row, more ? chunk1 : chunk, S0{});
-      if (row == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+      if (row == 0 && chunk + 1 < chunks) load_patch(chunk + 1);   // (uniform; the last chunk stages nothing)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         int oy, ox, wt;
@@ -820,7 +943,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
         }
       }
       store_b(buf ^ 1, S0{});
-      if (row == 2) {            // every wave is done with this chunk's patch
+      if constexpr (UP) {
+        if (row == 1 && up_chunk && chunk + 1 < chunks) store_low();   // uniform
+      }
+      if (row == 2 && chunk + 1 < chunks) {   // every wave is done with this chunk's patch
         __syncthreads();
         store_patch();
       }
@@ -831,6 +957,47 @@ __global__ __launch_bounds__(256, 2) void conv_patch_b16_kernel(const IgemmParam
   }
 
   __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+  // Output tile through LDS (round 4): a lane of the 32 x 32 accumulator block holds ONE channel
+  // of 16 pixels, so the direct form is 16 two-byte stores per block (64-byte runs, the texture
+  // path's worst case).  The tile is rounded into [pixel][BN + 8] bf16 over the dead patch /
+  // weight stages and leaves as 16 bytes per lane, BN * 2 bytes contiguous per pixel.
+  constexpr int OLD = BN + 8;
+  static_assert(TH * 32 * OLD <= PPIX * LDA + 2 * B_TILE, "the output tile fits in the dead stages");
+  // (UP: the launcher checks it - the scalar form next to the loader's state spills)
+  const bool wide = UP || (!p.accumulate && (p.ldo & 7) == 0 &&
+                           (reinterpret_cast<uintptr_t>(outp) & 15) == 0);   // uniform
+  if (wide) {
+    __bf16* Os = smem_h;   // (the barrier that ends the last K step has passed)
+    // (the lane's tile coordinates are derived again from an opaque copy of the thread index:
+    // kept across the K loop they are what tips the 64-column loader form into scratch)
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int o_lane = (((te >> 6) / WAVES_N) * TM * 32 + 4 * ((te >> 5) & 1)) * OLD +
+                       ((te >> 6) % WAVES_N) * WN + (te & 31);
+#pragma unroll
+    for (int nb = 0; nb < TN; ++nb) {
+      const float bv = p.bias ? p.bias[n0 + wn0 + nb * 32 + li] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[m][nb][r] += bv;
+          Os[o_lane + (m * 32 + (r & 3) + 8 * (r >> 2)) * OLD + nb * 32] = (__bf16)acc[m][nb][r];
+        }
+    }
+    __syncthreads();
+    constexpr int SEGS = BN / 8, O_SLOTS = TH * 32 * SEGS;
+    static_assert(O_SLOTS % 256 == 0, "whole passes");
+#pragma unroll
+    for (int i = 0; i < O_SLOTS / 256; ++i) {
+      const int slot = te + 256 * i;
+      const int pix = slot / SEGS, seg = slot - pix * SEGS;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Os + pix * OLD + seg * 8);
+      *reinterpret_cast<f32x4*>(outp + (((size_t)n * H + (y0 + (pix >> 5))) * W + x0 + (pix & 31)) * p.ldo +
+                                n0 + seg * 8) = v;
+    }
+    __syncthreads();       // the statistics epilogues reuse the stages
+  } else if constexpr (!UP)
 #pragma unroll
   for (int nb = 0; nb < TN; ++nb) {
     const int col = n0 + wn0 + nb * 32 + li;
@@ -1464,13 +1631,14 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
   const int a_lane = (wrow0 * PW + li) * LDA + 8 * lh;
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
   for (int chunk = 0; chunk < chunks; ++chunk) {
-    const int chunk_n = chunk + 1 < chunks ? chunk + 1 : chunk;   // the last chunk re-stages itself
+    const bool more_chunks = chunk + 1 < chunks;   // (the last chunk stages no patch)
+    const int chunk_n = more_chunks ? chunk + 1 : chunk;
     for_range_p<0, 3>([&](auto sc) {
       constexpr int st = decltype(sc)::value;
       constexpr int st1 = st == 2 ? 0 : st + 1;
       const int buf = (chunk + st) & 1;   // step = 3 * chunk + st
       load_b(std::integral_constant<int, st1>{}, st == 2 ? chunk_n : chunk);
-      if (st == 0) load_patch(chunk_n);
+      if (st == 0 && more_chunks) load_patch(chunk_n);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         constexpr S2PTap T0 = kS2PTaps[3 * st], T1 = kS2PTaps[3 * st + 1], T2 = kS2PTaps[3 * st + 2];
@@ -1499,7 +1667,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
         }
       }
       store_b(buf ^ 1);
-      if (st == 2) {            // every wave is done with this chunk's patch
+      if (st == 2 && more_chunks) {   // every wave is done with this chunk's patch
         __syncthreads();
         store_patch();
       }
@@ -1989,6 +2157,48 @@ bool patch_s2_applicable(const IgemmParams& p) {
          p.Wl == p.Wout && p.Hl % 4 == 0 && p.Wl % 32 == 0 && p.C0 % 16 == 0 && p.C1 % 16 == 0 &&
          !p.accumulate && p.tapw[0] == std_taps.tapw[0] && p.tapw[1] == std_taps.tapw[1] &&
          p.tapw[2] == std_taps.tapw[2];
+}
+
+// fused forward with the up-sampling in the loader (source 0 = the low-resolution tensor)
+template <int BN, int WM, int WN, int TH>
+int launch_patch_b16_up_t(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((TH + 2) * 34) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16) +
+                         (size_t)((TH / 2 + 2) * 18) * 36 * sizeof(float);
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  const long long tiles = (long long)p.N * (p.Hin / TH) * (p.Win / 32) * (p.Ncols / BN);
+  // (only the pre-rounded weight panels, p.w3: the fp32-panel form of the 64-column tile spills)
+  auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, true, true, false, true, true>;
+  UNET_SET_DYN_LDS(kern, lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_b16(up)");
+  return UNET_OK;
+}
+
+// y = conv3x3(cat(upsample2x(act(low)), act(skip))) on bf16 tensors: p.src0 = low
+// [N][Hin/2][Win/2][C0], p.src1 = skip [N][Hin][Win][C1], both activated on load.  Returns 1 when
+// no tile shape fits (the caller materialises the up-sampled tensor).
+int launch_patch_b16_up_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+  IgemmParams p = p0;
+  if (p.Hin % 4 || p.Win % 32 || p.C0 % 32 || p.C1 % 32 || p.C0 < 32 || !p.act0_alpha ||
+      (p.C1 && !p.act1_alpha) || !p.w3 || p.accumulate || (p.ldo & 7) ||
+      (reinterpret_cast<uintptr_t>(p.out) & 15))
+    return 1;
+  const long long M = (long long)p.N * p.Hin * p.Win, mt = M / 128;
+  const int nc = p.Ncols;
+  p.bs_partial = nullptr;
+  if (nc % 64 == 0 && p.Hin % 8 == 0 && (M / 256) * (nc / 64) >= 512) {
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_patch_b16_up_t<64, 64, 64, 8>(p, stream);
+  }
+  if (nc % 64 == 0 && mt * (nc / 64) >= 256) {
+    *stats_px = p.stats ? 128 : 0; p.stats_tiles = p.Hin * p.Win / 128;
+    return launch_patch_b16_up_t<64, 64, 32, 4>(p, stream);
+  }
+  if (nc == 32 && p.Hin % 8 == 0 && (M / 256) >= 256) {
+    *stats_px = p.stats ? 256 : 0; p.stats_tiles = p.Hin * p.Win / 256;
+    return launch_patch_b16_up_t<32, 64, 32, 8>(p, stream);
+  }
+  return 1;
 }
 
 template <int BN, int WM, int WN, int TH, bool ACT, bool STATS, bool BSTATS = false>

@@ -316,8 +316,9 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_b16x8_kernel(
         bf16x8 out;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const f32x4 res = (v[a][bb][hf] * wx[bb][0] + v[a][bb + 1][hf] * wx[bb][1]) * wy[a][0] +
-                            (v[a + 1][bb][hf] * wx[bb][0] + v[a + 1][bb + 1][hf] * wx[bb][1]) * wy[a][1];
+          const f32x4 res = blend2x2(v[a][bb][hf], v[a][bb + 1][hf], v[a + 1][bb][hf],
+                                                v[a + 1][bb + 1][hf], wx[bb][0], wx[bb][1],
+                                                wy[a][0], wy[a][1]);
 #pragma unroll
           for (int k = 0; k < 4; ++k) out[4 * hf + k] = (__bf16)res[k];
         }

@@ -797,6 +797,9 @@ def conv_in_fwd(s0, s1, slope, w, bias, ksize, stride, gamma, beta, eps, mask, b
 
 def conv_up_in_fwd_supported(low, skip, Cout):
     N, H, W, C1 = skip.shape
+    if _is_b16(skip.x):     # mixed-precision pipeline: both sources activated bf16 tensors
+        return low.alpha is not None and skip.alpha is not None and _is_b16(low.x) and \
+            bool(lib().unet_conv_up_in_fwd_b16_supported(N, H, W, low.shape[3], C1, Cout))
     return bool(lib().unet_conv_up_in_fwd_supported(N, H, W, low.shape[3], C1, Cout))
 
 
@@ -805,10 +808,11 @@ def conv_up_wino_supported(N, H, W, C0, C1, Cout):
     return bool(lib().unet_conv_up_wino_supported(N, H, W, C0, C1, Cout))
 
 
-def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask, wu=None):
+def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask, wu=None, w3=None):
     """y = conv3x3(cat(upsample2x(act(low)), act(skip))) + bias with the up-sampling in the
     loader, plus the InstanceNorm statistics of y (as conv_in_fwd).  wu: the Winograd forward
-    form of the weight (shape checked by the caller with conv_up_wino_supported)."""
+    form of the weight (shape checked by the caller with conv_up_wino_supported).  bf16 sources
+    (the mixed-precision pipeline): y is bf16, w3 = the bf16-rounded weight plane or None."""
     low, rl = _act(low)
     skip, rs = _act(skip)
     N, H, W, C1 = skip.shape
@@ -816,6 +820,22 @@ def conv_up_in_fwd(low, skip, slope, wf, bias, gamma, beta, eps, mask, wu=None):
     assert low.shape[1] * 2 == H and low.shape[2] * 2 == W and low.shape[0] == N
     Cout = wf.shape[1]
     assert wf.shape[0] == 9 and wf.shape[2] == C0 + C1
+    if _is_b16(skip.x):
+        y = _b16((N, H, W, Cout), skip.x)
+        st = _f32((4, N, Cout), skip.x)
+        ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1), skip.x)
+        px = ctypes.c_int(0)
+        t0 = _timer.begin("conv") if _timer is not None else None
+        check(lib().unet_conv_up_in_fwd_b16(rl, rs, slope, _ptr(wf), _ptr(w3), _ptr(bias), _ptr(y),
+                                            _ptr(ws), ws.numel(), ctypes.byref(px), N, H, W, Cout,
+                                            _stream()))
+        if t0 is not None:
+            _timer.end("conv_igemm_bf16", 2.0 * N * H * W * 9 * (C0 + C1) * Cout, 1, t0)
+        check(lib().unet_conv_in_stats_finalize_b16(_ptr(y), _ptr(ws), ws.numel(), px.value,
+                                                    _ptr(gamma), _ptr(beta), eps, _ptr(mask),
+                                                    _ptr(st[0]), _ptr(st[1]), _ptr(st[2]),
+                                                    _ptr(st[3]), N, H * W, Cout, _stream()))
+        return y, st
     y = _f32((N, H, W, Cout), skip.x)
     st = _f32((4, N, Cout), skip.x)
     ws = _ws(lib().unet_conv_in_fwd_workspace_bytes(N, H, W, Cout, 1), skip.x)

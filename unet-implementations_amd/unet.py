@@ -726,25 +726,28 @@ class _UNetFunction(torch.autograd.Function):
             The up-sampled tensor only lives for this call: backward works on `low`
             (ops.conv3x3_up_bwd_weight / _data)."""
             w = l.conv.weight
-            if not b16 and not x3 and l.ksize == 3 and \
-                    ops.conv_up_in_fwd_supported(low, skip, w.shape[0]):
+            if not x3 and l.ksize == 3 and ops.conv_up_in_fwd_supported(low, skip, w.shape[0]):
                 # the bilinear gather runs inside the conv's patch loader: no up-sampled tensor
+                # (fp32 tensors; bf16 tensors since round 4)
                 k = packed[id(w)]
                 m = mask_of[id(l)]
                 n_, h_, w_, c1_ = skip.shape
-                wu = table.uf[k] if (table.uf[k] is not None and low.alpha is not None and
+                wu = table.uf[k] if (not b16 and table.uf[k] is not None and
+                                     low.alpha is not None and
                                      skip.alpha is not None and ops.conv_up_wino_supported(
                                          n_, h_, w_, low.shape[3], c1_, w.shape[0])) else None
                 y, st = ops.conv_up_in_fwd(low, skip, slope, table.wf[k], l.conv.bias.detach(),
                                            l.norm.weight.detach(), l.norm.bias.detach(),
-                                           l.norm.eps, m, wu=wu)
+                                           l.norm.eps, m, wu=wu,
+                                           w3=table.wf3[k] if b16 else None)
                 if need_grad:
                     # Winograd form of the data gradient into the skip half
                     n_, h_, w_, c1_ = skip.shape
                     ud1 = table.ud[k] if (table.ud[k] is not None and ops.conv_wino_supported(
                         n_, h_, w_, w.shape[0], 0, c1_)) else None
                     saved.append(dict(layer=l, x0=None, x1=skip, y=y, st=st, mask=m,
-                                      wd=table.wd[k], wd3=None, x0_low=low, ud1=ud1))
+                                      wd=table.wd[k], wd3=table.wd3[k] if b16 else None,
+                                      x0_low=low, ud1=ud1))
                 if dbg_fwd is not None:
                     dbg_fwd.append((l.name, y, st))
                 return ops.Act(y, st[2], st[3])
