@@ -843,6 +843,231 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
 
 
 // ---------------------------------------------------------------------------
+// Mixed-precision weight gradient, stride 1, bf16 tensors: the ROW-RING form (round 4).
+//
+// conv_wgrad_bf16_kernel stages, per segment of S pixels, the three input rows under it and
+// prefetches ONE segment ahead: a segment is 18 MFMAs per wave (0.25 us) while a load takes
+// 1-2 us to come back under load, so every segment waits for its operands (PMC r04: matrix
+// cores busy 16 %, waves waiting 56 % of their cycles), and every input row is fetched and
+// activated three times.  Here a workgroup walks DOWN a column strip (S output pixels wide):
+//   * the input rows live in a four-slot ring in LDS ([sub-tile][slot][S + 2 pixels][32] bf16,
+//     slot = row & 3): a step reads rows oy-1 .. oy+1 and fills the slot of row oy+2 - each row
+//     is loaded, activated and rounded ONCE (a third of the loads and of the activation VALU);
+//   * the operands of a step are one input row and one dy row, 16 bytes per lane and load:
+//     12 registers a step, so the loads of DEPTH = 4 steps are in flight (the old form held
+//     36 registers for one);
+//   * the activation coefficients depend on (image, channel) only: read once per workgroup.
+// Blocking, MFMA fragments (ds_read_b64_tr_b16), slabs and the merge epilogue are those of
+// conv_wgrad_bf16_kernel.  g in [0, total_segs) enumerates (image, strip, output row) with the
+// row fastest; a workgroup's range lies inside one strip (the plan makes segs_per_block divide
+// Ho and a multiple of DEPTH).
+// ---------------------------------------------------------------------------
+template <int CI_T, int CO_T, int S, bool ACT, int DEPTH>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_b16_ring_kernel(const WgradParams p) {
+  constexpr int TI = CI_T / 32, TJ = CO_T / 32;
+  constexpr int NSB = TI * TJ, NPP = 4 / NSB, NT = 256;
+  constexpr int PW = S + 2;
+  constexpr int NG = (S / 16) / NPP;
+  static_assert((S / 16) % NPP == 0 && NG >= 1, "segment must split into whole k-groups");
+  constexpr int XSEG = CI_T / 8, DSEG = CO_T / 8;          // 16-byte slots per pixel
+  constexpr int XS8 = PW * XSEG, DS8 = S * DSEG;           // slots of an input row / a dy row
+  constexpr int NLX = (XS8 + NT - 1) / NT, NLD = (DS8 + NT - 1) / NT;
+  static_assert(NT % XSEG == 0 && NT % DSEG == 0, "a thread keeps its channel group");
+  constexpr int RSUB = 4 * PW * 32;                        // ring elements of a 32-channel sub-tile
+  constexpr int RING = TI * RSUB;
+  constexpr int DSUB = S * 32, DBUF = TJ * DSUB;
+  static_assert((size_t)(RING + 2 * DBUF) * 2 <= kWgradMergeLds4, "ring + dy stages fit the merge space");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
+  __bf16* Dst = smem_h + RING;
+  typedef int i32x4r __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sb = wave % NSB, pp = wave / NSB;
+  const int wi = sb / TJ, wj = sb - wi * TJ;
+
+  int bid = blockIdx.x;
+  const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+  const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+  const int sp = bid;
+  const int ci0 = ci_t * CI_T, co0 = co_t * CO_T;
+  const int g_begin = sp * p.segs_per_block;
+  const int strip = g_begin / p.Ho;
+  const int oy0 = g_begin - strip * p.Ho;
+  const int rows = p.segs_per_block;                       // (divides Ho: the strip is not left)
+  const int n = strip / p.segs_per_row;
+  const int x0 = (strip - n * p.segs_per_row) * S;
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+  // input-row slot k: pixel (tid + 256 k) / XSEG of the S + 2 under the strip, channels
+  // ci0 + 8 seg .. + 7; byte offset of the slot inside image row 0 and its LDS place in a ring row
+  const int xseg = tid % XSEG, dseg = tid % DSEG;
+  int x_off[NLX], x_lds[NLX];
+  unsigned x_okc = 0;                                      // bit k: the slot's column is inside the image
+#pragma unroll
+  for (int k = 0; k < NLX; ++k) {
+    const int slot = tid + NT * k;
+    const int pix = slot / XSEG;
+    const int ix = x0 - 1 + pix;
+    const bool ok = slot < XS8 && (unsigned)ix < (unsigned)p.W;
+    x_okc |= (ok ? 1u : 0u) << k;
+    x_off[k] = (ix * p.Cx + ci0 + xseg * 8) * 2;
+    x_lds[k] = (xseg >> 2) * RSUB + pix * 32 + (xseg & 3) * 8;
+  }
+  int d_off[NLD], d_lds[NLD];
+  unsigned d_okc = 0;
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int slot = tid + NT * k;
+    const int dpix = slot / DSEG;
+    const bool ok = slot < DS8 && x0 + dpix < p.Wo;
+    d_okc |= (ok ? 1u : 0u) << k;
+    d_off[k] = ((x0 + dpix) * p.Cout + co0 + dseg * 8) * 2;
+    d_lds[k] = (dseg >> 2) * DSUB + dpix * 32 + (dseg & 3) * 8;
+  }
+  f32x4 ca[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+  f32x4 cb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (ACT) {
+    const size_t o = (size_t)n * p.Cx + ci0 + xseg * 8;
+    ca[0] = *reinterpret_cast<const f32x4*>(p.alpha + o);
+    ca[1] = *reinterpret_cast<const f32x4*>(p.alpha + o + 4);
+    cb[0] = *reinterpret_cast<const f32x4*>(p.beta + o);
+    cb[1] = *reinterpret_cast<const f32x4*>(p.beta + o + 4);
+  }
+
+  i32x4r rx[DEPTH][NLX], rd[DEPTH][NLD];
+  unsigned rok[DEPTH];                                     // uniform: the set's input row is inside the image
+  // bundle t of the walk: input row oy0 + t + 1 (the new bottom row of step t) and dy row oy0 + t
+  auto load_x = [&](auto setc, int iy) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    const bool rowok = (unsigned)iy < (unsigned)p.H;
+    rok[SET] = rowok ? 1u : 0u;
+    const int rowbase = (n * p.H + iy) * p.W * p.Cx * 2;
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {
+      const bool ok = rowok && ((x_okc >> k) & 1u);
+      rx[SET][k] = __builtin_amdgcn_raw_buffer_load_b128(
+          rsx, ok ? (unsigned)(rowbase + x_off[k]) : 0x80000000u, 0, 0);
+    }
+  };
+  auto load_d = [&](auto setc, int oy) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    const bool rowok = oy < p.Ho;
+    const int rowbase = (n * p.Ho + oy) * p.Wo * p.Cout * 2;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const bool ok = rowok && ((d_okc >> k) & 1u);
+      rd[SET][k] = __builtin_amdgcn_raw_buffer_load_b128(
+          rsd, ok ? (unsigned)(rowbase + d_off[k]) : 0x80000000u, 0, 0);
+    }
+  };
+  auto store_x = [&](auto setc, int iy) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    __bf16* row = smem_h + (iy & 3) * (PW * 32);
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {
+      if (NT * (k + 1) <= XS8 || tid + NT * k < XS8) {
+        if (ACT) {
+          const bool ok = rok[SET] && ((x_okc >> k) & 1u);   // zero padding stays zero
+          const i32x4r q = rx[SET][k];
+          const f32x4 lo = act4(widen16(i32x2r{q[0], q[1]}), ca[0], cb[0], p.slope, ok);
+          const f32x4 hi = act4(widen16(i32x2r{q[2], q[3]}), ca[1], cb[1], p.slope, ok);
+          bf16x8 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = (__bf16)lo[e]; h[4 + e] = (__bf16)hi[e]; }
+          *reinterpret_cast<bf16x8*>(row + x_lds[k]) = h;
+        } else {
+          *reinterpret_cast<i32x4r*>(row + x_lds[k]) = rx[SET][k];
+        }
+      }
+    }
+  };
+  auto store_d = [&](auto setc, int buf) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    __bf16* base = Dst + buf * DBUF;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (NT * (k + 1) <= DS8 || tid + NT * k < DS8)
+        *reinterpret_cast<i32x4r*>(base + d_lds[k]) = rd[SET][k];
+  };
+
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+
+  using C0 = std::integral_constant<int, 0>;
+  // prologue: rows oy0 - 1 and oy0, then bundle 0; bundles 1 .. DEPTH-1 stay in flight
+  load_x(C0{}, oy0 - 1);
+  store_x(C0{}, oy0 - 1);
+  load_x(C0{}, oy0);
+  store_x(C0{}, oy0);
+  load_x(C0{}, oy0 + 1);
+  load_d(C0{}, oy0);
+  store_x(C0{}, oy0 + 1);
+  store_d(C0{}, 0);
+  for_range<1, DEPTH>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    load_x(jc, oy0 + j + 1);
+    load_d(jc, oy0 + j);
+  });
+  __syncthreads();
+
+  const int tg = lane >> 4, th = tg >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int tcol = 16 * (tg & 1) + 4 * tp;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  auto frag = [&](const __bf16* q) __attribute__((always_inline)) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  for (int t0 = 0; t0 < rows; t0 += DEPTH) {
+    for_range<0, DEPTH>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int JN = (j + 1) % DEPTH;
+      const int t = t0 + j;
+      const int oy = oy0 + t;
+      // set j is free (bundle t went to LDS at the end of step t - 1): bundle t + DEPTH
+      // (past the workgroup's range the loads are out of range on purpose: they return zeros
+      // that are stored into slots nothing reads - the waits stay countable)
+      const bool more = t + DEPTH < rows;
+      load_x(jc, more ? oy + DEPTH + 1 : -2);
+      load_d(jc, more ? oy + DEPTH : p.Ho);
+      const __bf16* P = smem_h + wi * RSUB;
+      const __bf16* D = Dst + (t & 1) * DBUF + wj * DSUB;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const int r0 = 16 * (pp + NPP * gq) + 8 * th + tq;
+        const bf16x8 b = frag(D + r0 * 32 + tcol);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const __bf16* pr = P + (((oy - 1 + u) & 3) * PW + r0) * 32 + tcol;
+#pragma unroll
+          for (int v = 0; v < 3; ++v)
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pr + v * 32), b, acc[u][v], 0, 0, 0);
+        }
+      }
+      // bundle t + 1 (set JN, loaded DEPTH - 1 steps ago): row oy + 2 into the slot no wave reads
+      store_x(std::integral_constant<int, JN>{}, oy + 2);
+      store_d(std::integral_constant<int, JN>{}, (t + 1) & 1);
+      __syncthreads();
+    });
+  }
+
+  wgrad_epilogue<NSB, NPP, TJ, NT>(reinterpret_cast<float*>(smem_h), p, sp, ci0, co0, sb, pp,
+                                   [&](auto tc) -> const f32x16& {
+    constexpr int t = decltype(tc)::value;
+    return acc[t / 3][t % 3];
+  });
+}
+
+// ---------------------------------------------------------------------------
 // Reduction of the per-workgroup slabs into the OIHW gradient.  Every weight-gradient kernel
 // leaves `nslab` partial gradients [tap][ci][co]; they are summed in a FIXED order (no float
 // atomics: run-to-run determinism) in up to three stages - chunks of 16 slabs while more than 16
@@ -1276,6 +1501,7 @@ int wgrad_tiles(int Cx, int Cout) {
 }
 
 // wide: the 8-wave kernel (fp32 tensors on the fp32 matrix cores)
+constexpr int kRingDepth = 4;   // steps whose operands are in flight in conv_wgrad_b16_ring_kernel
 WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec = 0,
                     bool wide = false) {
   WgradPlan pl{};
@@ -1328,6 +1554,14 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   pl.segs_per_block = ceil_div(pl.total_segs, split);
+  if (prec == 1 && stride == 1 && pl.nw == 4) {
+    // the row-ring kernel (bf16 tensors) walks down a column strip: a workgroup's range must
+    // lie inside one strip and be a whole number of prefetch rounds.  Harmless to the segment
+    // kernels, which enumerate the same g differently.
+    int r = pl.segs_per_block;
+    while (r < Ho && (Ho % r || r % kRingDepth)) ++r;
+    if (r <= Ho && Ho % r == 0 && r % kRingDepth == 0) pl.segs_per_block = r;
+  }
   pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
   // slabs + ping-pong room for the staged reduction (each stage shrinks 16x)
   const size_t E = (size_t)9 * Cx * Cout;
@@ -2170,6 +2404,29 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
   return UNET_OK;
 }
 
+// mixed-precision pipeline, stride 1, bf16 tensors: the row-ring form (plan: make_plan)
+bool wgrad_ring_ok(const WgradParams& p) {
+  return p.b16 && p.Ho == p.H && p.Wo == p.W && p.segs_per_block % kRingDepth == 0 &&
+         p.Ho % p.segs_per_block == 0 && p.total_segs % p.segs_per_block == 0 &&
+         p.Cx % 8 == 0 && p.Cout % 8 == 0;
+}
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_b16_ring(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = kWgradMergeLds4;
+  const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
+  if (p.alpha) {
+    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, true, kRingDepth>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, false, kRingDepth>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  }
+  UNET_CHECK_LAUNCH("conv_wgrad_b16_ring");
+  return UNET_OK;
+}
+
 // mixed-precision pipeline, stride 2: bf16 tensors, bf16 matrix cores
 template <int CI_T, int CO_T, int S>
 int launch_wgrad_b16_s2(const WgradParams& p, hipStream_t stream) {
@@ -2283,6 +2540,11 @@ WgradPlan make_plan_taps(long long Q, int Cx, int Cout, bool wide) {
   return pl;
 }
 
+// UNET_WGRAD_RING=0: the segment kernels instead of the row-ring form (A/B measurements)
+bool ring_off() {
+  static const bool off = [] { const char* e = getenv("UNET_WGRAD_RING"); return e && e[0] == '0'; }();
+  return off;
+}
 // kernel instantiation for a plan (tile, segment length, stride, operand mode)
 int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int prec,
                       hipStream_t stream) {
@@ -2306,6 +2568,12 @@ int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int
   if (p.b16 && prec == 1 && stride == 2 && (pl.S / 16) % pl.npp == 0) {
     if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_s2<64, 64, 16>(p, stream);
     if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_s2<32, 64, 32>(p, stream);
+  }
+  if (use_bf16 && prec == 1 && wgrad_ring_ok(p) && !ring_off()) {
+    if (pl.ci_t == 32 && pl.co_t == 32 && pl.S == 64) return launch_wgrad_b16_ring<32, 32, 64>(p, stream);
+    if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<32, 64, 32>(p, stream);
+    if (pl.ci_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<64, 64, 32>(p, stream);
+    if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_ring<64, 64, 16>(p, stream);
   }
   if (use_bf16 && prec == 1) {
     if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64>(p, stream);
