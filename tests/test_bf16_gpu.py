@@ -126,8 +126,14 @@ def test_rgb_stem_to_bf16(ua):
 
 @pytest.mark.parametrize("case", [(2, 12, 64, 32, 32, 1, 3), (1, 16, 32, 64, 64, 1, 3),
                                   (2, 16, 32, 64, 64, 2, 3), (2, 32, 128, 32, 64, 2, 3),
-                                  (3, 4, 4, 64, 128, 1, 3), (2, 2, 2, 512, 512, 1, 1)])
+                                  (3, 4, 4, 64, 128, 1, 3), (2, 2, 2, 512, 512, 1, 1),
+                                  # the row-ring kernel with several strips, several workgroups
+                                  # per strip and long walks: four waves (32 x 32 tile) and
+                                  # eight waves / two rows a step (64 x 64 tiles)
+                                  (2, 256, 192, 32, 32, 1, 3), (2, 128, 96, 64, 128, 1, 3)])
 def test_conv_in_bwd_weight_b16(ua, case):
+    """Stride 1, bf16 tensors: conv_wgrad_b16_ring_kernel (a workgroup walks down a column strip,
+    input rows in an LDS ring); stride 2: conv_wgrad_bf16_kernel<.., 2>; 1x1: the centre tap."""
     N, H, W, Cx, Cout, stride, ks = case
     x, coef = r16(rnd(N, Cx, H, W, seed=1)), coeffs(N, Cx, 30)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1

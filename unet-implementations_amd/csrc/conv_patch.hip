@@ -2232,7 +2232,8 @@ int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_
   // 8 x 32-pixel tiles of 64 columns where they still give two workgroups per CU: half the
   // weight-panel traffic (L2 -> LDS) per output of the 4 x 32 tiles; measured -2..-16 % per
   // launch on the 64..256-channel layers, -0.13 ms per step (profiles/r04_bf16_experiments.txt)
-  const bool th8 = nc % 64 == 0 && p.Hin % 8 == 0 && (M / 256) * (nc / 64) >= 512;
+  static const bool no_th8 = [] { const char* e = getenv("UNET_B16_TH8"); return e && e[0] == '0'; }();
+  const bool th8 = !no_th8 && nc % 64 == 0 && p.Hin % 8 == 0 && (M / 256) * (nc / 64) >= 512;
   if (!fused && bs_px && p.bs_partial) {   // data gradient with the BSTATS epilogue
     p.bs_tile0 = 0;
     if (th8) {

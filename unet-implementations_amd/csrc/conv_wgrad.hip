@@ -854,18 +854,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
 //     slot = row & 3): a step reads rows oy-1 .. oy+1 and fills the slot of row oy+2 - each row
 //     is loaded, activated and rounded ONCE (a third of the loads and of the activation VALU);
 //   * the operands of a step are one input row and one dy row, 16 bytes per lane and load:
-//     12 registers a step, so the loads of DEPTH = 4 steps are in flight (the old form held
-//     36 registers for one);
+//     12 registers a step, so the loads of DEPTH = 2 steps are in flight (the old form held
+//     36 registers for one step; DEPTH = 4 measured no better - with each row fetched once the
+//     kernel runs at ~75 % of what its HBM bytes, slabs included, allow);
 //   * the activation coefficients depend on (image, channel) only: read once per workgroup.
 // Blocking, MFMA fragments (ds_read_b64_tr_b16), slabs and the merge epilogue are those of
 // conv_wgrad_bf16_kernel.  g in [0, total_segs) enumerates (image, strip, output row) with the
 // row fastest; a workgroup's range lies inside one strip (the plan makes segs_per_block divide
 // Ho and a multiple of DEPTH).
 // ---------------------------------------------------------------------------
-template <int CI_T, int CO_T, int S, bool ACT, int DEPTH>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_b16_ring_kernel(const WgradParams p) {
+// RG = 2: eight waves, TWO output rows a step - waves 0-3 take the even row of the pair, waves
+// 4-7 the odd one (each half loads "its" input and dy row and runs the four-wave code on it; the
+// ring is shared: 8 slots); the two halves are merged with the pixel parts in the epilogue, so
+// a workgroup still leaves ONE slab: 256 slabs per layer instead of 512 - the slabs are a third
+// of the kernel's HBM traffic at 64 x 64 tiles and all of the reduction kernel's.
+template <int CI_T, int CO_T, int S, bool ACT, int DEPTH, int RG>
+__global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
-  constexpr int NSB = TI * TJ, NPP = 4 / NSB, NT = 256;
+  constexpr int NSB = TI * TJ, NPP = 4 / NSB, NT = 256;   // (NT: one row group)
   constexpr int PW = S + 2;
   constexpr int NG = (S / 16) / NPP;
   static_assert((S / 16) % NPP == 0 && NG >= 1, "segment must split into whole k-groups");
@@ -873,15 +879,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b16_ring_kernel(const Wgrad
   constexpr int XS8 = PW * XSEG, DS8 = S * DSEG;           // slots of an input row / a dy row
   constexpr int NLX = (XS8 + NT - 1) / NT, NLD = (DS8 + NT - 1) / NT;
   static_assert(NT % XSEG == 0 && NT % DSEG == 0, "a thread keeps its channel group");
-  constexpr int RSUB = 4 * PW * 32;                        // ring elements of a 32-channel sub-tile
+  constexpr int RR = 4 * RG;                               // ring slots (rows)
+  constexpr int RSUB = RR * PW * 32;                       // ring elements of a 32-channel sub-tile
   constexpr int RING = TI * RSUB;
   constexpr int DSUB = S * 32, DBUF = TJ * DSUB;
-  static_assert((size_t)(RING + 2 * DBUF) * 2 <= kWgradMergeLds4, "ring + dy stages fit the merge space");
+  static_assert((size_t)(RING + 2 * RG * DBUF) * 2 <= (RG == 2 ? kWgradMergeLds8 : kWgradMergeLds4),
+                "ring + dy stages fit the merge space");
   extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
   __bf16* Dst = smem_h + RING;
   typedef int i32x4r __attribute__((ext_vector_type(4)));
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = threadIdx.x >> 8;                         // row group (0 when RG == 1)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int sb = wave % NSB, pp = wave / NSB;
   const int wi = sb / TJ, wj = sb - wi * TJ;
 
@@ -966,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b16_ring_kernel(const Wgrad
   };
   auto store_x = [&](auto setc, int iy) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
-    __bf16* row = smem_h + (iy & 3) * (PW * 32);
+    __bf16* row = smem_h + (iy & (RR - 1)) * (PW * 32);
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {
       if (NT * (k + 1) <= XS8 || tid + NT * k < XS8) {
@@ -1003,19 +1012,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b16_ring_kernel(const Wgrad
       for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
 
   using C0 = std::integral_constant<int, 0>;
-  // prologue: rows oy0 - 1 and oy0, then bundle 0; bundles 1 .. DEPTH-1 stay in flight
-  load_x(C0{}, oy0 - 1);
-  store_x(C0{}, oy0 - 1);
-  load_x(C0{}, oy0);
-  store_x(C0{}, oy0);
-  load_x(C0{}, oy0 + 1);
-  load_d(C0{}, oy0);
-  store_x(C0{}, oy0 + 1);
-  store_d(C0{}, 0);
+  // bundle t of a row group: input row oy0 + RG t + 1 + lg (the new bottom rows of step t) and
+  // dy row oy0 + RG t + lg.  prologue: rows oy0 - 1 and oy0, then bundle 0; bundles 1 .. DEPTH-1
+  // stay in flight
+  for (int r = lg; r < 2; r += RG) {     // uniform per row group
+    load_x(C0{}, oy0 - 1 + r);
+    store_x(C0{}, oy0 - 1 + r);
+  }
+  load_x(C0{}, oy0 + 1 + lg);
+  load_d(C0{}, oy0 + lg);
+  store_x(C0{}, oy0 + 1 + lg);
+  store_d(C0{}, lg);
   for_range<1, DEPTH>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    load_x(jc, oy0 + j + 1);
-    load_d(jc, oy0 + j);
+    load_x(jc, oy0 + RG * j + 1 + lg);
+    load_d(jc, oy0 + RG * j + lg);
   });
   __syncthreads();
 
@@ -1027,40 +1038,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_b16_ring_kernel(const Wgrad
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  for (int t0 = 0; t0 < rows; t0 += DEPTH) {
+  const int steps = rows / RG;
+  for (int t0 = 0; t0 < steps; t0 += DEPTH) {
     for_range<0, DEPTH>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       constexpr int JN = (j + 1) % DEPTH;
       const int t = t0 + j;
-      const int oy = oy0 + t;
+      const int oy = oy0 + RG * t + lg;                    // this row group's output row
       // set j is free (bundle t went to LDS at the end of step t - 1): bundle t + DEPTH
       // (past the workgroup's range the loads are out of range on purpose: they return zeros
       // that are stored into slots nothing reads - the waits stay countable)
-      const bool more = t + DEPTH < rows;
-      load_x(jc, more ? oy + DEPTH + 1 : -2);
-      load_d(jc, more ? oy + DEPTH : p.Ho);
+      const bool more = t + DEPTH < steps;
+      load_x(jc, more ? oy + RG * DEPTH + 1 : -2);
+      load_d(jc, more ? oy + RG * DEPTH : p.Ho);
       const __bf16* P = smem_h + wi * RSUB;
-      const __bf16* D = Dst + (t & 1) * DBUF + wj * DSUB;
+      const __bf16* D = Dst + ((t & 1) * RG + lg) * DBUF + wj * DSUB;
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
         const int r0 = 16 * (pp + NPP * gq) + 8 * th + tq;
         const bf16x8 b = frag(D + r0 * 32 + tcol);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-          const __bf16* pr = P + (((oy - 1 + u) & 3) * PW + r0) * 32 + tcol;
+          const __bf16* pr = P + (((oy - 1 + u) & (RR - 1)) * PW + r0) * 32 + tcol;
 #pragma unroll
           for (int v = 0; v < 3; ++v)
             acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pr + v * 32), b, acc[u][v], 0, 0, 0);
         }
       }
-      // bundle t + 1 (set JN, loaded DEPTH - 1 steps ago): row oy + 2 into the slot no wave reads
-      store_x(std::integral_constant<int, JN>{}, oy + 2);
-      store_d(std::integral_constant<int, JN>{}, (t + 1) & 1);
+      // bundle t + 1 (set JN, loaded DEPTH - 1 steps ago): rows into the slots no wave reads
+      store_x(std::integral_constant<int, JN>{}, oy + RG + 1);
+      store_d(std::integral_constant<int, JN>{}, ((t + 1) & 1) * RG + lg);
       __syncthreads();
     });
   }
 
-  wgrad_epilogue<NSB, NPP, TJ, NT>(reinterpret_cast<float*>(smem_h), p, sp, ci0, co0, sb, pp,
+  wgrad_epilogue<NSB, NPP * RG, TJ, NT * RG>(reinterpret_cast<float*>(smem_h), p, sp, ci0, co0, sb,
+                                             lg * NPP + pp,
                                    [&](auto tc) -> const f32x16& {
     constexpr int t = decltype(tc)::value;
     return acc[t / 3][t % 3];
@@ -1485,6 +1498,7 @@ struct WgradPlan {
   int sps;   // slabs per pixel split: 1 (the parts of a sub-block are merged in LDS)
   int nw;    // waves per workgroup: 4, or 8 (fp32 tensors, one workgroup per CU, LDS merge)
   int ci_t, co_t, S, split, segs_per_row, total_segs, segs_per_block;
+  int rg;    // conv_wgrad_b16_ring_kernel: row groups of a workgroup (2 = eight waves), 0 = not planned for it
   size_t ws_floats;
   bool stem;
   int stem_blocks, stem_spb;
@@ -1501,9 +1515,10 @@ int wgrad_tiles(int Cx, int Cout) {
 }
 
 // wide: the 8-wave kernel (fp32 tensors on the fp32 matrix cores)
-constexpr int kRingDepth = 4;   // steps whose operands are in flight in conv_wgrad_b16_ring_kernel
+// (2: measured against 4 per layer - equal or 5-8 % faster, and 24 registers fewer)
+constexpr int kRingDepth = 2;   // steps whose operands are in flight in conv_wgrad_b16_ring_kernel
 WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec = 0,
-                    bool wide = false) {
+                    bool wide = false, bool ring8 = false) {
   WgradPlan pl{};
   pl.nw = 4;
   if (Cx == 3) {
@@ -1557,10 +1572,21 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   if (prec == 1 && stride == 1 && pl.nw == 4) {
     // the row-ring kernel (bf16 tensors) walks down a column strip: a workgroup's range must
     // lie inside one strip and be a whole number of prefetch rounds.  Harmless to the segment
-    // kernels, which enumerate the same g differently.
-    int r = pl.segs_per_block;
-    while (r < Ho && (Ho % r || r % kRingDepth)) ++r;
-    if (r <= Ho && Ho % r == 0 && r % kRingDepth == 0) pl.segs_per_block = r;
+    // kernels, which enumerate the same g differently.  ring8: its eight-wave form - one
+    // workgroup per CU, two rows a step, half the slabs - where the rows allow it.
+    auto rows_for = [&](int target_blocks, int rg) {
+      int sp = ceil_div(target_blocks, tiles);
+      if (sp > max_split) sp = max_split;
+      if (sp < 1) sp = 1;
+      int r = ceil_div(pl.total_segs, sp);
+      const int q = kRingDepth * rg;
+      while (r < Ho && (Ho % r || r % q)) ++r;
+      return (r <= Ho && Ho % r == 0 && r % q == 0) ? r : 0;
+    };
+    const int r2 = ring8 ? rows_for(256, 2) : 0;
+    const int r1 = rows_for(512, 1);
+    if (r2) { pl.segs_per_block = r2; pl.rg = 2; }
+    else if (r1) { pl.segs_per_block = r1; pl.rg = 1; }
   }
   pl.split = ceil_div(pl.total_segs, pl.segs_per_block);
   // slabs + ping-pong room for the staged reduction (each stage shrinks 16x)
@@ -2405,26 +2431,31 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
 }
 
 // mixed-precision pipeline, stride 1, bf16 tensors: the row-ring form (plan: make_plan)
-bool wgrad_ring_ok(const WgradParams& p) {
-  return p.b16 && p.Ho == p.H && p.Wo == p.W && p.segs_per_block % kRingDepth == 0 &&
-         p.Ho % p.segs_per_block == 0 && p.total_segs % p.segs_per_block == 0 &&
-         p.Cx % 8 == 0 && p.Cout % 8 == 0;
+bool wgrad_ring_ok(const WgradParams& p, int rg) {
+  return rg >= 1 && p.b16 && p.Ho == p.H && p.Wo == p.W &&
+         p.segs_per_block % (kRingDepth * rg) == 0 && p.Ho % p.segs_per_block == 0 &&
+         p.total_segs % p.segs_per_block == 0 && p.Cx % 8 == 0 && p.Cout % 8 == 0;
 }
-template <int CI_T, int CO_T, int S>
-int launch_wgrad_b16_ring(const WgradParams& p, hipStream_t stream) {
-  constexpr size_t lds = kWgradMergeLds4;
+template <int CI_T, int CO_T, int S, int RG>
+int launch_wgrad_b16_ring_t(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = RG == 2 ? kWgradMergeLds8 : kWgradMergeLds4;
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   if (p.alpha) {
-    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, true, kRingDepth>;
+    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, true, kRingDepth, RG>;
     UNET_SET_DYN_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, stream, p);
   } else {
-    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, false, kRingDepth>;
+    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, false, kRingDepth, RG>;
     UNET_SET_DYN_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, stream, p);
   }
   UNET_CHECK_LAUNCH("conv_wgrad_b16_ring");
   return UNET_OK;
+}
+template <int CI_T, int CO_T, int S>
+int launch_wgrad_b16_ring(const WgradParams& p, int rg, hipStream_t stream) {
+  return rg == 2 ? launch_wgrad_b16_ring_t<CI_T, CO_T, S, 2>(p, stream)
+                 : launch_wgrad_b16_ring_t<CI_T, CO_T, S, 1>(p, stream);
 }
 
 // mixed-precision pipeline, stride 2: bf16 tensors, bf16 matrix cores
@@ -2569,11 +2600,11 @@ int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int
     if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_s2<64, 64, 16>(p, stream);
     if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_s2<32, 64, 32>(p, stream);
   }
-  if (use_bf16 && prec == 1 && wgrad_ring_ok(p) && !ring_off()) {
-    if (pl.ci_t == 32 && pl.co_t == 32 && pl.S == 64) return launch_wgrad_b16_ring<32, 32, 64>(p, stream);
-    if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<32, 64, 32>(p, stream);
-    if (pl.ci_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<64, 64, 32>(p, stream);
-    if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_ring<64, 64, 16>(p, stream);
+  if (use_bf16 && prec == 1 && wgrad_ring_ok(p, pl.rg) && !ring_off()) {
+    if (pl.ci_t == 32 && pl.co_t == 32 && pl.S == 64) return launch_wgrad_b16_ring<32, 32, 64>(p, pl.rg, stream);
+    if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<32, 64, 32>(p, pl.rg, stream);
+    if (pl.ci_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<64, 64, 32>(p, pl.rg, stream);
+    if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_ring<64, 64, 16>(p, pl.rg, stream);
   }
   if (use_bf16 && prec == 1) {
     if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64>(p, stream);
@@ -2710,9 +2741,14 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   // ... and the 32 -> 32 channel layers their own (one workgroup per CU keeps the whole M)
   const bool wino32 = prec == 0 && !b16 && !center_only && wgrad_wino32_ok(N, H, W, Cx, Cout, stride) &&
                       wgrad_batch_chunk(N, H, W, Cx, Cout, stride) >= N;
+  // bf16 tensors, stride 1: the eight-wave row-ring kernel where the plan finds rows for it
+  static const bool ring8_off = [] { const char* e = getenv("UNET_WGRAD_RING8"); return e && e[0] == '0'; }();
+  // (64 x 64 channel tiles only: measured per layer - 32 x 32 tiles, enc0 / dec4 at 512 x 512,
+  // lose 20 % in the eight-wave form, the 64- and 128-channel layers gain 15 %, deeper ones +-0)
+  const bool ring8 = b16 && pprec == 1 && !ring8_off && Cx % 64 == 0 && Cout % 64 == 0;
   const WgradPlan pl = wino32 ? make_plan_wino32(N, H, W)
                        : wino ? make_plan_wino(N, H, W, Cx, Cout)
-                              : make_plan(N, H, W, Cx, Cout, stride, pprec, wide);
+                              : make_plan(N, H, W, Cx, Cout, stride, pprec, wide, ring8);
   const size_t need = ((wino || wino32) ? pl.ws_floats
                             : wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec, wide)) * sizeof(float);
   if (workspace_bytes < need || need == 0) {
@@ -2764,7 +2800,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int nslab = 0;
     for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
       const int nc = N - nb < nmax ? N - nb : nmax;
-      const WgradPlan pc = (wino || wino32) ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide);
+      const WgradPlan pc = (wino || wino32) ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide, ring8);
       WgradParams p{};
       p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
                                            (size_t)nb * H * W * Cx * es);
