@@ -210,7 +210,10 @@ def test_instnorm_bwd_upsample_head_b16(ua):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 16, 64, 64), (1, 16, 16, 32, 64), (3, 2, 2, 64, 64),
-                                  (2, 32, 32, 128, 64), (1, 24, 40, 64, 128)])
+                                  (2, 32, 32, 128, 64), (1, 24, 40, 64, 128),
+                                  # 32 x 32 channel tiles (the last decoder stage: 64 -> 32):
+                                  # conv_wgrad_taps_b16_kernel<32, 32, 64>, ragged last segment
+                                  (2, 24, 20, 64, 32), (1, 64, 64, 32, 32)])
 def test_up_backward_b16(ua, case):
     N, h, w, Cx, Cout = case
     x, coef = r16(rnd(N, Cx, h, w, seed=1)), coeffs(N, Cx, 60)

@@ -483,13 +483,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wgrad_taps_kernel(const Wgrad
 // rows) and read with the transposing LDS read, as in conv_wgrad_bf16_kernel below: per
 // 16-pixel k-group one A fragment and nine D fragments.  D is copied raw (16 bytes = 8 channels
 // per slot: no bf16 -> fp32 -> bf16 round trip); x is activated in fp32 and rounded.
-// 64 x 64 tiles: wave w owns sub-block w for all nine taps (one pixel part).
+// 64 x 64 tiles: wave w owns sub-block w for all nine taps (one pixel part); 32 x 32 tiles
+// (round 4: the 32-column layer of the last decoder stage, 266 us on the fp32 matrix cores):
+// four pixel parts of a 64-pixel segment, merged in the epilogue.
 // ---------------------------------------------------------------------------
 template <int CI_T, int CO_T, int S, bool ACT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
   constexpr int NSB = TI * TJ, NPP = 4 / NSB;
-  static_assert(NSB == 2 || NSB == 4, "tile must have 2 or 4 sub-blocks");
+  static_assert(NSB == 1 || NSB == 2 || NSB == 4, "tile must have 1, 2 or 4 sub-blocks");
   constexpr int NT = 256;
   constexpr int SUB = S * 32;                  // elements of one 32-channel sub-tile
   constexpr int ATILE = TI * SUB, DTILE = 9 * TJ * SUB, STAGE = ATILE + DTILE;
@@ -2546,7 +2548,7 @@ int launch_wgrad_taps(const WgradParams& p, hipStream_t stream) {
 
 // plan of the low-resolution tap GEMM: Q pixels, (Cx x Cout) channel tiles
 // wide: the 8-wave kernel (fp32 tensors)
-WgradPlan make_plan_taps(long long Q, int Cx, int Cout, bool wide) {
+WgradPlan make_plan_taps(long long Q, int Cx, int Cout, bool wide, bool b16 = false) {
   WgradPlan pl{};
   pl.ci_t = (Cx % 64 == 0) ? 64 : 32;
   pl.co_t = (Cout % 64 == 0) ? 64 : 32;
@@ -2556,6 +2558,7 @@ WgradPlan make_plan_taps(long long Q, int Cx, int Cout, bool wide) {
   pl.npp = pl.nw / nsb;
   pl.sps = 1;
   pl.S = (nsb == 1 ? 32 : 16) * (wide ? 2 : 1);
+  if (b16 && nsb == 1) pl.S = 64;   // conv_wgrad_taps_b16_kernel: four k-groups, one per wave
   pl.segs_per_row = 0;
   pl.total_segs = (int)ceil_div64(Q, pl.S);
   const int tiles = (Cx / pl.ci_t) * (Cout / pl.co_t);
@@ -3036,7 +3039,7 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
   for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
     const int nc = N - nb < nmax ? N - nb : nmax;
     const long long Q = (long long)nc * h * w;
-    const WgradPlan pl = make_plan_taps(Q, Cx, Cout, wide);
+    const WgradPlan pl = make_plan_taps(Q, Cx, Cout, wide, b16);
     WgradParams p{};
     p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x->x) +
                                          (size_t)nb * h * w * Cx * es);
@@ -3060,6 +3063,7 @@ static int up_bwd_weight_impl(const unet_act_src* x, float slope, const float* D
       else rc = launch_wgrad_taps8<32, 32, 64>(p, stream);
     } else {
       if (pl.ci_t == 64 && b16) rc = launch_wgrad_taps_b16<64, 64, 16>(p, stream);
+      else if (pl.ci_t == 32 && pl.co_t == 32 && b16) rc = launch_wgrad_taps_b16<32, 32, 64>(p, stream);
       else if (pl.ci_t == 64) rc = launch_wgrad_taps<64, 64, 16>(p, stream);
       else if (pl.co_t == 64) rc = launch_wgrad_taps<32, 64, 16>(p, stream);
       else rc = launch_wgrad_taps<32, 32, 32>(p, stream);
