@@ -568,6 +568,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 // order and rounded to bf16 ONCE - the value the materialised form (upsample2x_fwd_b16x8_kernel
 // + this kernel on its output) stages, so the two are bit-identical and the up-sampled tensor
 // (268 MB at 512 x 512) is neither written nor read.  As conv_patch_up_kernel (fp32).
+#ifdef B16_STAMPS
+__device__ unsigned long long g_stamps[256 * 16];   // (timing experiments only: tools/stamps_b16.py)
+#endif
 template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false,
           bool WB = false, bool UP = false>
 // (32-accumulator tiles without the up-sampling loader - and, when fused, with the pre-rounded
@@ -576,6 +579,14 @@ template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, 
 __global__ __launch_bounds__(256, ((WM / 32) * (WN / 32) <= 2 && !UP && (WB || !ACT)) ? 3 : 2)
 void conv_patch_b16_kernel(const IgemmParams p) {
   static_assert(!UP || (ACT && STATS && !BSTATS), "UP is a fused-forward loader");
+#ifdef B16_STAMPS
+  int stamp_i = 0;
+#define STAMP() do { if (threadIdx.x == 0 && blockIdx.x >= B16_STAMPS && blockIdx.x < B16_STAMPS + 256 && stamp_i < 16) \
+      g_stamps[(blockIdx.x - B16_STAMPS) * 16 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+  STAMP();
   constexpr int BK = 32, LDA = BK + 8;       // bf16 elements per LDS row
   constexpr int TW = 32, PW = TW + 2;
   constexpr int PPIX = (TH + 2) * PW;
@@ -638,7 +649,8 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     pp_lin[i] = ok ? (n * H + iy) * W + ix : (int)0x80000000;
   }
-  const int pp_lds0 = (tid >> 3) * LDA + (tid & 7) * 4;
+  auto pp_lds0_of = [&](int t) __attribute__((always_inline)) { return (t >> 3) * LDA + (t & 7) * 4; };
+  int pp_lds0 = pp_lds0_of(tid);   // (store_patch derives it again from an opaque thread index)
   auto pp_lds = [&](int i) __attribute__((always_inline)) {
     return (i == LAST && !last_ok) ? pp_lds0 : pp_lds0 + i * 32 * LDA;
   };
@@ -672,23 +684,31 @@ void conv_patch_b16_kernel(const IgemmParams p) {
                   ((y0 - 1 + prow == 0) ? 8 : 0) | ((x0 - 1 + pcol == 0) ? 4 : 0);
     }
   }
-  // weight slot j: (tap in row, column row, segment)
-  unsigned wslot_off[B_PASSES];
-  int wslot_lds[B_PASSES], wslot_tap[B_PASSES];
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) {
-    const int slot = (tid + 256 * j) % B_SLOTS;
-    const int tr = slot / (BN * B_SEGS), rem = slot - tr * BN * B_SEGS;
-    const int row = rem / B_SEGS, seg = rem % B_SEGS;
-    wslot_tap[j] = tr;
-    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * (32 / B_SEGS)) * (WB ? 2u : 4u);
-    wslot_lds[j] = (tr * BN + row) * LDA + seg * (32 / B_SEGS);
-  }
+  // weight slot of pass j = tid + 256 j: (tap in row, column row, segment).  BN * B_SEGS (slots
+  // of one tap) and 256 are powers of two, so the slot of pass j is the slot of pass 0 moved by
+  // compile-time amounts - three registers instead of three per pass (slots past the panel, in
+  // the last pass, load tap 2 again and are not stored):
+  constexpr int PER = BN * B_SEGS;
+  static_assert((PER & (PER - 1)) == 0 && (PER >= 256 || 256 % PER == 0), "power-of-two tap panels");
+  // (derived again from an opaque copy of the thread index where they are used: registers that
+  // would otherwise be held across the MFMAs)
+  auto tid_again = [&]() __attribute__((always_inline)) { int t = tid; asm volatile("" : "+v"(t)); return t; };
+  auto ws_tap0_of = [&](int t) __attribute__((always_inline)) { return PER >= 256 ? 0 : t / PER; };   // tap of pass j: + (256 j) / PER
+  auto wslot_off0_of = [&](int t) __attribute__((always_inline)) {
+    const int rem0 = t % PER;
+    return (unsigned)((p.n_off + n0 + rem0 / B_SEGS) * Ktot + (rem0 % B_SEGS) * (32 / B_SEGS)) * (WB ? 2u : 4u);
+  };
+  auto wslot_lds0_of = [&](int t) __attribute__((always_inline)) {
+    const int rem0 = t % PER;
+    return (ws_tap0_of(t) * BN + rem0 / B_SEGS) * LDA + (rem0 % B_SEGS) * (32 / B_SEGS);
+  };
+  auto ws_tapj = [](int j) { return (256 * j) / PER; };           // pass j: tap + this, column row + ws_rowj
+  auto ws_rowj = [](int j) { return ((256 * j) % PER) / B_SEGS; };
 
   // WB: two register sets - the panel of step s + 2 is loaded while that of s + 1 waits for its
   // LDS stage (a full step of flight; with one set the loads of s + 1 were stored at the end of
   // the step that issued them)
-  constexpr int B_SETS = (WB && !(BN == 32 && ACT)) ? 2 : 1;   // (32 fused columns: one set - registers for the third workgroup)
+  constexpr int B_SETS = WB ? 2 : 1;
   i32x2r pr[P_PASSES];      // the patch slots in flight, raw (8 bytes = 4 bf16: two registers)
   f32x4 rb[B_SETS][B_PASSES];
   f32x16 acc[TM][TN];
@@ -711,7 +731,12 @@ void conv_patch_b16_kernel(const IgemmParams p) {
   // (opaque: the pixel index times the channel count of BOTH sources would otherwise be kept per
   // pass across the K loop - 2 x P_PASSES registers that decide two or three workgroups per CU)
   auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
-  auto load_patch = [&](int chunk) __attribute__((always_inline)) {
+  // `dead`: the loads of a chunk that does not exist (issued all the same, out of range = no memory
+  // access, so that every path through a K step issues the SAME NUMBER of loads: hipcc then counts
+  // vmcnt exactly; with a conditional load anywhere in the loop it falls back to vmcnt(0) at every
+  // LDS store of a weight panel, which exposed a full load latency per step - round 4 finding)
+  auto load_patch = [&](int chunk, bool dead = false) __attribute__((always_inline)) {
+    const unsigned kill = dead ? 0x80000000u : 0u;
     const int c = chunk * BK;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
@@ -722,26 +747,29 @@ void conv_patch_b16_kernel(const IgemmParams p) {
       if (first) {   // uniform: the low-resolution pixels under the patch (clamped, all valid)
 #pragma unroll
         for (int j = 0; j < L_PASSES; ++j)
-          pr[j] = buf_ld4_raw16(rs0, (unsigned)(lp_lin[j] * Cs + cc), 0u);
+          pr[j] = buf_ld4_raw16(rs0, (unsigned)(lp_lin[j] * Cs + cc), kill);
+#pragma unroll
+        for (int j = L_PASSES; j < P_PASSES; ++j)   // (as many loads as the other branch: see `dead`)
+          pr[j] = buf_ld4_raw16(rs0, 0u, 0x80000000u);
       } else {
 #pragma unroll
         for (int i = 0; i < P_PASSES; ++i)
-          pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i));
+          pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i) | kill);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < P_PASSES; ++i)
-        pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i));
+        pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i) | kill);
     }
     if (ACT) {
       const float* al = first ? p.act0_alpha : p.act1_alpha;
       const float* be = first ? p.act0_beta : p.act1_beta;
-      if (al) {   // uniform
-        const size_t o = (size_t)n * Cs + cc;
-        ca = *reinterpret_cast<const f32x4*>(al + o);
-        cb = *reinterpret_cast<const f32x4*>(be + o);
-        cs = p.slope;
-      } else {    // plain source: z = v, slope 1 = identity
+      // (always two loads - a plain source reads the head of the weights instead - see `dead`)
+      const size_t o = (size_t)n * Cs + cc;
+      ca = *reinterpret_cast<const f32x4*>(al ? al + o : p.w);
+      cb = *reinterpret_cast<const f32x4*>(al ? be + o : p.w);
+      cs = p.slope;
+      if (!al) {  // uniform; plain source: z = v, slope 1 = identity
         ca = f32x4{1.f, 1.f, 1.f, 1.f};
         cb = f32x4{0.f, 0.f, 0.f, 0.f};
         cs = 1.f;
@@ -794,13 +822,18 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     }
   };
   auto store_patch = [&]() __attribute__((always_inline)) {
+    { int t = tid; asm volatile("" : "+v"(t)); pp_lds0 = pp_lds0_of(t); }
     if constexpr (UP) {
       if (up_chunk) { blend_patch(); return; }   // uniform
     }
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i) {
       if (ACT) {
-        const f32x4 v = act4(widen16(pr[i]), ca, cb, cs, pp_oob(i) == 0u);
+        // (opaque: the padding factor of every slot is loop-invariant and would be hoisted into
+        // P_PASSES registers - pairs, for the packed multiplies - held across the whole K loop)
+        unsigned oob = pp_oob(i);
+        asm volatile("" : "+v"(oob));
+        const f32x4 v = act4(widen16(pr[i]), ca, cb, cs, oob == 0u);
         *reinterpret_cast<bf16x4*>(Ps + pp_lds(i)) = to_bf16(v);
         asm volatile("" ::: "memory");   // one slot's temporaries at a time
       } else {   // a plain bf16 operand goes to LDS as it came (bf16 -> fp32 -> bf16 is the identity)
@@ -814,22 +847,28 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     tap_of(3 * row, oy, ox, wt0);
     tap_of(3 * row + 1, oy, ox, wt1);
     tap_of(3 * row + 2, oy, ox, wt2);
+    const int t_ = tid_again();
+    const int ws_tap0 = ws_tap0_of(t_);
+    const unsigned wslot_off0 = wslot_off0_of(t_);
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-      const int wt = wslot_tap[j] == 0 ? wt0 : (wslot_tap[j] == 1 ? wt1 : wt2);
-      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * (WB ? 2u : 4u);
+      const int tap = ws_tap0 + ws_tapj(j);
+      const int wt = tap == 0 ? wt0 : (tap == 1 ? wt1 : wt2);
+      const unsigned woff = (unsigned)(wt * p.tap_stride + ws_rowj(j) * Ktot + chunk * BK) * (WB ? 2u : 4u);
       rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 rsw, wslot_off[j] + woff, 0, 0));
+                                                 rsw, wslot_off0 + woff, 0, 0));
     }
   };
   auto store_b = [&](int buf, auto setc) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
     __bf16* Bb = Bs + buf * B_TILE;
+    const int wslot_lds0 = wslot_lds0_of(tid_again());
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j)
       if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS) {
-        if constexpr (WB) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[SET][j];   // 8 bf16
-        else *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[SET][j]);
+        const int lds = wslot_lds0 + (ws_tapj(j) * BN + ws_rowj(j)) * LDA;
+        if constexpr (WB) *reinterpret_cast<f32x4*>(Bb + lds) = rb[SET][j];   // 8 bf16
+        else *reinterpret_cast<bf16x4*>(Bb + lds) = to_bf16(rb[SET][j]);
       }
   };
 
@@ -844,36 +883,36 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     store_low();
     __syncthreads();
   }
+  STAMP();          // loads issued
   store_patch();
   store_b(0, S0{});
   __syncthreads();
+  STAMP();          // first stage in LDS
 
   // lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of its row
   const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
-  int row = 0, chunk = 0;
-  // one K step on LDS stage `buf` (SET: the register set that receives this step's load)
-  auto k_step = [&](int s, auto setc) __attribute__((always_inline)) {
-    constexpr int SET = decltype(setc)::value;
-    using OTHER = std::integral_constant<int, (B_SETS - 1) - SET>;
-    const int buf = s & 1;
-    const int row1 = (row == 2) ? 0 : row + 1;
-    const int chunk1 = (row == 2) ? chunk + 1 : chunk;
-    if constexpr (B_SETS == 2) {          // the panel of step s + 2 (the tail re-loads the last one)
-      const int row2 = (row1 == 2) ? 0 : row1 + 1;
-      const int chunk2 = (row1 == 2) ? chunk1 + 1 : chunk1;
-      const bool more2 = s + 2 < steps;
-      load_b(more2 ? row2 : row, more2 ? chunk2 : chunk, setc);
-    } else {
-      const bool more = s + 1 < steps;
-      load_b(more ? row1 : row, more ? chunk1 : chunk, setc);
+  // One K step (three taps of kernel row ROW) with EVERYTHING that issues a load fixed at compile
+  // time: the row, the register set that receives this step's panel load (PH; the other set holds
+  // the panel of the next step), an unconditional patch load at row 0 (`dead` in the last chunk).
+  // Two sets alternate with period two and the rows with period three, so the loop body is two
+  // chunks (six steps), with a three-step tail for an odd chunk count.
+  auto step = [&](auto rowc, auto phc, int chunk) __attribute__((always_inline)) {
+    constexpr int ROW = decltype(rowc)::value, PH = decltype(phc)::value;
+    using LOADSET = std::integral_constant<int, B_SETS == 2 ? PH : 0>;
+    using STORESET = std::integral_constant<int, B_SETS == 2 ? 1 - PH : 0>;
+    constexpr int DIST = B_SETS == 2 ? 2 : 1;          // panel of step s + DIST
+    const int buf = (chunk + ROW) & 1;                 // s = 3 chunk + ROW
+    {
+      constexpr int rown = (ROW + DIST) % 3;
+      const int chunkn = chunk + (ROW + DIST) / 3;
+      load_b(rown, chunkn < chunks ? chunkn : chunks - 1, LOADSET{});   // (past the end: any panel)
     }
-    if (row == 0 && chunk + 1 < chunks) load_patch(chunk + 1);   // (uniform; the last chunk stages nothing)
-
+    if constexpr (ROW == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk, chunk + 1 >= chunks);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int oy, ox, wt;
-      tap_of(3 * row + j, oy, ox, wt);
+      tap_of(3 * ROW + j, oy, ox, wt);
       const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
       const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
 #pragma unroll
@@ -892,68 +931,31 @@ void conv_patch_b16_kernel(const IgemmParams p) {
             acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[m][nb], 0, 0, 0);
       }
     }
-    if constexpr (B_SETS == 2) store_b(buf ^ 1, OTHER{});   // step s + 1's panel, loaded a step ago
-    else store_b(buf ^ 1, setc);
-    if constexpr (UP) {        // the next chunk's low-resolution pixels: a barrier ahead of the blend
-      if (row == 1 && up_chunk && chunk + 1 < chunks) store_low();   // uniform
+    store_b(buf ^ 1, STORESET{});
+    if constexpr (UP && ROW == 1) {   // the next chunk's low-resolution pixels: a barrier ahead of the blend
+      if (up_chunk && chunk + 1 < chunks) store_low();   // uniform
     }
-    if (row == 2 && chunk + 1 < chunks) {   // every wave is done with this chunk's patch
-      __syncthreads();
-      store_patch();
-    }
-    __syncthreads();
-    row = row1;
-    chunk = chunk1;
-  };
-  if constexpr (B_SETS == 2) {
-    for (int s = 0; s < steps; s += 2) {
-      k_step(s, S0{});
-      if (s + 1 < steps) k_step(s + 1, S1{});
-    }
-  } else {
-    // (the one-set form spelled out as before: through k_step the 128-column fused
-    // instantiation needed one register too many)
-    for (int s = 0; s < steps; ++s) {
-      const int buf = s & 1;
-      const int row1 = (row == 2) ? 0 : row + 1;
-      const int chunk1 = (row == 2) ? chunk + 1 : chunk;
-      const bool more = s + 1 < steps;
-      load_b(more ? row1 : row, more ? chunk1 : chunk, S0{});
-      if (row == 0 && chunk + 1 < chunks) load_patch(chunk + 1);   // (uniform; the last chunk stages nothing)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        int oy, ox, wt;
-        tap_of(3 * row + j, oy, ox, wt);
-        const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
-        const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 a[TM], b[TN];
-#pragma unroll
-          for (int m = 0; m < TM; ++m)
-            a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
-#pragma unroll
-          for (int nb = 0; nb < TN; ++nb)
-            b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
-#pragma unroll
-          for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int nb = 0; nb < TN; ++nb)
-              acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[m][nb], 0, 0, 0);
-        }
-      }
-      store_b(buf ^ 1, S0{});
-      if constexpr (UP) {
-        if (row == 1 && up_chunk && chunk + 1 < chunks) store_low();   // uniform
-      }
-      if (row == 2 && chunk + 1 < chunks) {   // every wave is done with this chunk's patch
+    if constexpr (ROW == 2) {
+      if (chunk + 1 < chunks) {   // uniform; every wave is done with this chunk's patch
         __syncthreads();
         store_patch();
       }
-      __syncthreads();
-      row = row1;
-      chunk = chunk1;
     }
+    __syncthreads();
+    STAMP();
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  if constexpr (B_SETS == 2) {
+    int c = 0;
+    for (; c + 2 <= chunks; c += 2) {
+      step(R0{}, R0{}, c); step(R1{}, R1{}, c); step(R2{}, R0{}, c);
+      step(R0{}, R1{}, c + 1); step(R1{}, R0{}, c + 1); step(R2{}, R1{}, c + 1);
+    }
+    if (c < chunks) { step(R0{}, R0{}, c); step(R1{}, R1{}, c); step(R2{}, R0{}, c); }
+  } else {
+    for (int c = 0; c < chunks; ++c) { step(R0{}, R0{}, c); step(R1{}, R0{}, c); step(R2{}, R0{}, c); }
   }
 
   __bf16* outp = reinterpret_cast<__bf16*>(p.out);
@@ -985,7 +987,9 @@ void conv_patch_b16_kernel(const IgemmParams p) {
           Os[o_lane + (m * 32 + (r & 3) + 8 * (r >> 2)) * OLD + nb * 32] = (__bf16)acc[m][nb][r];
         }
     }
+    STAMP();               // tile rounded into LDS
     __syncthreads();
+    STAMP();
     constexpr int SEGS = BN / 8, O_SLOTS = TH * 32 * SEGS;
     static_assert(O_SLOTS % 256 == 0, "whole passes");
 #pragma unroll
@@ -996,7 +1000,9 @@ void conv_patch_b16_kernel(const IgemmParams p) {
       *reinterpret_cast<f32x4*>(outp + (((size_t)n * H + (y0 + (pix >> 5))) * W + x0 + (pix & 31)) * p.ldo +
                                 n0 + seg * 8) = v;
     }
+    STAMP();               // stores issued
     __syncthreads();       // the statistics epilogues reuse the stages
+    STAMP();               // output stored
   } else if constexpr (!UP)
 #pragma unroll
   for (int nb = 0; nb < TN; ++nb) {
@@ -1051,6 +1057,8 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     if (block_col_stats<BN, WAVES_M>(red, 0, 0, false, float2{0.f, 0.f}, 32.f * TM, out))
       p.stats[((size_t)n * p.stats_tiles + ty * tiles_x + tx) * p.Ncols + n0 + tid] = out;
   }
+  STAMP();
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -2209,6 +2217,11 @@ int launch_patch_b16_t(const IgemmParams& p, hipStream_t stream) {
     auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS, true>;
     UNET_SET_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  } else if constexpr (TH == 8 && BN == 64) {
+    // (the 8-row 64-column tile exists for the pre-rounded panels only - launch_patch_b16_auto
+    // does not pick it without them: its fused form with fp32 panels spills)
+    unet_set_error("conv_patch_b16: the 8 x 32-pixel tile needs the bf16 weight plane");
+    return UNET_E_INVALID;
   } else {
     auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, ACT, STATS, BSTATS, false>;
     UNET_SET_DYN_LDS(kern, lds);
@@ -2232,8 +2245,7 @@ int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_
   // 8 x 32-pixel tiles of 64 columns where they still give two workgroups per CU: half the
   // weight-panel traffic (L2 -> LDS) per output of the 4 x 32 tiles; measured -2..-16 % per
   // launch on the 64..256-channel layers, -0.13 ms per step (profiles/r04_bf16_experiments.txt)
-  static const bool no_th8 = [] { const char* e = getenv("UNET_B16_TH8"); return e && e[0] == '0'; }();
-  const bool th8 = !no_th8 && nc % 64 == 0 && p.Hin % 8 == 0 && (M / 256) * (nc / 64) >= 512;
+  const bool th8 = p.w3 && nc % 64 == 0 && p.Hin % 8 == 0 && (M / 256) * (nc / 64) >= 512;
   if (!fused && bs_px && p.bs_partial) {   // data gradient with the BSTATS epilogue
     p.bs_tile0 = 0;
     if (th8) {
@@ -2437,3 +2449,9 @@ int launch_patch_split_auto(const IgemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace unet_conv
+
+#ifdef B16_STAMPS
+extern "C" int unet_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(unet_conv::g_stamps), sizeof(unsigned long long) * 256 * 16);
+}
+#endif
