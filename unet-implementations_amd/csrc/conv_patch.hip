@@ -876,6 +876,14 @@ void conv_patch_b16_kernel(const IgemmParams p) {
   const int steps = chunks * 3;
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, B_SETS - 1>;
+  // the bias of this lane's columns, fetched here (phase stamps: read at the top of the epilogue,
+  // its latency was ~0.8 of the 13 us of a 64-channel tile); one load whether there is a bias or not
+  float bias_v[TN];
+#pragma unroll
+  for (int nb = 0; nb < TN; ++nb) {
+    const float bv = (p.bias ? p.bias : p.w)[n0 + wn0 + nb * 32 + li];
+    bias_v[nb] = p.bias ? bv : 0.f;
+  }
   load_patch(0);
   load_b(0, 0, S0{});
   if constexpr (B_SETS == 2) load_b(steps > 1 ? 1 : 0, 0, S1{});   // (chunks >= 1: step 1 = row 1 of chunk 0)
@@ -978,7 +986,7 @@ void conv_patch_b16_kernel(const IgemmParams p) {
                        ((te >> 6) % WAVES_N) * WN + (te & 31);
 #pragma unroll
     for (int nb = 0; nb < TN; ++nb) {
-      const float bv = p.bias ? p.bias[n0 + wn0 + nb * 32 + li] : 0.f;
+      const float bv = bias_v[nb];
 #pragma unroll
       for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -1007,7 +1015,7 @@ void conv_patch_b16_kernel(const IgemmParams p) {
 #pragma unroll
   for (int nb = 0; nb < TN; ++nb) {
     const int col = n0 + wn0 + nb * 32 + li;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+    const float bv = bias_v[nb];
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
       __bf16* o = outp + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
