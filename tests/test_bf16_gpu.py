@@ -130,7 +130,10 @@ def test_rgb_stem_to_bf16(ua):
                                   # the row-ring kernel with several strips, several workgroups
                                   # per strip and long walks: four waves (32 x 32 tile) and
                                   # eight waves / two rows a step (64 x 64 tiles)
-                                  (2, 256, 192, 32, 32, 1, 3), (2, 128, 96, 64, 128, 1, 3)])
+                                  (2, 256, 192, 32, 32, 1, 3), (2, 128, 96, 64, 128, 1, 3),
+                                  # a ragged last strip (W = 80 = 32 + 32 + 16) and an image
+                                  # height that is not a power of two
+                                  (2, 24, 80, 64, 64, 1, 3), (1, 40, 144, 32, 32, 1, 3)])
 def test_conv_in_bwd_weight_b16(ua, case):
     """Stride 1, bf16 tensors: conv_wgrad_b16_ring_kernel (a workgroup walks down a column strip,
     input rows in an LDS ring); stride 2: conv_wgrad_bf16_kernel<.., 2>; 1x1: the centre tap."""
