@@ -1165,7 +1165,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
   // coefficients of this thread's four channels (slot % SEG is the same for every pass)
   f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f};
   float cs = 1.f;
-  auto load_patch = [&](int chunk) {
+  // `dead`: the loads of a chunk that does not exist are issued all the same, out of range (no
+  // memory access), so that every path through the tap steps issues the same number of loads and
+  // hipcc counts vmcnt exactly (round 4: with the taps rolled around a conditional patch load it
+  // waited vmcnt(0) in the middle of EVERY tap, draining the next chunk's patch 1 us after its
+  // issue - what the peeled tap 0 of conv_patch_f32_kernel had already cured there)
+  auto load_patch = [&](int chunk, bool dead = false) __attribute__((always_inline)) {
+    const unsigned kill = dead ? 0x80000000u : 0u;
     const int c = chunk * BK;
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
@@ -1173,30 +1179,31 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
     const unsigned cbytes = (unsigned)(first ? c : c - p.C0) * 4u;
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i) {
-      const unsigned off = ((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i];
+      const unsigned off = (((unsigned)(pp_lin[i] * Cs) + cbytes) + pp_oob[i]) | kill;
       pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
     const float* al = first ? p.act0_alpha : p.act1_alpha;
     const float* be = first ? p.act0_beta : p.act1_beta;
-    if (al) {   // uniform
+    {   // (always two loads - a plain source reads the head of the weights instead)
       const size_t o = (size_t)n * Cs + (first ? c : c - p.C0) + (tid % SEG) * 4;
-      ca = *reinterpret_cast<const f32x4*>(al + o);
-      cb = *reinterpret_cast<const f32x4*>(be + o);
+      ca = *reinterpret_cast<const f32x4*>(al ? al + o : p.w);
+      cb = *reinterpret_cast<const f32x4*>(al ? be + o : p.w);
       cs = p.slope;
-    } else {    // plain source: z = v, slope 1 = identity
-      ca = f32x4{1.f, 1.f, 1.f, 1.f};
-      cb = f32x4{0.f, 0.f, 0.f, 0.f};
-      cs = 1.f;
+      if (!al) {  // uniform; plain source: z = v, slope 1 = identity
+        ca = f32x4{1.f, 1.f, 1.f, 1.f};
+        cb = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = 1.f;
+      }
     }
   };
-  auto store_patch = [&]() {
+  auto store_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i) {
       pr[i] = act4(pr[i], ca, cb, cs, (pp_oob[i] >> 31) == 0u);
       *reinterpret_cast<f32x4*>(Ps + pp_lds[i]) = pr[i];
     }
   };
-  auto load_b = [&](int t, int chunk) {
+  auto load_b = [&](int t, int chunk) __attribute__((always_inline)) {
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const int wt = (int)(((tw >> ((t & 3) * 8)) & 0xffu) >> 4);
     const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
@@ -1205,14 +1212,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                             rsw, wslot_off[j] + woff, 0, 0));
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf) __attribute__((always_inline)) {
     float* Bb = Bs + buf * B_TILE;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[j];
   };
 
   const int chunks = Ktot / BK;
-  const int steps = chunks * 9;
   load_patch(0);
   load_b(0, 0);
   store_patch();
@@ -1223,14 +1229,15 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
   // li + {0, ODD0, 1}[kx]; lane (li, lh) reads 4 consecutive k at k offset 4*lh
   const int a_lane = (2 * wrow0 * PWC + li) * LDA + 4 * lh;
   const int b_lane = (wn0 + li) * LDA + 4 * lh;
-  int t = 0, chunk = 0;
-  for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
+  // Tap 0 of a chunk (the step that also issues the next chunk's patch loads) is PEELED from
+  // the rolled loop over taps 1..8, as in conv_patch_f32_kernel: every step then issues a fixed
+  // number of loads and the waits are exact (the panel of the next tap only).
+  auto tap_step = [&](auto first_tag, int t, int chunk, int chunk_n, bool dead) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int buf = (chunk + t) & 1;   // step = 9 * chunk + t
     const int t1 = (t == 8) ? 0 : t + 1;
-    const int chunk1 = (t == 8) ? chunk + 1 : chunk;
-    const bool more = s + 1 < steps;
-    load_b(more ? t1 : t, more ? chunk1 : chunk);
-    if (t == 0) load_patch(chunk + 1 < chunks ? chunk + 1 : chunk);
+    load_b(t1, t == 8 ? chunk_n : chunk);
+    if constexpr (FIRST) load_patch(chunk_n, dead);
 
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
@@ -1263,13 +1270,21 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const IgemmParams
                                                               acc[m][nb], 0, 0, 0);
     }
     store_b(buf ^ 1);
-    if (t == 8) {            // every wave is done with this chunk's patch
-      __syncthreads();
-      store_patch();
-    }
+  };
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const bool dead = chunk + 1 >= chunks;           // (the last chunk stages nothing)
+    const int chunk_n = dead ? chunk : chunk + 1;
+    tap_step(std::true_type{}, 0, chunk, chunk_n, dead);
     __syncthreads();
-    t = t1;
-    chunk = chunk1;
+#pragma nounroll
+    for (int t = 1; t < 9; ++t) {
+      tap_step(std::false_type{}, t, chunk, chunk_n, dead);
+      if (t == 8 && !dead) {   // every wave is done with this chunk's patch
+        __syncthreads();
+        store_patch();
+      }
+      __syncthreads();
+    }
   }
 
 #pragma unroll
