@@ -1435,7 +1435,9 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_kernel(const Igemm
   const int a_lane = (wrow0 * PW + li) * LDA + 4 * lh;
   const int b_lane = (wn0 + li) * LDA + 4 * lh;
   for (int chunk = 0; chunk < chunks; ++chunk) {
-    const int chunk_n = chunk + 1 < chunks ? chunk + 1 : chunk;   // the last chunk re-stages itself
+    // (the last chunk re-stages itself; `dead` out-of-range loads and no second store measured
+    // 0.5 % SLOWER on the step, A/B on one box - tools/ab_libs.sh)
+    const int chunk_n = chunk + 1 < chunks ? chunk + 1 : chunk;
     for_range_p<0, 9>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       constexpr S2PTap T = kS2PTaps[t];
@@ -1620,11 +1622,12 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     return h;
   };
-  auto load_patch = [&](int chunk) {
+  // (`dead`: out-of-range loads for the chunk after the last: a fixed load count per step)
+  auto load_patch = [&](int chunk, bool dead = false) {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i)
       pr[i] = buf_ld4<__bf16>(rs0, (unsigned)(pp_lin[i] * Ktot + chunk * BK + seg4),
-                              pp_lin[i] < 0 ? 0x80000000u : 0u);
+                              (pp_lin[i] < 0 || dead) ? 0x80000000u : 0u);
   };
   auto store_patch = [&]() {
 #pragma unroll
@@ -1669,7 +1672,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
       constexpr int st1 = st == 2 ? 0 : st + 1;
       const int buf = (chunk + st) & 1;   // step = 3 * chunk + st
       load_b(std::integral_constant<int, st1>{}, st == 2 ? chunk_n : chunk);
-      if (st == 0 && more_chunks) load_patch(chunk_n);
+      if (st == 0) load_patch(chunk_n, !more_chunks);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         constexpr S2PTap T0 = kS2PTaps[3 * st], T1 = kS2PTaps[3 * st + 1], T2 = kS2PTaps[3 * st + 2];
