@@ -133,10 +133,15 @@ def test_rgb_stem_to_bf16(ua):
                                   (2, 256, 192, 32, 32, 1, 3), (2, 128, 96, 64, 128, 1, 3),
                                   # a ragged last strip (W = 80 = 32 + 32 + 16) and an image
                                   # height that is not a power of two
-                                  (2, 24, 80, 64, 64, 1, 3), (1, 40, 144, 32, 32, 1, 3)])
+                                  (2, 24, 80, 64, 64, 1, 3), (1, 40, 144, 32, 32, 1, 3),
+                                  # stride 2 on the row ring (two input rows a step): 64 x 64
+                                  # tiles / eight waves, 32 x 64 tiles, odd sizes
+                                  (2, 128, 128, 64, 128, 2, 3), (2, 256, 192, 32, 64, 2, 3),
+                                  (1, 48, 80, 64, 64, 2, 3)])
 def test_conv_in_bwd_weight_b16(ua, case):
     """Stride 1, bf16 tensors: conv_wgrad_b16_ring_kernel (a workgroup walks down a column strip,
-    input rows in an LDS ring); stride 2: conv_wgrad_bf16_kernel<.., 2>; 1x1: the centre tap."""
+    input rows in an LDS ring, one new row a step at stride 1, two at stride 2; shapes whose row
+    count does not split: conv_wgrad_bf16_kernel); 1x1: the centre tap."""
     N, H, W, Cx, Cout, stride, ks = case
     x, coef = r16(rnd(N, Cx, H, W, seed=1)), coeffs(N, Cx, 30)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1

@@ -870,23 +870,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradPara
 // ring is shared: 8 slots); the two halves are merged with the pixel parts in the epilogue, so
 // a workgroup still leaves ONE slab: 256 slabs per layer instead of 512 - the slabs are a third
 // of the kernel's HBM traffic at 64 x 64 tiles and all of the reduction kernel's.
-template <int CI_T, int CO_T, int S, bool ACT, int DEPTH, int RG>
+// STRIDE = 2: an output row needs input rows 2 oy - 1 .. 2 oy + 1, of which 2 oy and 2 oy + 1
+// are new: a bundle is TWO input rows (S * 2 + 1 pixels wide) and one dy row, the ring has
+// 8 RG slots, and the A fragment rows are two patch pixels apart (the transposing read takes a
+// row address per lane).
+template <int CI_T, int CO_T, int S, bool ACT, int DEPTH, int RG, int STRIDE = 1>
 __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring_kernel(const WgradParams p) {
   constexpr int TI = CI_T / 32, TJ = CO_T / 32;
   constexpr int NSB = TI * TJ, NPP = 4 / NSB, NT = 256;   // (NT: one row group)
-  constexpr int PW = S + 2;
+  constexpr int PW = (S - 1) * STRIDE + 3;
+  constexpr int NR = STRIDE;                               // new input rows per output row
   constexpr int NG = (S / 16) / NPP;
   static_assert((S / 16) % NPP == 0 && NG >= 1, "segment must split into whole k-groups");
   constexpr int XSEG = CI_T / 8, DSEG = CO_T / 8;          // 16-byte slots per pixel
-  constexpr int XS8 = PW * XSEG, DS8 = S * DSEG;           // slots of an input row / a dy row
+  constexpr int XS8 = NR * PW * XSEG, DS8 = S * DSEG;      // slots of a bundle's input rows / of a dy row
   constexpr int NLX = (XS8 + NT - 1) / NT, NLD = (DS8 + NT - 1) / NT;
   static_assert(NT % XSEG == 0 && NT % DSEG == 0, "a thread keeps its channel group");
-  constexpr int RR = 4 * RG;                               // ring slots (rows)
+  constexpr int RR = 4 * RG * STRIDE;                      // ring slots (rows)
   constexpr int RSUB = RR * PW * 32;                       // ring elements of a 32-channel sub-tile
   constexpr int RING = TI * RSUB;
   constexpr int DSUB = S * 32, DBUF = TJ * DSUB;
   static_assert((size_t)(RING + 2 * RG * DBUF) * 2 <= (RG == 2 ? kWgradMergeLds8 : kWgradMergeLds4),
                 "ring + dy stages fit the merge space");
+  static_assert(STRIDE == 1 || STRIDE == 2, "stride 1 or 2");
   extern __shared__ __attribute__((aligned(16))) __bf16 smem_h[];
   __bf16* Dst = smem_h + RING;
   typedef int i32x4r __attribute__((ext_vector_type(4)));
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
   const int oy0 = g_begin - strip * p.Ho;
   const int rows = p.segs_per_block;                       // (divides Ho: the strip is not left)
   const int n = strip / p.segs_per_row;
-  const int x0 = (strip - n * p.segs_per_row) * S;
+  const int x0 = (strip - n * p.segs_per_row) * S;         // first OUTPUT column of the strip
 
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
@@ -918,15 +924,18 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
   const int xseg = tid % XSEG, dseg = tid % DSEG;
   int x_off[NLX], x_lds[NLX];
   unsigned x_okc = 0;                                      // bit k: the slot's column is inside the image
+  unsigned x_row1 = 0;                                     // bit k: the slot belongs to the bundle's second row
 #pragma unroll
   for (int k = 0; k < NLX; ++k) {
     const int slot = tid + NT * k;
-    const int pix = slot / XSEG;
-    const int ix = x0 - 1 + pix;
+    const int r2 = (slot / XSEG) / PW;                     // 0 (.. NR - 1)
+    const int pix = slot / XSEG - r2 * PW;
+    const int ix = x0 * STRIDE - 1 + pix;
     const bool ok = slot < XS8 && (unsigned)ix < (unsigned)p.W;
     x_okc |= (ok ? 1u : 0u) << k;
-    x_off[k] = (ix * p.Cx + ci0 + xseg * 8) * 2;
-    x_lds[k] = (xseg >> 2) * RSUB + pix * 32 + (xseg & 3) * 8;
+    x_row1 |= (r2 ? 1u : 0u) << k;
+    x_off[k] = ((r2 * p.W + ix) * p.Cx + ci0 + xseg * 8) * 2;
+    x_lds[k] = (xseg >> 2) * RSUB + (r2 * PW + pix) * 32 + (xseg & 3) * 8;
   }
   int d_off[NLD], d_lds[NLD];
   unsigned d_okc = 0;
@@ -950,15 +959,17 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
   }
 
   i32x4r rx[DEPTH][NLX], rd[DEPTH][NLD];
-  unsigned rok[DEPTH];                                     // uniform: the set's input row is inside the image
-  // bundle t of the walk: input row oy0 + t + 1 (the new bottom row of step t) and dy row oy0 + t
+  unsigned rok[DEPTH];                                     // uniform: bit r: row iy + r of the set is inside the image
+  // bundle t of the walk: the new bottom row(s) of step t - rows iy .. iy + NR - 1 - and dy row oy0 + t
   auto load_x = [&](auto setc, int iy) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
-    const bool rowok = (unsigned)iy < (unsigned)p.H;
-    rok[SET] = rowok ? 1u : 0u;
+    const unsigned ok0 = (unsigned)iy < (unsigned)p.H ? 1u : 0u;
+    const unsigned ok1 = (NR == 2 && (unsigned)(iy + 1) < (unsigned)p.H) ? 2u : 0u;
+    rok[SET] = ok0 | ok1;
     const int rowbase = (n * p.H + iy) * p.W * p.Cx * 2;
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {
+      const bool rowok = (rok[SET] >> ((x_row1 >> k) & 1u)) & 1u;
       const bool ok = rowok && ((x_okc >> k) & 1u);
       rx[SET][k] = __builtin_amdgcn_raw_buffer_load_b128(
           rsx, ok ? (unsigned)(rowbase + x_off[k]) : 0x80000000u, 0, 0);
@@ -982,7 +993,7 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
     for (int k = 0; k < NLX; ++k) {
       if (NT * (k + 1) <= XS8 || tid + NT * k < XS8) {
         if (ACT) {
-          const bool ok = rok[SET] && ((x_okc >> k) & 1u);   // zero padding stays zero
+          const bool ok = ((rok[SET] >> ((x_row1 >> k) & 1u)) & 1u) && ((x_okc >> k) & 1u);   // zero padding stays zero
           const i32x4r q = rx[SET][k];
           const f32x4 lo = act4(widen16(i32x2r{q[0], q[1]}), ca[0], cb[0], p.slope, ok);
           const f32x4 hi = act4(widen16(i32x2r{q[2], q[3]}), ca[1], cb[1], p.slope, ok);
@@ -1017,17 +1028,24 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
   // bundle t of a row group: input row oy0 + RG t + 1 + lg (the new bottom rows of step t) and
   // dy row oy0 + RG t + lg.  prologue: rows oy0 - 1 and oy0, then bundle 0; bundles 1 .. DEPTH-1
   // stay in flight
-  for (int r = lg; r < 2; r += RG) {     // uniform per row group
-    load_x(C0{}, oy0 - 1 + r);
-    store_x(C0{}, oy0 - 1 + r);
+  // (first new input row of output row oy: oy + 1 at stride 1, 2 oy at stride 2)
+  auto new_row = [](int oy) { return STRIDE == 1 ? oy + 1 : 2 * oy; };
+  if constexpr (STRIDE == 1) {
+    for (int r = lg; r < 2; r += RG) {     // uniform per row group
+      load_x(C0{}, oy0 - 1 + r);
+      store_x(C0{}, oy0 - 1 + r);
+    }
+  } else {                                 // row 2 oy0 - 1 = the second row of bundle "-1"
+    load_x(C0{}, new_row(oy0 - RG + lg));  // (the group of output row oy0 - 1 brings it; the
+    store_x(C0{}, new_row(oy0 - RG + lg)); //  other rows of that round land in slots nothing reads)
   }
-  load_x(C0{}, oy0 + 1 + lg);
+  load_x(C0{}, new_row(oy0 + lg));
   load_d(C0{}, oy0 + lg);
-  store_x(C0{}, oy0 + 1 + lg);
+  store_x(C0{}, new_row(oy0 + lg));
   store_d(C0{}, lg);
   for_range<1, DEPTH>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    load_x(jc, oy0 + RG * j + 1 + lg);
+    load_x(jc, new_row(oy0 + RG * j + lg));
     load_d(jc, oy0 + RG * j + lg);
   });
   __syncthreads();
@@ -1038,6 +1056,11 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
   auto frag = [&](const __bf16* q) __attribute__((always_inline)) {
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto frag_a = [&](const __bf16* q) __attribute__((always_inline)) {   // rows STRIDE pixels apart
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * STRIDE * 32));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
   const int steps = rows / RG;
@@ -1051,7 +1074,7 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
       // (past the workgroup's range the loads are out of range on purpose: they return zeros
       // that are stored into slots nothing reads - the waits stay countable)
       const bool more = t + DEPTH < steps;
-      load_x(jc, more ? oy + RG * DEPTH + 1 : -2);
+      load_x(jc, more ? new_row(oy + RG * DEPTH) : -4);
       load_d(jc, more ? oy + RG * DEPTH : p.Ho);
       const __bf16* P = smem_h + wi * RSUB;
       const __bf16* D = Dst + ((t & 1) * RG + lg) * DBUF + wj * DSUB;
@@ -1061,14 +1084,14 @@ __global__ __launch_bounds__(256 * RG, RG == 2 ? 1 : 2) void conv_wgrad_b16_ring
         const bf16x8 b = frag(D + r0 * 32 + tcol);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-          const __bf16* pr = P + (((oy - 1 + u) & (RR - 1)) * PW + r0) * 32 + tcol;
+          const __bf16* pr = P + (((STRIDE * oy - 1 + u) & (RR - 1)) * PW + STRIDE * r0) * 32 + tcol;
 #pragma unroll
           for (int v = 0; v < 3; ++v)
-            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pr + v * 32), b, acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_a(pr + v * 32), b, acc[u][v], 0, 0, 0);
         }
       }
       // bundle t + 1 (set JN, loaded DEPTH - 1 steps ago): rows into the slots no wave reads
-      store_x(std::integral_constant<int, JN>{}, oy + RG + 1);
+      store_x(std::integral_constant<int, JN>{}, new_row(oy + RG));
       store_d(std::integral_constant<int, JN>{}, ((t + 1) & 1) * RG + lg);
       __syncthreads();
     });
@@ -1520,7 +1543,7 @@ int wgrad_tiles(int Cx, int Cout) {
 // (2: measured against 4 per layer - equal or 5-8 % faster, and 24 registers fewer)
 constexpr int kRingDepth = 2;   // steps whose operands are in flight in conv_wgrad_b16_ring_kernel
 WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec = 0,
-                    bool wide = false, bool ring8 = false) {
+                    bool wide = false, bool ring8 = false, bool ring_s2 = false) {
   WgradPlan pl{};
   pl.nw = 4;
   if (Cx == 3) {
@@ -1571,7 +1594,7 @@ WgradPlan make_plan(int N, int H, int W, int Cx, int Cout, int stride, int prec 
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   pl.segs_per_block = ceil_div(pl.total_segs, split);
-  if (prec == 1 && stride == 1 && pl.nw == 4) {
+  if (((prec == 1 && stride == 1) || (ring_s2 && stride == 2)) && pl.nw == 4) {
     // the row-ring kernel (bf16 tensors) walks down a column strip: a workgroup's range must
     // lie inside one strip and be a whole number of prefetch rounds.  Harmless to the segment
     // kernels, which enumerate the same g differently.  ring8: its eight-wave form - one
@@ -2434,30 +2457,30 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t stream) {
 
 // mixed-precision pipeline, stride 1, bf16 tensors: the row-ring form (plan: make_plan)
 bool wgrad_ring_ok(const WgradParams& p, int rg) {
-  return rg >= 1 && p.b16 && p.Ho == p.H && p.Wo == p.W &&
+  return rg >= 1 && p.b16 &&
          p.segs_per_block % (kRingDepth * rg) == 0 && p.Ho % p.segs_per_block == 0 &&
          p.total_segs % p.segs_per_block == 0 && p.Cx % 8 == 0 && p.Cout % 8 == 0;
 }
-template <int CI_T, int CO_T, int S, int RG>
+template <int CI_T, int CO_T, int S, int RG, int STRIDE>
 int launch_wgrad_b16_ring_t(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = RG == 2 ? kWgradMergeLds8 : kWgradMergeLds4;
   const unsigned grid = (unsigned)(p.split * p.ci_tiles * p.co_tiles);
   if (p.alpha) {
-    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, true, kRingDepth, RG>;
+    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, true, kRingDepth, RG, STRIDE>;
     UNET_SET_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, stream, p);
   } else {
-    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, false, kRingDepth, RG>;
+    auto kern = conv_wgrad_b16_ring_kernel<CI_T, CO_T, S, false, kRingDepth, RG, STRIDE>;
     UNET_SET_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * RG), lds, stream, p);
   }
   UNET_CHECK_LAUNCH("conv_wgrad_b16_ring");
   return UNET_OK;
 }
-template <int CI_T, int CO_T, int S>
+template <int CI_T, int CO_T, int S, int STRIDE = 1>
 int launch_wgrad_b16_ring(const WgradParams& p, int rg, hipStream_t stream) {
-  return rg == 2 ? launch_wgrad_b16_ring_t<CI_T, CO_T, S, 2>(p, stream)
-                 : launch_wgrad_b16_ring_t<CI_T, CO_T, S, 1>(p, stream);
+  return rg == 2 ? launch_wgrad_b16_ring_t<CI_T, CO_T, S, 2, STRIDE>(p, stream)
+                 : launch_wgrad_b16_ring_t<CI_T, CO_T, S, 1, STRIDE>(p, stream);
 }
 
 // mixed-precision pipeline, stride 2: bf16 tensors, bf16 matrix cores
@@ -2598,6 +2621,11 @@ int launch_wgrad_plan(const WgradParams& p, const WgradPlan& pl, int stride, int
     if (pl.ci_t == 32 && pl.co_t == 32) return launch_wgrad_bf16<32, 32, 64, 3, true>(p, stream);
     if (pl.ci_t == 32) return launch_wgrad_bf16<32, 64, 32, 3>(p, stream);
     return launch_wgrad_bf16<64, 64, 16, 3>(p, stream);
+  }
+  if (p.b16 && prec == 1 && stride == 2 && (pl.S / 16) % pl.npp == 0 && wgrad_ring_ok(p, pl.rg) &&
+      !ring_off()) {   // the row-ring form with two input rows a step
+    if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_ring<64, 64, 16, 2>(p, pl.rg, stream);
+    if (pl.ci_t == 32 && pl.co_t == 64 && pl.S == 32) return launch_wgrad_b16_ring<32, 64, 32, 2>(p, pl.rg, stream);
   }
   if (p.b16 && prec == 1 && stride == 2 && (pl.S / 16) % pl.npp == 0) {
     if (pl.ci_t == 64 && pl.S == 16) return launch_wgrad_b16_s2<64, 64, 16>(p, stream);
@@ -2748,10 +2776,11 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
   static const bool ring8_off = [] { const char* e = getenv("UNET_WGRAD_RING8"); return e && e[0] == '0'; }();
   // (64 x 64 channel tiles only: measured per layer - 32 x 32 tiles, enc0 / dec4 at 512 x 512,
   // lose 20 % in the eight-wave form, the 64- and 128-channel layers gain 15 %, deeper ones +-0)
-  const bool ring8 = b16 && pprec == 1 && !ring8_off && Cx % 64 == 0 && Cout % 64 == 0;
+  const bool ring_s2 = b16 && prec == 1 && stride == 2;
+  const bool ring8 = b16 && (pprec == 1 || ring_s2) && !ring8_off && Cx % 64 == 0 && Cout % 64 == 0;
   const WgradPlan pl = wino32 ? make_plan_wino32(N, H, W)
                        : wino ? make_plan_wino(N, H, W, Cx, Cout)
-                              : make_plan(N, H, W, Cx, Cout, stride, pprec, wide, ring8);
+                              : make_plan(N, H, W, Cx, Cout, stride, pprec, wide, ring8, ring_s2);
   const size_t need = ((wino || wino32) ? pl.ws_floats
                             : wgrad_ws_floats(N, H, W, Cx, Cout, stride, pprec, wide)) * sizeof(float);
   if (workspace_bytes < need || need == 0) {
@@ -2803,7 +2832,7 @@ static int conv_bwd_weight_impl(const float* x, int Cx, const float* dy, float* 
     int nslab = 0;
     for (int nb = 0; nb < N; nb += nmax) {   // one pass unless a tensor exceeds 2 GiB
       const int nc = N - nb < nmax ? N - nb : nmax;
-      const WgradPlan pc = (wino || wino32) ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide, ring8);
+      const WgradPlan pc = (wino || wino32) ? pl : make_plan(nc, H, W, Cx, Cout, stride, pprec, wide, ring8, ring_s2);
       WgradParams p{};
       p.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) +
                                            (size_t)nb * H * W * Cx * es);
