@@ -661,7 +661,7 @@ void conv_patch_b16_kernel(const IgemmParams p) {
   // UP: low-resolution scratch slots (clamped pixel index of the source; a pass = 32 pixels) and,
   // per patch slot, its top-left scratch pixel (bits 4..) + the parities that pick the 0.75 / 0.25
   // weights (bits 0, 1)
-  int lp_lin[UP ? L_PASSES : 1], pp_low[UP ? P_PASSES : 1];
+  int lp_lin[UP ? L_PASSES : 1];
   if constexpr (UP) {
     const int h = H >> 1, w = W >> 1;
 #pragma unroll
@@ -673,15 +673,6 @@ void conv_patch_b16_kernel(const IgemmParams p) {
       gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
       gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
       lp_lin[j] = (n * h + gy) * w + gx;
-    }
-#pragma unroll
-    for (int i = 0; i < P_PASSES; ++i) {
-      const int pix = slot_of(i) >> 3;
-      const int prow = pix / PW, pcol = pix - prow * PW;
-      // (image row / column 0: PyTorch clamps the source coordinate to 0, weights (0, 1) on the
-      // clamped pair - bits 2, 3)
-      pp_low[i] = (((prow >> 1) * LW + (pcol >> 1)) << 4) | ((prow & 1) << 1) | (pcol & 1) |
-                  ((y0 - 1 + prow == 0) ? 8 : 0) | ((x0 - 1 + pcol == 0) ? 4 : 0);
     }
   }
   // weight slot of pass j = tid + 256 j: (tap in row, column row, segment).  BN * B_SEGS (slots
@@ -794,30 +785,54 @@ void conv_patch_b16_kernel(const IgemmParams p) {
       }
     }
   };
+  // The blend, by 2 x 2 BLOCKS of patch pixels: patch rows 2b, 2b + 1 (an odd and the next even
+  // image row) take the same two low-resolution rows, with weights (0.75, 0.25) and (0.25, 0.75) -
+  // image row 0: (0, 1), PyTorch clamps the source coordinate - and columns alike, so a block
+  // shares its four scratch pixels: 4 reads, 4 row blends and 4 column blends for four outputs
+  // (one pixel at a time it was 16 reads and 12 blends), the same fused multiply-adds in the same
+  // order as blend2x2 / upsample2x_fwd_b16x8_kernel: bit-identical.  Zero padding after the blend.
   auto blend_patch = [&]() __attribute__((always_inline)) {
     if constexpr (UP) {
+      constexpr int BW = PW / 2, BH = (TH + 2) / 2;
+      constexpr int U_PASSES = (BH * BW * 8 + 255) / 256;
+      int tb = tid;               // (opaque: nothing of this is carried across the K loop)
+      asm volatile("" : "+v"(tb));
+      const int sg4 = (tb & 7) * 4;
 #pragma unroll
-      for (int i = 0; i < P_PASSES; ++i) {
-        // (opaque per use: the scheduler would otherwise keep the scratch address, the four
-        // weights and the padding factor of EVERY pass in registers across the K loop)
-        int lw = pp_low[i];
-        unsigned oob = pp_oob(i);
-        asm volatile("" : "+v"(lw), "+v"(oob));
-        const float* L = Ls + (lw >> 4) * LLD + seg4;
-        const f32x4 p00 = *reinterpret_cast<const f32x4*>(L);
-        const f32x4 p01 = *reinterpret_cast<const f32x4*>(L + LLD);
-        const f32x4 p10 = *reinterpret_cast<const f32x4*>(L + LW * LLD);
-        const f32x4 p11 = *reinterpret_cast<const f32x4*>(L + LW * LLD + LLD);
-        // odd patch row = even image row 2k: taps (k-1, k) weigh (0.25, 0.75); even patch row =
-        // odd image row: (0.75, 0.25); columns alike (y0, x0 are even)
-        const float wy1 = (lw & 8) ? 1.f : ((lw & 2) ? 0.75f : 0.25f), wy0 = 1.f - wy1;
-        const float wx1 = (lw & 4) ? 1.f : ((lw & 1) ? 0.75f : 0.25f), wx0 = 1.f - wx1;
-        const float okf = oob == 0u ? 1.f : 0.f;
-        const f32x4 v = blend2x2(p00, p01, p10, p11, wx0, wx1, wy0, wy1) * okf;
-        *reinterpret_cast<bf16x4*>(Ps + pp_lds(i)) = to_bf16(v);
-        // two passes (eight ds_read_b128) in flight, no more: hoisting all 4 * P_PASSES reads
-        // ahead of the first blend is what the scheduler does otherwise (176 registers at TH = 8)
-        if (i & 1) asm volatile("" ::: "memory");
+      for (int i = 0; i < U_PASSES; ++i) {
+        const int bq = (tb >> 3) + 32 * i;
+        if (bq < BH * BW) {
+          const int brow = bq / BW, bcol = bq - brow * BW;
+          const float* L = Ls + (brow * LW + bcol) * LLD + sg4;
+          const f32x4 p00 = *reinterpret_cast<const f32x4*>(L);
+          const f32x4 p01 = *reinterpret_cast<const f32x4*>(L + LLD);
+          const f32x4 p10 = *reinterpret_cast<const f32x4*>(L + LW * LLD);
+          const f32x4 p11 = *reinterpret_cast<const f32x4*>(L + LW * LLD + LLD);
+          const int iy0 = y0 - 1 + 2 * brow, ix0 = x0 - 1 + 2 * bcol;   // image pixel of (dy, dx) = (0, 0)
+          const float wxb1 = ix0 + 1 == 0 ? 1.f : 0.75f, wxb0 = 1.f - wxb1;   // dx = 1 (even image column)
+          const float wyb1 = iy0 + 1 == 0 ? 1.f : 0.75f, wyb0 = 1.f - wyb1;   // dy = 1 (even image row)
+          f32x4 t[2][2];          // [low row][dx]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            t[0][0][e] = __builtin_fmaf(p01[e], 0.25f, p00[e] * 0.75f);
+            t[1][0][e] = __builtin_fmaf(p11[e], 0.25f, p10[e] * 0.75f);
+            t[0][1][e] = __builtin_fmaf(p01[e], wxb1, p00[e] * wxb0);
+            t[1][1][e] = __builtin_fmaf(p11[e], wxb1, p10[e] * wxb0);
+          }
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const float wy1 = dy ? wyb1 : 0.25f, wy0 = dy ? wyb0 : 0.75f;
+              const bool ok = (unsigned)(iy0 + dy) < (unsigned)H && (unsigned)(ix0 + dx) < (unsigned)W;
+              const float okf = ok ? 1.f : 0.f;
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[1][dx][e], wy1, t[0][dx][e] * wy0) * okf;
+              *reinterpret_cast<bf16x4*>(Ps + ((2 * brow + dy) * PW + 2 * bcol + dx) * LDA + sg4) = to_bf16(v);
+            }
+        }
+        asm volatile("" ::: "memory");   // one pass (four ds_read_b128) at a time
       }
     }
   };
