@@ -460,9 +460,12 @@ def main():
 
     # The data-parallel step is capturable too (RCCL's collectives become graph nodes on RCCL's
     # stream).  At N = 1 the leg always runs (with UNET_BENCH_RCCL=1 through the one-rank RCCL
-    # group, collectives captured); at N > 1 it runs under a time limit (Bailout above) and can be
-    # switched off with UNET_BENCH_DDP_GRAPH=0.
-    ddp_graph = use_dist and backend == "nccl" and os.environ.get("UNET_BENCH_DDP_GRAPH", "1") != "0"
+    # group, collectives captured).  At N > 1 it is OPT-IN (UNET_BENCH_DDP_GRAPH=1, under the
+    # Bailout time limit above): no node with more than one GPU was ever available to rehearse a
+    # multi-rank capture, and a failure there need not be an exception (RCCL's watchdog thread
+    # aborts the process), which would cost the run its eager line as well.
+    ddp_graph = use_dist and backend == "nccl" and \
+        os.environ.get("UNET_BENCH_DDP_GRAPH", "1" if world == 1 else "0") != "0"
 
     def graph_leg():
         """The same K steps replayed from ONE HIP graph (ua.GraphedTrainStep): what the step
