@@ -719,13 +719,18 @@ void conv_patch_b16_kernel(const IgemmParams p) {
   float cs = 1.f;
   static_assert(L_PASSES <= P_PASSES, "the low-resolution slots travel in pr[]");
   bool up_chunk = false;           // UP: the chunk in the registers comes from source 0 (uniform)
-  // (opaque: the pixel index times the channel count of BOTH sources would otherwise be kept per
-  // pass across the K loop - 2 x P_PASSES registers that decide two or three workgroups per CU)
-  auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
   // `dead`: the loads of a chunk that does not exist (issued all the same, out of range = no memory
   // access, so that every path through a K step issues the SAME NUMBER of loads: hipcc then counts
   // vmcnt exactly; with a conditional load anywhere in the loop it falls back to vmcnt(0) at every
   // LDS store of a weight panel, which exposed a full load latency per step - round 4 finding)
+  // Byte offsets of the patch slots in the CURRENT source (pixel * channels + this thread's four
+  // channels, bit 31 = padding), rebuilt when the source changes - once per tile at most; a
+  // chunk's loads then cost no VALU instruction at all: the chunk offset rides in the SCALAR
+  // offset of the buffer load (raw buffers: not part of the range check, so padding slots stay
+  // out of range).  (Phase stamps: a K step that issued 11 loads cost 0.6-1.0 us more than one
+  // that did not - six address instructions per load.)
+  unsigned pp_off[P_PASSES];
+  int pp_src = -1;
   auto load_patch = [&](int chunk, bool dead = false) __attribute__((always_inline)) {
     const unsigned kill = dead ? 0x80000000u : 0u;
     const int c = chunk * BK;
@@ -733,6 +738,13 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int Cs = first ? p.C0 : p.C1;
     const int cc = (first ? c : c - p.C0) + seg4;
+    if (pp_src != (first ? 0 : 1)) {   // uniform; no load inside
+      pp_src = first ? 0 : 1;
+#pragma unroll
+      for (int i = 0; i < P_PASSES; ++i)
+        pp_off[i] = ((unsigned)((pp_lin[i] & 0x7fffffff) * Cs + seg4) * 2u) | pp_oob(i);
+    }
+    const int soff = (first ? c : c - p.C0) * 2;       // bytes, scalar
     if constexpr (UP) {
       up_chunk = first;
       if (first) {   // uniform: the low-resolution pixels under the patch (clamped, all valid)
@@ -745,12 +757,12 @@ void conv_patch_b16_kernel(const IgemmParams p) {
       } else {
 #pragma unroll
         for (int i = 0; i < P_PASSES; ++i)
-          pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i) | kill);
+          pr[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, pp_off[i] | kill, soff, 0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < P_PASSES; ++i)
-        pr[i] = buf_ld4_raw16(rs, (unsigned)((opaque(pp_lin[i]) & 0x7fffffff) * Cs + cc), pp_oob(i) | kill);
+        pr[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, pp_off[i] | kill, soff, 0);
     }
     if (ACT) {
       const float* al = first ? p.act0_alpha : p.act1_alpha;
