@@ -487,3 +487,26 @@ def test_prerounded_bf16_weights_are_bit_identical(ua, case):
     dx_a = ua.ops.conv3x3_bwd_data(dy, wd, 0, C0, H, W, 1, bf16="bf16")
     dx_b = ua.ops.conv3x3_bwd_data(dy, wd, 0, C0, H, W, 1, bf16="bf16", wd3=wd3)
     assert torch.equal(dx_a, dx_b)
+
+
+def test_weight_gradient_shape_sweep_b16(ua):
+    """Twenty-four seeded shapes (heights that are and are not multiples of the ring's round,
+    ragged strips, both strides, every channel tile) through unet_conv_in_bwd_weight_b16: each
+    lands on the row-ring kernel (one or two row groups), or - when the rows do not split - on the
+    segment kernel, and all are held against the fp64 evaluation of the same bf16 operands."""
+    g = torch.Generator().manual_seed(1234)
+    pick = lambda xs: xs[int(torch.randint(len(xs), (1,), generator=g))]
+    for case in range(24):
+        stride = pick([1, 1, 2])
+        Cx, Cout = pick([32, 64, 128]), pick([32, 64, 128])
+        N = pick([1, 2, 3])
+        H = pick([8, 12, 16, 20, 24, 40, 64]) * stride
+        W = pick([16, 32, 48, 80, 96]) * stride
+        x, coef = r16(rnd(N, Cx, H, W, seed=100 + case)), coeffs(N, Cx, 200 + case)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        dy = r16(rnd(N, Cout, Ho, Wo, seed=300 + case))
+        wz = torch.zeros(Cout, Cx, 3, 3, dtype=torch.double, requires_grad=True)
+        F.conv2d(act_ref(x, *coef), wz, None, stride=stride, padding=1).backward(dy.double())
+        dw = torch.zeros(Cout, Cx, 3, 3, device=DEV)
+        ua.ops.conv_in_bwd_weight(src(ua, x, coef), SLOPE, to_nhwc_b16(dy), dw, 0, 3, stride)
+        check(dw.cpu(), wz.grad, 5e-3, f"dw case {case}: N={N} {H}x{W} {Cx}->{Cout} stride {stride}")
