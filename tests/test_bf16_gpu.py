@@ -83,6 +83,11 @@ FWD = [  # (N, H, W, C0, C1, Cout, stride, ksize)
     (8, 16, 16, 512, 0, 512, 1, 3),     # 1/32-resolution layer at bs 8: K-group gather-GEMM (KG 4)
     (8, 32, 32, 512, 0, 512, 2, 3),     # ... its stride-2 sibling (encoder_stages.5.block.0)
     (2, 16, 16, 64, 64, 64, 1, 3),      # two sources through the K-group form (KG 4)
+    # the stride-2 fused forward on the patch kernel (conv_patch_b16_kernel<.., SD = 2>): one and
+    # two 32-channel chunks, image borders on every side, H != W
+    (4, 256, 256, 32, 0, 64, 2, 3),
+    (2, 256, 128, 64, 0, 128, 2, 3),
+    (8, 64, 128, 128, 0, 256, 2, 3),
 ]
 
 

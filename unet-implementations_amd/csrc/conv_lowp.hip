@@ -667,6 +667,10 @@ int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px, 
     if (rc != 1) return rc;
     if (bs_px) *bs_px = 0;
   }
+  if (stats_px && !bs_px) {   // the stride-2 fused forward: its own patch form (conv_patch.hip)
+    const int rc = launch_patch_s2_b16_auto(p, stream, stats_px);
+    if (rc != 1) return rc;
+  }
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
     return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px, bs_px);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)

@@ -253,6 +253,7 @@ bool wino_up32_applicable(const IgemmParams& p);              // (64 up + 32) ->
 int launch_wino_up32(const IgemmParams& p, hipStream_t stream);
 bool patch_s2_applicable(const IgemmParams& p);               // stride-2 forward, conv_patch.hip
 int launch_patch_s2_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);
+int launch_patch_s2_b16_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);   // bf16 tensors
 int launch_dgrad_s2_patch_auto(const IgemmParams& p, hipStream_t stream, int* bs_tiles_out);
 int launch_patch_b16_up_auto(const IgemmParams& p, hipStream_t stream, int* stats_px);   // conv_patch.hip
 int launch_dgrad_s2_patch_b16_auto(const IgemmParams& p, hipStream_t stream, int* bs_tiles_out);   // bf16 tensors

@@ -571,14 +571,22 @@ __global__ __launch_bounds__(256, 2) void conv_patch_f32_kernel(const IgemmParam
 #ifdef B16_STAMPS
 __device__ unsigned long long g_stamps[256 * 16];   // (timing experiments only: tools/stamps_b16.py)
 #endif
+// SD = 2 (round 4, fused forward only): the stride-2 first convolution of an encoder stage.  The
+// patch is the (2 TH + 1) x 65 INPUT pixels under a TH x 32 tile of output pixels; an LDS patch
+// row holds the 33 even input columns first and the 32 odd ones behind them (as
+// conv_patch_s2_kernel), so the fragment of tap kx for output columns 0..31 is 32 consecutive
+// slots (kx = 0: even 0.., kx = 1: odd 0.., kx = 2: even 1..) and fragment rows of consecutive
+// output rows are two patch rows apart.  Everything else - K steps of three taps, panels,
+// statistics, the output tile through LDS - is the stride-1 code.
 template <int BN, int WM, int WN, int TH, bool ACT = false, bool STATS = false, bool BSTATS = false,
-          bool WB = false, bool UP = false>
+          bool WB = false, bool UP = false, int SD = 1>
 // (32-accumulator tiles without the up-sampling loader - and, when fused, with the pre-rounded
 // weight panels - stay under 170 registers and 48 KB of LDS: three workgroups per CU - the short K loops of the 32- and 64-channel layers expose one
 // HBM latency per chunk, and the third workgroup is what covers it)
-__global__ __launch_bounds__(256, ((WM / 32) * (WN / 32) <= 2 && !UP && (WB || !ACT)) ? 3 : 2)
+__global__ __launch_bounds__(256, ((WM / 32) * (WN / 32) <= 2 && !UP && (WB || !ACT) && SD == 1) ? 3 : 2)
 void conv_patch_b16_kernel(const IgemmParams p) {
   static_assert(!UP || (ACT && STATS && !BSTATS), "UP is a fused-forward loader");
+  static_assert(SD == 1 || (SD == 2 && ACT && STATS && !BSTATS && !UP), "stride 2: the fused forward");
 #ifdef B16_STAMPS
   int stamp_i = 0;
 #define STAMP() do { if (threadIdx.x == 0 && blockIdx.x >= B16_STAMPS && blockIdx.x < B16_STAMPS + 256 && stamp_i < 16) \
@@ -588,8 +596,9 @@ void conv_patch_b16_kernel(const IgemmParams p) {
 #endif
   STAMP();
   constexpr int BK = 32, LDA = BK + 8;       // bf16 elements per LDS row
-  constexpr int TW = 32, PW = TW + 2;
-  constexpr int PPIX = (TH + 2) * PW;
+  constexpr int TW = 32, PW = SD == 2 ? 2 * TW + 1 : TW + 2;
+  constexpr int ODD0 = TW + 1;               // SD = 2: first odd-column slot of a patch row
+  constexpr int PPIX = (SD == 2 ? 2 * TH + 1 : TH + 2) * PW;
   constexpr int LW = TW / 2 + 2, LPIX = (TH / 2 + 2) * LW;   // UP: low-resolution scratch pixels
   constexpr int L_PASSES = (LPIX * 8 + 255) / 256, LLD = 36;  // fp32 scratch rows of 36 floats
   constexpr int P_SLOTS = PPIX * 8;          // 4-channel slots: 32 channels per pixel
@@ -611,8 +620,9 @@ void conv_patch_b16_kernel(const IgemmParams p) {
   const int li = lane & 31, lh = lane >> 5;
   const int wrow0 = (wave / WAVES_N) * TM, wn0 = (wave % WAVES_N) * WN;
 
-  const int H = p.Hin, W = p.Win;
-  const int tiles_n = p.Ncols / BN, tiles_x = W / TW, tiles_y = H / TH;
+  const int H = p.Hin, W = p.Win;            // input image (the bounds of the patch)
+  const int Ho = SD == 2 ? p.Hl : H, Wo = SD == 2 ? p.Wl : W;   // output image (the tiles)
+  const int tiles_n = p.Ncols / BN, tiles_x = Wo / TW, tiles_y = Ho / TH;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % tiles_n; bid /= tiles_n;
   const int tx = bid % tiles_x; bid /= tiles_x;
@@ -644,8 +654,9 @@ void conv_patch_b16_kernel(const IgemmParams p) {
 #pragma unroll
   for (int i = 0; i < P_PASSES; ++i) {
     const int pix = slot_of(i) >> 3;
-    const int prow = pix / PW, pcol = pix - prow * PW;
-    const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+    const int prow = pix / PW, pidx = pix - prow * PW;
+    const int pcol = SD == 2 ? (pidx < ODD0 ? 2 * pidx : 2 * (pidx - ODD0) + 1) : pidx;
+    const int iy = SD * y0 - 1 + prow, ix = SD * x0 - 1 + pcol;
     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     pp_lin[i] = ok ? (n * H + iy) * W + ix : (int)0x80000000;
   }
@@ -925,7 +936,14 @@ void conv_patch_b16_kernel(const IgemmParams p) {
   STAMP();          // first stage in LDS
 
   // lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of its row
-  const int a_lane = ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
+  // (SD = 2: output pixel (wrow0 + m, li), tap (ky, kx) -> patch row 2 (wrow0 + m) + ky, column
+  // slot li + {0, ODD0, 1}[kx])
+  const int a_lane = SD == 2 ? (2 * wrow0 * PW + li) * LDA + 8 * lh
+                             : ((wrow0 + 1) * PW + li + 1) * LDA + 8 * lh;
+  auto tap_lds = [&](int oy, int ox) __attribute__((always_inline)) {   // (oy, ox) = (ky - 1, kx - 1)
+    if constexpr (SD == 2) return ((oy + 1) * PW + (ox == 0 ? ODD0 : (ox + 1) >> 1)) * LDA;
+    else return (oy * PW + ox) * LDA;
+  };
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
   // One K step (three taps of kernel row ROW) with EVERYTHING that issues a load fixed at compile
   // time: the row, the register set that receives this step's panel load (PH; the other set holds
@@ -948,14 +966,14 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     for (int j = 0; j < 3; ++j) {
       int oy, ox, wt;
       tap_of(3 * ROW + j, oy, ox, wt);
-      const __bf16* Ab = Ps + a_lane + (oy * PW + ox) * LDA;
+      const __bf16* Ab = Ps + a_lane + tap_lds(oy, ox);
       const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
         bf16x8 a[TM], b[TN];
 #pragma unroll
         for (int m = 0; m < TM; ++m)
-          a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
+          a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * SD * PW * LDA + kk * 16);
 #pragma unroll
         for (int nb = 0; nb < TN; ++nb)
           b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
@@ -1032,7 +1050,7 @@ void conv_patch_b16_kernel(const IgemmParams p) {
       const int slot = te + 256 * i;
       const int pix = slot / SEGS, seg = slot - pix * SEGS;
       const f32x4 v = *reinterpret_cast<const f32x4*>(Os + pix * OLD + seg * 8);
-      *reinterpret_cast<f32x4*>(outp + (((size_t)n * H + (y0 + (pix >> 5))) * W + x0 + (pix & 31)) * p.ldo +
+      *reinterpret_cast<f32x4*>(outp + (((size_t)n * Ho + (y0 + (pix >> 5))) * Wo + x0 + (pix & 31)) * p.ldo +
                                 n0 + seg * 8) = v;
     }
     STAMP();               // stores issued
@@ -1045,7 +1063,7 @@ void conv_patch_b16_kernel(const IgemmParams p) {
     const float bv = bias_v[nb];
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-      __bf16* o = outp + (((size_t)n * H + (y0 + wrow0 + m)) * W + x0 + 4 * lh) * p.ldo + col;
+      __bf16* o = outp + (((size_t)n * Ho + (y0 + wrow0 + m)) * Wo + x0 + 4 * lh) * p.ldo + col;
       if (p.accumulate) {        // uniform: all 16 reads in flight before the first add
         float old[16];
 #pragma unroll
@@ -2345,6 +2363,36 @@ int launch_patch_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_
 
 // Fused-layer stride-2 forward on the patch-staged kernel; returns 1 when no tile shape fills
 // the chip (the caller falls back to the gather-GEMM).  *stats_px = pixels per statistics tile.
+// Stride-2 fused forward on bf16 tensors (round 4): conv_patch_b16_kernel<.., SD = 2>.  Returns 1
+// when the shape does not tile or fill the chip (the caller keeps the bf16 gather-GEMM).
+template <int BN, int WM, int WN, int TH>
+int launch_patch_b16_s2_t(const IgemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)((2 * TH + 1) * 65) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16);
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  const long long tiles = (long long)p.N * (p.Hl / TH) * (p.Wl / 32) * (p.Ncols / BN);
+  auto kern = conv_patch_b16_kernel<BN, WM, WN, TH, true, true, false, true, false, 2>;
+  UNET_SET_DYN_LDS(kern, lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  UNET_CHECK_LAUNCH("conv_patch_b16(stride 2)");
+  return UNET_OK;
+}
+int launch_patch_s2_b16_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
+  static const bool off = [] { const char* e = getenv("UNET_B16_S2_PATCH"); return e && e[0] == '0'; }();
+  IgemmParams p = p0;
+  if (off || !p.w3 || !patch_s2_applicable(p) || p.C0 % 32 || p.C1 % 32 || (p.ldo & 7) ||
+      (reinterpret_cast<uintptr_t>(p.out) & 15))
+    return 1;
+  const long long mt = (long long)p.N * p.Hl * p.Wl / 128;
+  const int nc = p.Ncols;
+  if (nc % 64 == 0 && mt * (nc / 64) >= 512) {
+    *stats_px = p.stats ? 128 : 0;
+    p.stats_tiles = p.Hl * p.Wl / 128;
+    p.bs_partial = nullptr;
+    return launch_patch_b16_s2_t<64, 64, 32, 4>(p, stream);
+  }
+  return 1;
+}
+
 int launch_patch_s2_auto(const IgemmParams& p0, hipStream_t stream, int* stats_px) {
   IgemmParams p = p0;
   const long long mt = (long long)p.N * p.Hl * p.Wl / 128;
