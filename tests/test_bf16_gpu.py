@@ -175,6 +175,13 @@ def test_conv3x3_bwd_data_b16(ua, case):
     dx = ua.ops.conv3x3_bwd_data(to_nhwc_b16(dy), wd, 0, Cin, H, W, stride)
     assert dx.dtype == BF
     check(from_nhwc(dx), xz.grad, 6e-3, "dx")
+    # the same with the pack's pre-rounded bf16 plane (what the network passes): the kernels take
+    # their panels from it without conversion, two register sets in flight - bit-identical
+    table = ua.ops.PackTable([w.to(DEV)], 1, None)
+    table.run()
+    dx3 = ua.ops.conv3x3_bwd_data(to_nhwc_b16(dy), table.wd[0], 0, Cin, H, W, stride, bf16="bf16",
+                                  wd3=table.wd3[0])
+    assert torch.equal(dx3, dx)
 
 
 def test_instnorm_bwd_upsample_head_b16(ua):

@@ -1589,14 +1589,20 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_kernel(const Igemm
 // as a tap is only 2 x TM x TN MFMAs at the bf16 rate - three taps (three weight panels staged
 // together) per barrier.  Replaces sixteen per-class gather-GEMM launches per step.
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TH>
+template <int BN, int WM, int WN, int TH, bool WB = false>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const IgemmParams p) {
   constexpr int BK = 32, LDA = BK + 8;
   constexpr int TW = 32, PW = TW + 1, PH = TH + 1;
   constexpr int PPIX = PH * PW;
   constexpr int P_SLOTS = PPIX * 8;          // 4-channel slots
   constexpr int P_PASSES = (P_SLOTS + 255) / 256;
-  constexpr int B_SLOTS = 3 * BN * 8, B_PASSES = (B_SLOTS + 255) / 256;
+  // WB (round 4): the weights pre-rounded to bf16 (p.w3): 8-channel slots, no conversion, and TWO
+  // panel register sets - the panel of step s + 2 is in flight while that of s + 1 waits for its
+  // LDS stage (with one set every step waited for the panel it had just asked for: matrix pipes
+  // 6-9 % busy, waves waiting 61-72 % of their cycles)
+  constexpr int B_SEGS = WB ? 4 : 8;
+  constexpr int B_SETS = WB ? 2 : 1;
+  constexpr int B_SLOTS = 3 * BN * B_SEGS, B_PASSES = (B_SLOTS + 255) / 256;
   constexpr int B_TILE = 3 * BN * LDA;       // three taps per step
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -1621,7 +1627,9 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
 
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.src0), 0, (int)p.src0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+  const __amdgpu_buffer_rsrc_t rsw = WB ? __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(p.w3), 0, (int)p.w3_bytes, 0x00020000)
+                                        : __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
   // per slot ONE register: the linear dy pixel, or -1 for a slot outside the grid / past the
@@ -1644,14 +1652,15 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
     const int slot = (tid + 256 * j) % B_SLOTS;
-    const int tr = slot / (BN * 8), rem = slot - tr * BN * 8;
-    const int row = rem >> 3, seg = rem & 7;
+    const int tr = slot / (BN * B_SEGS), rem = slot - tr * BN * B_SEGS;
+    const int row = rem / B_SEGS, seg = rem % B_SEGS;
     wslot_tap[j] = tr;
-    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * 4) * 4u;
-    wslot_lds[j] = (tr * BN + row) * LDA + seg * 4;
+    wslot_off[j] = (unsigned)((p.n_off + n0 + row) * Ktot + seg * (32 / B_SEGS)) * (WB ? 2u : 4u);
+    wslot_lds[j] = (tr * BN + row) * LDA + seg * (32 / B_SEGS);
   }
 
-  f32x4 pr[P_PASSES], rb[B_PASSES];
+  i32x2r pr[P_PASSES];           // raw bf16 (a plain operand goes to LDS as it came)
+  f32x4 rb[B_SETS][B_PASSES];
   f32x16 acc[4][TM][TN];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1671,87 +1680,114 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_patch_b16_kernel(const I
   auto load_patch = [&](int chunk, bool dead = false) {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i)
-      pr[i] = buf_ld4<__bf16>(rs0, (unsigned)(pp_lin[i] * Ktot + chunk * BK + seg4),
-                              (pp_lin[i] < 0 || dead) ? 0x80000000u : 0u);
+      pr[i] = buf_ld4_raw16(rs0, (unsigned)(pp_lin[i] * Ktot + chunk * BK + seg4),
+                            (pp_lin[i] < 0 || dead) ? 0x80000000u : 0u);
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < P_PASSES; ++i)
       if (256 * (i + 1) <= P_SLOTS || tid + 256 * i < P_SLOTS)
-        *reinterpret_cast<bf16x4*>(Ps + pp_lds0 + i * 32 * LDA) = to_bf16(pr[i]);
+        *reinterpret_cast<i32x2r*>(Ps + pp_lds0 + i * 32 * LDA) = pr[i];
   };
-  auto load_b = [&](auto step_tag, int chunk) {   // the three taps 3*step .. 3*step+2
+  auto load_b = [&](auto step_tag, int chunk, auto setc) {   // the three taps 3*step .. 3*step+2
     constexpr int st = decltype(step_tag)::value;
+    constexpr int SET = decltype(setc)::value;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const int wt = wslot_tap[j] == 0 ? kS2PTaps[3 * st].ky * 3 + kS2PTaps[3 * st].kx
                    : wslot_tap[j] == 1 ? kS2PTaps[3 * st + 1].ky * 3 + kS2PTaps[3 * st + 1].kx
                                        : kS2PTaps[3 * st + 2].ky * 3 + kS2PTaps[3 * st + 2].kx;
-      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * 4u;
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rsw, wslot_off[j] + woff, 0, 0));
+      const unsigned woff = (unsigned)(wt * p.tap_stride + chunk * BK) * (WB ? 2u : 4u);
+      rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rsw, wslot_off[j] + woff, 0, 0));
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, auto setc) {
+    constexpr int SET = decltype(setc)::value;
     __bf16* Bb = Bs + buf * B_TILE;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j)
-      if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS)
-        *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[j]);
+      if (256 * (j + 1) <= B_SLOTS || tid + 256 * j < B_SLOTS) {
+        if constexpr (WB) *reinterpret_cast<f32x4*>(Bb + wslot_lds[j]) = rb[SET][j];   // 8 bf16
+        else *reinterpret_cast<bf16x4*>(Bb + wslot_lds[j]) = to_bf16(rb[SET][j]);
+      }
   };
 
   const int chunks = Ktot / BK;
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
   load_patch(0);
-  load_b(std::integral_constant<int, 0>{}, 0);
+  load_b(C0{}, 0, C0{});
+  if constexpr (B_SETS == 2) load_b(C1{}, 0, C1{});
   store_patch();
-  store_b(0);
+  store_b(0, C0{});
   __syncthreads();
 
   const int a_lane = (wrow0 * PW + li) * LDA + 8 * lh;
   const int b_lane = (wn0 + li) * LDA + 8 * lh;
-  for (int chunk = 0; chunk < chunks; ++chunk) {
-    const bool more_chunks = chunk + 1 < chunks;   // (the last chunk stages no patch)
-    const int chunk_n = more_chunks ? chunk + 1 : chunk;
-    for_range_p<0, 3>([&](auto sc) {
-      constexpr int st = decltype(sc)::value;
-      constexpr int st1 = st == 2 ? 0 : st + 1;
-      const int buf = (chunk + st) & 1;   // step = 3 * chunk + st
-      load_b(std::integral_constant<int, st1>{}, st == 2 ? chunk_n : chunk);
-      if (st == 0) load_patch(chunk_n, !more_chunks);
+  // one K step (three taps, their output classes compile-time values); PH = s & 1 = the LDS stage
+  // it reads and the register set that receives its panel load.  Two sets alternate with period
+  // two, the steps of a chunk with period three: the loop body is two chunks (six steps) with a
+  // three-step tail, every load unconditional (`dead` patch loads in the last chunk).
+  auto dstep = [&](auto sc, auto phc, int chunk) __attribute__((always_inline)) {
+    constexpr int st = decltype(sc)::value, PH = decltype(phc)::value;
+    using LOADSET = std::integral_constant<int, B_SETS == 2 ? PH : 0>;
+    using STORESET = std::integral_constant<int, B_SETS == 2 ? 1 - PH : 0>;
+    constexpr int DIST = B_SETS == 2 ? 2 : 1;
+    const bool more_chunks = chunk + 1 < chunks;
+    const int buf = B_SETS == 2 ? PH : ((chunk + st) & 1);   // step = 3 * chunk + st
+    {
+      constexpr int stn = (st + DIST) % 3;
+      const int chunkn = chunk + (st + DIST) / 3;
+      load_b(std::integral_constant<int, stn>{}, chunkn < chunks ? chunkn : chunks - 1, LOADSET{});
+    }
+    if constexpr (st == 0) load_patch(more_chunks ? chunk + 1 : chunk, !more_chunks);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        constexpr S2PTap T0 = kS2PTaps[3 * st], T1 = kS2PTaps[3 * st + 1], T2 = kS2PTaps[3 * st + 2];
-        const S2PTap T = j == 0 ? T0 : (j == 1 ? T1 : T2);
-        const __bf16* Ab = Ps + a_lane + (T.oy * PW + T.ox) * LDA;
-        const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
+    for (int j = 0; j < 3; ++j) {
+      constexpr S2PTap T0 = kS2PTaps[3 * st], T1 = kS2PTaps[3 * st + 1], T2 = kS2PTaps[3 * st + 2];
+      const S2PTap T = j == 0 ? T0 : (j == 1 ? T1 : T2);
+      const __bf16* Ab = Ps + a_lane + (T.oy * PW + T.ox) * LDA;
+      const __bf16* Bb = Bs + buf * B_TILE + j * BN * LDA + b_lane;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 a[TM], b[TN];
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 a[TM], b[TN];
 #pragma unroll
-          for (int m = 0; m < TM; ++m)
-            a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
+        for (int m = 0; m < TM; ++m)
+          a[m] = *reinterpret_cast<const bf16x8*>(Ab + m * PW * LDA + kk * 16);
 #pragma unroll
-          for (int nb = 0; nb < TN; ++nb)
-            b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
+        for (int nb = 0; nb < TN; ++nb)
+          b[nb] = *reinterpret_cast<const bf16x8*>(Bb + nb * 32 * LDA + kk * 16);
 #pragma unroll
-          for (int m = 0; m < TM; ++m)
+        for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int nb = 0; nb < TN; ++nb) {
-              // T.cls is a compile-time value once j is unrolled
-              if (T.cls == 0) acc[0][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[0][m][nb], 0, 0, 0);
-              else if (T.cls == 1) acc[1][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[1][m][nb], 0, 0, 0);
-              else if (T.cls == 2) acc[2][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[2][m][nb], 0, 0, 0);
-              else acc[3][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[3][m][nb], 0, 0, 0);
-            }
-        }
+          for (int nb = 0; nb < TN; ++nb) {
+            // T.cls is a compile-time value once j is unrolled
+            if (T.cls == 0) acc[0][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[0][m][nb], 0, 0, 0);
+            else if (T.cls == 1) acc[1][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[1][m][nb], 0, 0, 0);
+            else if (T.cls == 2) acc[2][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[2][m][nb], 0, 0, 0);
+            else acc[3][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[nb], acc[3][m][nb], 0, 0, 0);
+          }
       }
-      store_b(buf ^ 1);
-      if (st == 2 && more_chunks) {   // every wave is done with this chunk's patch
+    }
+    store_b(buf ^ 1, STORESET{});
+    if constexpr (st == 2) {
+      if (more_chunks) {   // uniform; every wave is done with this chunk's patch
         __syncthreads();
         store_patch();
       }
-      __syncthreads();
-    });
+    }
+    __syncthreads();
+  };
+  if constexpr (B_SETS == 2) {
+    int c = 0;
+    for (; c + 2 <= chunks; c += 2) {
+      dstep(C0{}, C0{}, c); dstep(C1{}, C1{}, c); dstep(C2{}, C0{}, c);
+      dstep(C0{}, C1{}, c + 1); dstep(C1{}, C0{}, c + 1); dstep(C2{}, C1{}, c + 1);
+    }
+    if (c < chunks) { dstep(C0{}, C0{}, c); dstep(C1{}, C1{}, c); dstep(C2{}, C0{}, c); }
+  } else {
+    for (int c = 0; c < chunks; ++c) { dstep(C0{}, C0{}, c); dstep(C1{}, C0{}, c); dstep(C2{}, C0{}, c); }
   }
 
   // ---- epilogue: class c -> dx pixel (2a + c/2, 2b + c%2), column li; BSTATS (uniform
@@ -2174,10 +2210,17 @@ int launch_dgrad_s2_patch(const IgemmParams& p, hipStream_t stream) {
 template <int BN, int WM, int WN, int TH>
 int launch_dgrad_s2_patch_b16(const IgemmParams& p, hipStream_t stream) {
   constexpr size_t lds = ((size_t)((TH + 1) * 33) * 40 + 2 * 3 * (size_t)BN * 40) * sizeof(__bf16);
-  auto kern = conv_dgrad_s2_patch_b16_kernel<BN, WM, WN, TH>;
-  UNET_SET_DYN_LDS(kern, lds);
   const long long tiles = (long long)p.N * (p.Hl / TH) * (p.Wl / 32) * (p.Ncols / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  static const bool one_set = [] { const char* e = getenv("UNET_B16_S2_DGRAD_WB"); return e && e[0] == '0'; }();
+  if (p.w3 && !one_set) {   // the weights pre-rounded to bf16: two panel sets
+    auto kern = conv_dgrad_s2_patch_b16_kernel<BN, WM, WN, TH, true>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  } else {
+    auto kern = conv_dgrad_s2_patch_b16_kernel<BN, WM, WN, TH, false>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  }
   UNET_CHECK_LAUNCH("conv_dgrad_s2_patch_b16");
   return UNET_OK;
 }
