@@ -94,7 +94,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
   const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  f32x4 ra[A_PASSES], rb[B_PASSES];
+  // NSET = 2 (the data-gradient forms, round 4): the tiles of step k + 2 are in flight while
+  // those of k + 1 wait for their LDS stage; with one set every step waited for the loads it had
+  // just issued - 8 MFMAs a step against an L2 round trip.  (The fused forward keeps one set: its
+  // per-row activation coefficients would double with the tiles.)
+  constexpr int NSET = FUSED ? 1 : 2;
+  f32x4 ra[NSET][A_PASSES], rb[NSET][B_PASSES];
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
   float cs = 1.f;
   unsigned okm = 0;
 
-  auto load_tiles = [&](int t, int chunk) {
+  auto load_tiles = [&](int t, int chunk, auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
     const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
@@ -147,14 +153,14 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
       const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
       if (FUSED) okm |= (ok ? 1u : 0u) << i;
       // invalid lanes get bit 31 set: beyond num_records (< 2 GiB), the load returns 0
-      ra[i] = buf_ld4<TS>(rs, (unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff),
-                          ok ? 0u : 0x80000000u);
+      ra[SET][i] = buf_ld4<TS>(rs, (unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff),
+                               ok ? 0u : 0x80000000u);
     }
     const unsigned woff = wrow_off + (unsigned)(wt * p.tap_stride + c) * 4u;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff + (unsigned)(ROWS * j * Ktot) * 4u, 0, 0);
-      rb[j] = __builtin_bit_cast(f32x4, v);
+      rb[SET][j] = __builtin_bit_cast(f32x4, v);
     }
   };
   auto to_bf16 = [](const f32x4 v) {
@@ -162,16 +168,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
     return h;
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
     __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
     __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      if (FUSED) ra[i] = act4(ra[i], ca[i], cb[i], cs, (okm >> i) & 1u);
-      *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[i]);
+      if (FUSED) ra[SET][i] = act4(ra[SET][i], ca[i], cb[i], cs, (okm >> i) & 1u);
+      *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[SET][i]);
     }
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<bf16x4*>(Bb + ROWS * j * LDA) = to_bf16(rb[j]);
+    for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<bf16x4*>(Bb + ROWS * j * LDA) = to_bf16(rb[SET][j]);
   };
 
   int t_next = 0, chunk_next = 0;
@@ -186,18 +193,25 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     chunk_next = on ? chunk_next + (wrap ? 1 : 0) : chunk_next;
   };
 
-  load_tiles(t_next, chunk_next);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSET - 1>;
+  load_tiles(t_next, chunk_next, S0{});
   advance(KS > 1);
-  store_tiles(0);
+  if constexpr (NSET == 2) {   // step 1's tiles (KS == 1: step 0's again, never stored)
+    load_tiles(t_next, chunk_next, S1{});
+    advance(KS > 2);
+  }
+  store_tiles(0, S0{});
   __syncthreads();
 
   // fragment addresses: lane (li, lh) reads the 8 consecutive k = 16*kk + 8*lh .. +7 of row li
   // (the natural A/B operand map of v_mfma_f32_32x32x16_bf16)
   const int frag_off = li * LDA + 8 * lh;
-  for (int ks = 0; ks < KS; ++ks) {
+  // one K step; LOADSET receives the tiles of step ks + NSET, STORESET holds those of ks + 1
+  auto k_step = [&](int ks, auto loadc, auto storec) __attribute__((always_inline)) {
     const int buf = ks & 1;
-    load_tiles(t_next, chunk_next);
-    advance(ks + 2 < KS);
+    load_tiles(t_next, chunk_next, loadc);           // (past the end: the last step's tiles again)
+    advance(ks + NSET + 1 < KS);
     const __bf16* Ab = As + buf * A_TILE + wm0 * LDA + frag_off;
     const __bf16* Bb = Bs + buf * B_TILE + wn0 * LDA + frag_off;
     bf16x8 a[2][TM], b[2][TN];
@@ -222,13 +236,21 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
         for (int n = 0; n < TN; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m], b[cur][n], acc[m][n], 0, 0, 0);
     }
-    store_tiles(buf ^ 1);
+    store_tiles(buf ^ 1, storec);
     // buffer loads first (they are the critical path here), fragment reads ahead of the MFMAs
     __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
     __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
     __syncthreads();
+  };
+  if constexpr (NSET == 2) {
+    for (int ks = 0; ks < KS; ks += 2) {
+      k_step(ks, S0{}, S1{});
+      if (ks + 1 < KS) k_step(ks + 1, S1{}, S0{});
+    }
+  } else {
+    for (int ks = 0; ks < KS; ++ks) k_step(ks, S0{}, S0{});
   }
 
   // the K loop ended on a barrier: every LDS stage is free scratch from here on
