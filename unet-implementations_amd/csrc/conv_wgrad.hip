@@ -543,35 +543,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const Wgrad
     d_lds[k] = ATILE + (t * TJ + (c8 >> 2)) * SUB + px * 32 + (c8 & 3) * 8;
   }
 
-  f32x4 ra[NLA], rdv[NLD];
-  f32x4 ca[NLA], cb[NLA];
-  unsigned okm = 0;
+  // two register sets (round 4): the segment after next is in flight while the next one waits
+  // for its LDS stage (with one set a step - nine MFMAs - waited for the loads it had just issued:
+  // matrix pipes 10 % busy)
+  // (the 32 x 32 tile's D segment is nine 16-byte slots a thread: one set there)
+  constexpr int NS = NLD <= 5 ? 2 : 1;
+  f32x4 ra[NS][NLA], rdv[NS][NLD];
+  f32x4 ca[NS][NLA], cb[NS][NLA];
+  unsigned okm[NS] = {};
   int lq0 = 0;   // first pixel of the segment being loaded
-  auto load_stage = [&]() {
-    okm = 0;
+  auto load_stage = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
+    okm[SET] = 0;
 #pragma unroll
     for (int k = 0; k < NLA; ++k) {
       const int q = lq0 + a_px[k];
       const bool ok = q < Q && (NA % NT == 0 || tid + NT * k < NA);
-      ra[k] = buf_ld4<__bf16>(rsx, (unsigned)(q * p.Cx + a_ch), ok ? 0u : 0x80000000u);
+      ra[SET][k] = buf_ld4<__bf16>(rsx, (unsigned)(q * p.Cx + a_ch), ok ? 0u : 0x80000000u);
       if (ACT) {
         const int n = ok ? q / HW : 0;
-        ca[k] = *reinterpret_cast<const f32x4*>(p.alpha + (size_t)n * p.Cx + a_ch);
-        cb[k] = *reinterpret_cast<const f32x4*>(p.beta + (size_t)n * p.Cx + a_ch);
-        okm |= (ok ? 1u : 0u) << k;
+        ca[SET][k] = *reinterpret_cast<const f32x4*>(p.alpha + (size_t)n * p.Cx + a_ch);
+        cb[SET][k] = *reinterpret_cast<const f32x4*>(p.beta + (size_t)n * p.Cx + a_ch);
+        okm[SET] |= (ok ? 1u : 0u) << k;
       }
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
-      rdv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                             rsd, d_off[k] + (unsigned)(lq0 * (9 * p.Cout)) * 2u, 0, 0));
+      rdv[SET][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rsd, d_off[k] + (unsigned)(lq0 * (9 * p.Cout)) * 2u, 0, 0));
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, auto setc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value;
     __bf16* base = smem_h + buf * STAGE;
 #pragma unroll
     for (int k = 0; k < NLA; ++k) {
-      f32x4 v = ra[k];
-      if (ACT) v = act4(v, ca[k], cb[k], p.slope, (okm >> k) & 1u);
+      f32x4 v = ra[SET][k];
+      if (ACT) v = act4(v, ca[SET][k], cb[SET][k], p.slope, (okm[SET] >> k) & 1u);
       bf16x4 h;
       h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
       if (NA % NT == 0 || tid + NT * k < NA) *reinterpret_cast<bf16x4*>(base + a_lds[k]) = h;
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const Wgrad
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
       if (NT * (k + 1) <= ND || tid + NT * k < ND)
-        *reinterpret_cast<f32x4*>(base + d_lds[k]) = rdv[k];
+        *reinterpret_cast<f32x4*>(base + d_lds[k]) = rdv[SET][k];
   };
 
   f32x16 acc[9];
@@ -589,9 +596,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const Wgrad
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if (g_begin < g_end) {
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NS - 1>;
     lq0 = g_begin * S;
-    load_stage();
-    store_stage(0);
+    load_stage(S0{});
+    if constexpr (NS == 2) {
+      if (g_begin + 1 < g_end) lq0 += S;   // (a range of one segment loads it twice: never stored)
+      load_stage(S1{});
+    }
+    store_stage(0, S0{});
     __syncthreads();
     const int tg = lane >> 4, th = tg >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
     const int tcol = 16 * (tg & 1) + 4 * tp;
@@ -601,10 +614,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const Wgrad
       const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * 32));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    for (int g = g_begin; g < g_end; ++g) {
+    // step g on stage (g - g_begin) & 1; LOADSET receives segment g + 2 (past the end: the last
+    // one again - every path issues the same loads), STORESET holds segment g + 1
+    auto seg_step = [&](int g, auto loadc, auto storec) __attribute__((always_inline)) {
       const int buf = (g - g_begin) & 1;
-      if (g + 1 < g_end) lq0 += S;   // the last iteration re-stages the final segment
-      load_stage();
+      if (g + NS < g_end) lq0 += S;
+      load_stage(loadc);
       const __bf16* A = smem_h + buf * STAGE + wi * SUB;
       const __bf16* D = smem_h + buf * STAGE + ATILE + wj * SUB;
 #pragma unroll
@@ -616,8 +631,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_b16_kernel(const Wgrad
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
               a, frag(D + t * TJ * SUB + r0 * 32 + tcol), acc[t], 0, 0, 0);
       }
-      store_stage(buf ^ 1);
+      store_stage(buf ^ 1, storec);
       __syncthreads();
+    };
+    if constexpr (NS == 2) {
+      for (int g = g_begin; g < g_end; g += 2) {
+        seg_step(g, S0{}, S1{});
+        if (g + 1 < g_end) seg_step(g + 1, S1{}, S0{});
+      }
+    } else {
+      for (int g = g_begin; g < g_end; ++g) seg_step(g, S0{}, S0{});
     }
   }
 
