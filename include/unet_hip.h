@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 7
+#define UNET_ABI_VERSION 8
 
 #define UNET_OK 0
 #define UNET_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -689,6 +689,14 @@ int unet_conv3x3_up_bwd_data_bs_b16(const uint16_t* D, const float* wd, int Cin_
                                     int ci_offset, uint16_t* g, int N, int h, int w, int Cout,
                                     int Ccols, int accumulate, unet_bwd_stats* bs,
                                     unet_stream_t stream);
+/* ... with the weights also pre-rounded to bf16 (wdb = [9][Cin_total][Cout] bf16, plane 0 of
+ * wd3; NULL = as above): the contraction runs as a plain bf16 GEMM over the 9 * Cout contiguous
+ * values of a D row (64-wide K steps, no conversion of the weights).  Same result as the form
+ * above up to the summation order of the fp32 accumulators; bs may be NULL. */
+int unet_conv3x3_up_bwd_data_bs_b16_wb(const uint16_t* D, const float* wd, const uint16_t* wdb,
+                                       int Cin_total, int ci_offset, uint16_t* g, int N, int h,
+                                       int w, int Cout, int Ccols, int accumulate,
+                                       unet_bwd_stats* bs, unet_stream_t stream);
 int unet_head1x1_in_fwd_b16(const unet_act_src* x, float slope, const float* w, const float* b,
                             float* logits_nchw, int N, int HW, int K, unet_stream_t stream);
 int unet_head1x1_in_bwd_b16(const unet_act_src* x, float slope, const float* dlogits_nchw,

@@ -277,6 +277,65 @@ def test_up_backward_b16(ua, case):
         check(outs[0][2], outs[1][2], 3e-3, "dbeta")
 
 
+@pytest.mark.parametrize("case", [
+    (8, 64, 64, 128, 64, 0, False),     # K = 576, two column tiles
+    (2, 128, 128, 64, 32, 0, False),    # K = 288: steps straddle taps, ragged last step
+    (8, 16, 16, 128, 256, 0, False),    # four K groups per tile (64 tiles), K = 2304
+    (8, 32, 32, 256, 128, 64, True),    # a column slice of a wider layer, accumulating
+    (8, 16, 16, 512, 512, 0, False),    # the 1/32-resolution stage of the network: K = 4608
+    (1, 8, 8, 64, 64, 0, False),        # one tile
+    (1, 6, 6, 64, 64, 0, False),        # M % 64 != 0: the gather form runs (same entry point)
+])
+def test_up_backward_data_b16_plain_gemm(ua, case):
+    """unet_conv3x3_up_bwd_data_bs_b16_wb (round 4): the low-resolution data gradient of the
+    up-sampled operand as a plain bf16 GEMM over the 9 * Cout contiguous values of a D row
+    (conv_igemm_bf16_kernel<.., DENSE>; weights from their bf16 plane).  Held to the same GEMM in
+    fp64 on the SAME bf16 operands (D and the rounded weights), so only the fp32 accumulation and
+    the final rounding differ; to the gather form of test_up_backward_b16 (which is held to
+    autograd there); and the BSTATS epilogue must leave the same bits and usable summaries."""
+    N, h, w, Cx, Cout, off, acc = case
+    ctot = Cx + off + (32 if off else 0)
+    wt = rnd(Cout, ctot, 3, 3, seed=3, scale=(2.0 / (9 * Cout)) ** 0.5).to(DEV)
+    table = ua.ops.PackTable([wt], True, None)
+    table.run()
+    wd, wd3 = table.wd[0], table.wd3[0]
+    D = r16(rnd(N, h, w, 9 * Cout, seed=5)).to(DEV).to(BF)
+    g0 = r16(rnd(N, h, w, Cx, seed=6)).to(DEV).to(BF) if acc else None
+    g = ua.ops.conv3x3_up_bwd_data(D, wd, off, Cx, out=g0.clone() if acc else None,
+                                   accumulate=acc, wd3=wd3)
+    assert g.dtype == BF and g.shape == (N, h, w, Cx)
+    # fp64 GEMM on the bf16 operands: B[t * Cout + co][ci] = bf16(w[co][off + ci][t])
+    wb = wt.to(BF).double()[:, off:off + Cx].permute(2, 3, 0, 1).reshape(9 * Cout, Cx)
+    ref = D.double().reshape(-1, 9 * Cout) @ wb
+    if acc:
+        ref = ref + g0.double().reshape(-1, Cx)
+    err = (g.double().reshape(-1, Cx) - ref).abs().max().item()
+    assert err <= 2.0 ** -8 * ref.abs().max().item() + 1e-6, err    # one bf16 rounding of the result
+    old = ua.ops.conv3x3_up_bwd_data(D, wd, off, Cx, out=g0.clone() if acc else None,
+                                     accumulate=acc)
+    check(g.float().cpu(), old.float().cpu(), 8e-3, "plain GEMM vs gather form")
+    if (h * w) % 64 == 0 and not acc:
+        yl = r16(rnd(N, h, w, Cx, seed=20) * 1.5 + 0.3).to(DEV).to(BF)
+        gamma = (rnd(Cx, seed=21) * 0.2 + 1.0).to(DEV)
+        beta = (rnd(Cx, seed=22) * 0.2).to(DEV)
+        yf = yl.float()
+        mean = yf.mean(dim=(1, 2))
+        rstd = 1.0 / torch.sqrt(yf.var(dim=(1, 2), unbiased=False) + 1e-5)
+        st = torch.stack([mean, rstd, torch.zeros_like(mean), torch.zeros_like(mean)]).contiguous()
+        nn = ua.ops.NextNorm(yl, st, gamma, beta, None, SLOPE)
+        g2 = ua.ops.conv3x3_up_bwd_data(D, wd, off, Cx, nxt=nn, wd3=wd3)
+        assert torch.equal(g2, g) and nn.tiles > 0
+        outs = []
+        for partials in ((nn.partial, nn.tiles), None):
+            dg, db, dbias = (torch.empty(Cx, device=DEV) for _ in range(3))
+            dz = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), yl, st[0], st[1], gamma, beta, None,
+                                                SLOPE, dg, db, dbias, partials=partials)
+            outs.append((dz.float(), dg, db))
+        check(outs[0][0], outs[1][0], 8e-3, "dz")
+        check(outs[0][1], outs[1][1], 3e-3, "dgamma")
+        check(outs[0][2], outs[1][2], 3e-3, "dbeta")
+
+
 @pytest.mark.parametrize("case", [(8, 256, 256, 64, 32, 32, True), (8, 32, 32, 512, 512, 512, True),
                                   (2, 128, 128, 256, 128, 128, True), (4, 256, 256, 128, 64, 64, True),
                                   (1, 256, 256, 128, 64, 64, True), (2, 16, 32, 64, 64, 64, False)])

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(_HERE, "libunet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 7      # UNET_ABI_VERSION of include/unet_hip.h this binding was written against
+ABI_VERSION = 8      # UNET_ABI_VERSION of include/unet_hip.h this binding was written against
 
 _c = ctypes
 _p = _c.c_void_p
@@ -164,6 +164,8 @@ SIGNATURES = {
                                      _i, _p]),
     "unet_conv3x3_up_bwd_data_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_conv3x3_up_bwd_data_bs_b16": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _pbs, _p]),
+    "unet_conv3x3_up_bwd_data_bs_b16_wb": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _pbs,
+                                           _p]),
     "unet_head1x1_in_fwd_b16": (_i, [_ps, _f, _p, _p, _p, _i, _i, _i, _p]),
     "unet_head1x1_in_bwd_b16": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _p]),
     "unet_upsample2x_bwd_taps": (_i, [_p, _p, _i, _i, _i, _i, _p]),

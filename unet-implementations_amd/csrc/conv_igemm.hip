@@ -1840,7 +1840,7 @@ static int conv_in_stats_finalize_impl(const float* y, void* workspace, size_t w
 static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
                                     float* g, int N, int h, int w, int Cout, int Ccols,
                                     int accumulate, unet_stream_t stream, int b16,
-                                    unet_bwd_stats* bs = nullptr);
+                                    unet_bwd_stats* bs = nullptr, const uint16_t* wdb = nullptr);
 
 extern "C" int unet_conv3x3_up_bwd_data_bs(const float* D, const float* wd, int Cin_total,
                                            int ci_offset, float* g, int N, int h, int w, int Cout,
@@ -1866,6 +1866,18 @@ extern "C" int unet_conv3x3_up_bwd_data_b16(const uint16_t* D, const float* wd, 
                                   stream, 1);
 }
 
+// wdb = the data-gradient weights pre-rounded to bf16 ([9][Cin_total][Cout], plane 0 of the
+// pack's wd3): a plain bf16 GEMM over the 9 * Cout contiguous values of a D row.  bs may be null.
+extern "C" int unet_conv3x3_up_bwd_data_bs_b16_wb(const uint16_t* D, const float* wd,
+                                                  const uint16_t* wdb, int Cin_total,
+                                                  int ci_offset, uint16_t* g, int N, int h, int w,
+                                                  int Cout, int Ccols, int accumulate,
+                                                  unet_bwd_stats* bs, unet_stream_t stream) {
+  return conv3x3_up_bwd_data_impl(reinterpret_cast<const float*>(D), wd, Cin_total, ci_offset,
+                                  reinterpret_cast<float*>(g), N, h, w, Cout, Ccols, accumulate,
+                                  stream, 1, bs, wdb);
+}
+
 // the same with the BSTATS epilogue: g is final for the layer described by bs (bs->y bf16)
 extern "C" int unet_conv3x3_up_bwd_data_bs_b16(const uint16_t* D, const float* wd, int Cin_total,
                                                int ci_offset, uint16_t* g, int N, int h, int w,
@@ -1879,7 +1891,7 @@ extern "C" int unet_conv3x3_up_bwd_data_bs_b16(const uint16_t* D, const float* w
 static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_total, int ci_offset,
                                     float* g, int N, int h, int w, int Cout, int Ccols,
                                     int accumulate, unet_stream_t stream, int b16,
-                                    unet_bwd_stats* bs) {
+                                    unet_bwd_stats* bs, const uint16_t* wdb) {
   const long long es = b16 ? 2 : 4;
   if (bs) bs->tiles_out = 0;
   const bool use_bs = bs && bs->y && bs->mean && bs->rstd && bs->gamma && bs->beta &&
@@ -1903,7 +1915,7 @@ static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_tot
                                            (size_t)nb * h * w * 9 * Cout * es),
             wd, Cin_total, ci_offset,
             reinterpret_cast<float*>(reinterpret_cast<char*>(g) + (size_t)nb * h * w * Ccols * es),
-            n, h, w, Cout, Ccols, accumulate, stream, b16);
+            n, h, w, Cout, Ccols, accumulate, stream, b16, nullptr, wdb);
         if (rc != UNET_OK) return rc;
       }
       return UNET_OK;
@@ -1911,6 +1923,11 @@ static int conv3x3_up_bwd_data_impl(const float* D, const float* wd, int Cin_tot
   }
   IgemmParams p{};
   p.src0 = D; p.src1 = nullptr; p.C0 = Cout; p.C1 = 0;
+  if (b16 && wdb) {   // the weights pre-rounded to bf16: the plain-GEMM form (conv_lowp.hip)
+    p.w3 = reinterpret_cast<const __bf16*>(wdb);
+    p.w3_plane = 9 * Cout * Cin_total;
+    p.w3_bytes = (unsigned)((long long)p.w3_plane * 2);
+  }
   p.src0_pitch = 9 * Cout; p.tap_cstride = Cout;
   p.w = wd; p.tap_stride = Cin_total * Cout; p.n_off = ci_offset; p.bias = nullptr;
   p.src0_bytes = (unsigned)((long long)N * h * w * 9 * Cout * es);

@@ -27,12 +27,21 @@ namespace {
 // !FUSED with p.bs_partial: the BSTATS epilogue (the output is FINAL for the layer behind it:
 // per-tile sums of that layer's InstanceNorm backward, from the fp32 accumulators and the stored
 // raw outputs y) - as conv_igemm_kernel / conv_patch_b16_kernel.
+// DENSE (round 4; the low-resolution data gradient of the up-sampled operand, "channel taps":
+// A row m = the 9 * C0 contiguous bf16 of D[m][tap][c], every row valid, no geometry): the
+// contraction is a plain GEMM over K = 9 * C0, so the K step is 64 wide - a whole 128-byte line
+// of every A row per step instead of half of one (the other half came back eight steps later,
+// from L2 or further), 16-byte loads on both operands, the weights from their bf16 plane (p.w3,
+// no conversion, half the L2 traffic), half the barriers.  A K step may straddle taps (C0 = 32)
+// and the last one may be ragged (9 * 32 = 4.5 steps): lanes past K read zeros.
 template <int BM, int BN, int WM, int WN, typename TS = float, typename TO = float,
-          bool FUSED = false, int KG = 1>
+          bool FUSED = false, int KG = 1, bool DENSE = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_kernel(const IgemmParams p) {
-  constexpr int BK = 32;
+  static_assert(!DENSE || (!FUSED && sizeof(TS) == 2), "DENSE: bf16 rows, plain GEMM");
+  constexpr int BK = DENSE ? 64 : 32;
   constexpr int LDA = BK + 8;  // bf16 elements per LDS row
-  constexpr int SEGS = BK / 4;         // 16-B segments per tile row
+  constexpr int EPS = DENSE ? 8 : 4;   // elements per loader segment
+  constexpr int SEGS = BK / EPS;       // loader segments per tile row
   constexpr int ROWS = 256 / SEGS;     // tile rows covered by one loader pass
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -92,6 +101,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
       const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
   // weight rows of this thread: ((n_off + n0 + lrow + 32*j) * Ktot + lseg*4) floats
   const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
+  // DENSE: the bf16 weight plane; A rows by byte offset (pitch = 9 * C0 elements)
+  const __amdgpu_buffer_rsrc_t rsw3 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(DENSE ? p.w3 : nullptr), 0, DENSE ? (int)p.w3_bytes : 0, 0x00020000);
+  const int Kd = 9 * p.C0;                          // DENSE: the GEMM's K
+  const int c0_log2 = __builtin_ctz((unsigned)p.C0);   // (launcher: C0 is a power of two)
+  unsigned a_off[DENSE ? A_PASSES : 1];
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      a_off[i] = (unsigned)((m0 + lrow + ROWS * i) * Kd + lseg * 8) * 2u;
+  }
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   // NSET = 2 (the data-gradient forms, round 4): the tiles of step k + 2 are in flight while
@@ -108,7 +128,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const int KS = p.ntaps * (Ktot / BK) / KG;   // K steps of this group (the launcher checks % KG)
+  // K steps of this group (the launcher checks % KG)
+  const int KS = DENSE ? ((Kd + BK - 1) / BK) / KG : p.ntaps * (Ktot / BK) / KG;
   constexpr int CP = FUSED ? A_PASSES : 1;
   f32x4 ca[CP], cb[CP];
   float cs = 1.f;
@@ -116,6 +137,22 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
 
   auto load_tiles = [&](int t, int chunk, auto setc) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
+    if constexpr (DENSE) {   // `chunk` = the K step (t unused): k = chunk * 64 + lseg * 8 ..+7
+      const int k = chunk * BK + lseg * 8;
+      const unsigned kill = k < Kd ? 0u : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i)
+        ra[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs0, a_off[i] | kill, (unsigned)(chunk * BK) * 2u, 0));
+      const int tap = k >> c0_log2;
+      const unsigned woff =
+          (unsigned)(tap * p.tap_stride + (p.n_off + n0 + lrow) * Ktot + (k - (tap << c0_log2))) * 2u | kill;
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j)
+        rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsw3, woff + (unsigned)(ROWS * j * Ktot) * 2u, 0, 0));
+      return;
+    }
     const unsigned tw = (t < 4) ? p.tapw[0] : (t < 8 ? p.tapw[1] : p.tapw[2]);
     const unsigned e = (tw >> ((t & 3) * 8)) & 0xffu;
     const int oy = (int)(e & 3u) - 1, ox = (int)((e >> 2) & 3u) - 1;
@@ -170,8 +207,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
   };
   auto store_tiles = [&](int buf, auto setc) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value;
-    __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * 4;
-    __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * 4;
+    __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * EPS;
+    __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * EPS;
+    if constexpr (DENSE) {   // raw bf16 bits, 16 bytes a lane
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[SET][i];
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + ROWS * j * LDA) = rb[SET][j];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       if (FUSED) ra[SET][i] = act4(ra[SET][i], ca[i], cb[i], cs, (okm >> i) & 1u);
@@ -186,7 +230,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     chunk_next = grp * KS / p.ntaps;
     t_next = grp * KS - chunk_next * p.ntaps;
   }
+  if constexpr (DENSE) { t_next = 0; chunk_next = grp * KS; }   // chunk_next = the K step
   auto advance = [&](bool on) {  // branch-free: keeps the K step a single basic block
+    if constexpr (DENSE) { chunk_next += on ? 1 : 0; return; }
     const int tn = t_next + 1;
     const bool wrap = tn == p.ntaps;
     t_next = on ? (wrap ? 0 : tn) : t_next;
@@ -239,8 +285,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     store_tiles(buf ^ 1, storec);
     // buffer loads first (they are the critical path here), fragment reads ahead of the MFMAs
     __builtin_amdgcn_sched_group_barrier(0x020, A_PASSES + B_PASSES, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, (BK / 16) * (TM + TN), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (BK / 16) * TM * TN, 0);
     __builtin_amdgcn_sched_group_barrier(0x200, A_PASSES + B_PASSES, 0);
     __syncthreads();
   };
@@ -613,13 +659,24 @@ int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
 // bf16 STORAGE (the real mixed-precision pipeline): sources and output are bf16 tensors.
 // stats_px: the fused-layer forward (statistics epilogue where every tile lies in one image);
 // bs_px: a data gradient whose output is final for a layer (BSTATS epilogue, same condition).
-template <int BM, int BN, int WM, int WN, int KG = 1>
+template <int BM, int BN, int WM, int WN, int KG = 1, bool DENSE = false>
 int launch_igemm_b16(IgemmParams p, hipStream_t stream, int* stats_px, int* bs_px = nullptr) {
-  constexpr size_t lds = KG * 2 * (size_t)(BM + BN) * 40 * sizeof(__bf16);
+  constexpr size_t lds = KG * 2 * (size_t)(BM + BN) * (DENSE ? 72 : 40) * sizeof(__bf16);
   static_assert(lds <= 160 * 1024, "LDS stages of every K group fit one CU");
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
   const int HlWl = p.Hl * p.Wl;
+  if constexpr (DENSE) {
+    if (bs_px && p.bs_partial && HlWl % BM == 0 && M % BM == 0) {
+      *bs_px = BM; p.bs_tiles = HlWl / BM * (p.sout * p.sout);
+    } else {
+      if (bs_px) *bs_px = 0;
+      p.bs_partial = nullptr;
+    }
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, false, KG, true>;
+    UNET_SET_DYN_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KG), lds, stream, p);
+  } else
   if (stats_px) {   // fused layer forward
     const bool direct = p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout;
     if (direct && p.stats && HlWl % BM == 0) { *stats_px = BM; p.stats_tiles = HlWl / BM; }
@@ -692,6 +749,20 @@ int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px, 
   if (stats_px && !bs_px) {   // the stride-2 fused forward: its own patch form (conv_patch.hip)
     const int rc = launch_patch_s2_b16_auto(p, stream, stats_px);
     if (rc != 1) return rc;
+  }
+  // "channel taps" on contiguous rows with the bf16 weight plane: the plain-GEMM (DENSE) form.
+  // 64 x 64 tiles throughout - four workgroups per CU (37 KB of LDS, 94 registers): the K loop
+  // is 5..72 steps short and what hides its prologue, epilogue and load latency is the other
+  // workgroups of the CU (measured against 128 x 128 / 128 x 64 tiles at two per CU: 72 -> 60 us
+  // at K = 576, 202 -> 140 at K = 288; profiles/r04_bf16_experiments.txt); four K groups per
+  // tile where the tiles do not fill the chip.
+  static const bool dense_off = [] { const char* e = getenv("UNET_B16_DENSE_TAPS"); return e && e[0] == '0'; }();
+  if (!dense_off && !stats_px && p.w3 && p.tap_cstride == p.C0 && p.src0_pitch == 9 * p.C0 &&
+      p.C1 == 0 && p.ntaps == 9 && (p.C0 & (p.C0 - 1)) == 0 && p.C0 >= 32 && p.sin == 1 &&
+      p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout && M % 64 == 0 && nc % 64 == 0) {
+    if ((M / 64) * (nc / 64) <= 256 && (9 * p.C0) % 256 == 0)
+      return launch_igemm_b16<64, 64, 32, 32, 4, true>(p, stream, nullptr, bs_px);
+    return launch_igemm_b16<64, 64, 32, 32, 1, true>(p, stream, nullptr, bs_px);
   }
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
     return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px, bs_px);

@@ -940,9 +940,10 @@ def conv3x3_up_bwd_weight(x, slope, D, dw_oihw, ci_offset):
     return dw_oihw
 
 
-def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False, nxt=None):
+def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False, nxt=None, wd3=None):
     """g[N, h, w, ccols] (+)= dL/d(low-res operand) of conv3x3(upsample2x(.)) from D.
-    nxt (NextNorm): g is final for that layer - also emit its backward reductions."""
+    nxt (NextNorm): g is final for that layer - also emit its backward reductions.
+    wd3 (bf16 tensors only): the data-gradient weights pre-rounded to bf16 (plain-GEMM form)."""
     N, h, w, C9 = D.shape
     Cout = C9 // 9
     cin_total = wd.shape[1]
@@ -951,7 +952,14 @@ def conv3x3_up_bwd_data(D, wd, ci_offset, ccols, out=None, accumulate=False, nxt
     g = out if out is not None else (_b16 if b16 else _f32)((N, h, w, ccols), D)
     fn = lib().unet_conv3x3_up_bwd_data_b16 if b16 else lib().unet_conv3x3_up_bwd_data
     t0 = _timer.begin("conv") if _timer is not None else None
-    if nxt is not None:
+    if b16 and wd3 is not None:
+        bs = nxt.c_struct() if nxt is not None else None
+        check(lib().unet_conv3x3_up_bwd_data_bs_b16_wb(
+            _ptr(D), _ptr(wd), _ptr(wd3), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,
+            1 if accumulate else 0, ctypes.byref(bs) if bs is not None else None, _stream()))
+        if nxt is not None:
+            nxt.tiles = bs.tiles_out
+    elif nxt is not None:
         bs = nxt.c_struct()
         fbs = lib().unet_conv3x3_up_bwd_data_bs_b16 if b16 else lib().unet_conv3x3_up_bwd_data_bs
         check(fbs(_ptr(D), _ptr(wd), cin_total, ci_offset, _ptr(g), N, h, w, Cout, ccols,

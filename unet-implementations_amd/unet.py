@@ -967,7 +967,9 @@ class _UNetFunction(torch.autograd.Function):
                 if want_dw:
                     ops.conv3x3_up_bwd_weight(low, slope, D, dw, 0)
                     ops.conv_in_bwd_weight(x1, slope, dy, dw, C0, 3, 1, x3=x3_bwd)
-                g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0, nxt=nxt) if need_dx else None
+                g_low = ops.conv3x3_up_bwd_data(D, rec["wd"], 0, C0, nxt=nxt,
+                                                wd3=rec["wd3"] if ops._is_b16(D) else None) \
+                    if need_dx else None
                 if nxt is not None:
                     saved[i - 1]["nxt"] = nxt
                 dx1 = dx_fold
