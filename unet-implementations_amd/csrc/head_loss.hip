@@ -246,6 +246,23 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
   }
 }
 
+// Sum of one column over the slabs, in slab order, in double: 32 loads in flight, then their adds
+// (the order - and so the value - of the plain loop, which waited for one L2 round trip per slab:
+// 27 us per step for the 128 slabs of a 512 x 512 image).
+__device__ __forceinline__ double loss_column_sum(const float* __restrict__ col, int nblocks) {
+  double s = 0.0;
+  int b = 0;
+  for (; b + 32 <= nblocks; b += 32) {
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = col[(size_t)(b + j) * LQ];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s += (double)v[j];
+  }
+  for (; b < nblocks; ++b) s += (double)col[(size_t)b * LQ];
+  return s;
+}
+
 // single block: thread i < N*LQ sums its column over the slabs (double), then thread 0
 // evaluates the loss and the gradient coefficients.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(
@@ -255,9 +272,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(
   extern __shared__ double sums[];  // [N][LQ]
   for (int i = threadIdx.x; i < N * LQ; i += blockDim.x) {
     const int n = i / LQ, k = i - n * LQ;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[((size_t)n * nblocks + b) * LQ + k];
-    sums[i] = s;
+    sums[i] = loss_column_sum(partial + (size_t)n * nblocks * LQ + k, nblocks);
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -327,9 +342,7 @@ __global__ __launch_bounds__(256) void loss_shard_stats_kernel(const float* __re
                                                                double* __restrict__ stats) {
   for (int i = threadIdx.x; i < N * LQ; i += blockDim.x) {
     const int n = i / LQ, k = i - n * LQ;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[((size_t)n * nblocks + b) * LQ + k];
-    sums[i] = s;
+    sums[i] = loss_column_sum(partial + (size_t)n * nblocks * LQ + k, nblocks);
   }
   __syncthreads();   // global writes of this block are visible to it after the barrier
   if (threadIdx.x >= LSTATS) return;
