@@ -184,6 +184,32 @@ def test_conv3x3_bwd_data_b16(ua, case):
     assert torch.equal(dx3, dx)
 
 
+@pytest.mark.parametrize("case", [(8, 16, 16, 512, 512, 1),    # the network's 1/32-resolution layers
+                                  (8, 32, 32, 512, 512, 2),    # ... and the stride-2 layer into them
+                                  (2, 16, 16, 128, 256, 1), (1, 10, 12, 64, 256, 1),   # ragged M
+                                  (2, 16, 16, 128, 128, 1)])   # K steps not a multiple of 4: old form
+def test_conv3x3_bwd_data_b16_wide_gather(ua, case):
+    """Data gradients with at most one 64 x 64 tile per CU and the bf16 weight plane (round 4):
+    conv_igemm_bf16_kernel<.., MODE 1> - 64-wide K steps, raw 16-byte loads of both operands, four
+    K groups.  Against the fp64 gradient on the same bf16 operands (one rounding of the result)
+    and the form without the plane."""
+    N, H, W, Cin, Cout, stride = case
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = r16(rnd(N, Cout, Ho, Wo, seed=1))
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cout)) ** 0.5)
+    xz = torch.zeros(N, Cin, H, W, dtype=torch.double, device=DEV, requires_grad=True)
+    F.conv2d(xz, r16(w).double().to(DEV), None, stride=stride, padding=1).backward(dy.double().to(DEV))
+    table = ua.ops.PackTable([w.to(DEV)], 1, None)
+    table.run()
+    dx = ua.ops.conv3x3_bwd_data(to_nhwc_b16(dy), table.wd[0], 0, Cin, H, W, stride, bf16="bf16",
+                                 wd3=table.wd3[0])
+    ref = xz.grad.permute(0, 2, 3, 1)
+    err = (dx.double() - ref).abs().max().item()
+    assert err <= 2.0 ** -8 * ref.abs().max().item() + 1e-6, err
+    old = ua.ops.conv3x3_bwd_data(to_nhwc_b16(dy), table.wd[0], 0, Cin, H, W, stride)
+    check(dx.float().cpu(), old.float().cpu(), 8e-3, "wide vs 32-wide gather")
+
+
 def test_instnorm_bwd_upsample_head_b16(ua):
     N, H, W, C = 2, 16, 32, 32
     y = r16(rnd(N, C, H, W, seed=1))

@@ -35,12 +35,16 @@ namespace {
 // no conversion, half the L2 traffic), half the barriers.  A K step may straddle taps (C0 = 32)
 // and the last one may be ragged (9 * 32 = 4.5 steps): lanes past K read zeros.
 template <int BM, int BN, int WM, int WN, typename TS = float, typename TO = float,
-          bool FUSED = false, int KG = 1, bool DENSE = false>
+          bool FUSED = false, int KG = 1, int MODE = 0>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_kernel(const IgemmParams p) {
-  static_assert(!DENSE || (!FUSED && sizeof(TS) == 2), "DENSE: bf16 rows, plain GEMM");
-  constexpr int BK = DENSE ? 64 : 32;
+  // MODE 1 (WIDE): the gather form on the same 64-wide K steps (C0, C1 multiples of 64): raw
+  // 16-byte loads of 8 bf16 channels of a tap, weights from the bf16 plane - the data gradients
+  // of the 1/32-resolution stage.  MODE 2: DENSE.
+  constexpr bool DENSE = MODE == 2, WIDE = MODE != 0;
+  static_assert(!WIDE || (!FUSED && sizeof(TS) == 2), "WIDE / DENSE: bf16 rows, no activation");
+  constexpr int BK = WIDE ? 64 : 32;
   constexpr int LDA = BK + 8;  // bf16 elements per LDS row
-  constexpr int EPS = DENSE ? 8 : 4;   // elements per loader segment
+  constexpr int EPS = WIDE ? 8 : 4;   // elements per loader segment
   constexpr int SEGS = BK / EPS;       // loader segments per tile row
   constexpr int ROWS = 256 / SEGS;     // tile rows covered by one loader pass
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
   const unsigned wrow_off = (unsigned)((p.n_off + n0 + lrow) * Ktot + lseg * 4) * 4u;
   // DENSE: the bf16 weight plane; A rows by byte offset (pitch = 9 * C0 elements)
   const __amdgpu_buffer_rsrc_t rsw3 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(DENSE ? p.w3 : nullptr), 0, DENSE ? (int)p.w3_bytes : 0, 0x00020000);
+      const_cast<__bf16*>(WIDE ? p.w3 : nullptr), 0, WIDE ? (int)p.w3_bytes : 0, 0x00020000);
   const int Kd = 9 * p.C0;                          // DENSE: the GEMM's K
   const int c0_log2 = __builtin_ctz((unsigned)p.C0);   // (launcher: C0 is a power of two)
   unsigned a_off[DENSE ? A_PASSES : 1];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     const bool first = c < p.C0;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const int Cs = first ? (p.src0_pitch ? p.src0_pitch : p.C0) : p.C1;
-    const int cch = (first ? c : c - p.C0) + lseg * 4;     // channel within the K slice
+    const int cch = (first ? c : c - p.C0) + lseg * EPS;   // channel within the K slice
     const int coff = cch + wt * p.tap_cstride;
     if (FUSED) {
       const float* al = first ? p.act0_alpha : p.act1_alpha;
@@ -183,6 +187,22 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
         cs = 1.f;
       }
       okm = 0;
+    }
+    if constexpr (WIDE) {   // raw bf16 bits: 8 channels of the tap per lane, both operands
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
+        const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        ra[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 2u | (ok ? 0u : 0x80000000u), 0, 0));
+      }
+      const unsigned woff =
+          (unsigned)(wt * p.tap_stride + (p.n_off + n0 + lrow) * Ktot + c + lseg * 8) * 2u;
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j)
+        rb[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsw3, woff + (unsigned)(ROWS * j * Ktot) * 2u, 0, 0));
+      return;
     }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     constexpr int SET = decltype(setc)::value;
     __bf16* Ab = As + buf * A_TILE + lrow * LDA + lseg * EPS;
     __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * EPS;
-    if constexpr (DENSE) {   // raw bf16 bits, 16 bytes a lane
+    if constexpr (WIDE) {   // raw bf16 bits, 16 bytes a lane
 #pragma unroll
       for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[SET][i];
 #pragma unroll
@@ -659,21 +679,21 @@ int launch_igemm_bf16(const IgemmParams& p, hipStream_t stream) {
 // bf16 STORAGE (the real mixed-precision pipeline): sources and output are bf16 tensors.
 // stats_px: the fused-layer forward (statistics epilogue where every tile lies in one image);
 // bs_px: a data gradient whose output is final for a layer (BSTATS epilogue, same condition).
-template <int BM, int BN, int WM, int WN, int KG = 1, bool DENSE = false>
+template <int BM, int BN, int WM, int WN, int KG = 1, int MODE = 0>
 int launch_igemm_b16(IgemmParams p, hipStream_t stream, int* stats_px, int* bs_px = nullptr) {
-  constexpr size_t lds = KG * 2 * (size_t)(BM + BN) * (DENSE ? 72 : 40) * sizeof(__bf16);
+  constexpr size_t lds = KG * 2 * (size_t)(BM + BN) * (MODE ? 72 : 40) * sizeof(__bf16);
   static_assert(lds <= 160 * 1024, "LDS stages of every K group fit one CU");
   const long long M = (long long)p.N * p.Hl * p.Wl;
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
   const int HlWl = p.Hl * p.Wl;
-  if constexpr (DENSE) {
+  if constexpr (MODE != 0) {
     if (bs_px && p.bs_partial && HlWl % BM == 0 && M % BM == 0) {
       *bs_px = BM; p.bs_tiles = HlWl / BM * (p.sout * p.sout);
     } else {
       if (bs_px) *bs_px = 0;
       p.bs_partial = nullptr;
     }
-    auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, false, KG, true>;
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, false, KG, MODE>;
     UNET_SET_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KG), lds, stream, p);
   } else
@@ -761,13 +781,20 @@ int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px, 
       p.C1 == 0 && p.ntaps == 9 && (p.C0 & (p.C0 - 1)) == 0 && p.C0 >= 32 && p.sin == 1 &&
       p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout && M % 64 == 0 && nc % 64 == 0) {
     if ((M / 64) * (nc / 64) <= 256 && (9 * p.C0) % 256 == 0)
-      return launch_igemm_b16<64, 64, 32, 32, 4, true>(p, stream, nullptr, bs_px);
-    return launch_igemm_b16<64, 64, 32, 32, 1, true>(p, stream, nullptr, bs_px);
+      return launch_igemm_b16<64, 64, 32, 32, 4, 2>(p, stream, nullptr, bs_px);
+    return launch_igemm_b16<64, 64, 32, 32, 1, 2>(p, stream, nullptr, bs_px);
   }
   if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
     return launch_igemm_b16<128, 128, 64, 64>(p, stream, stats_px, bs_px);
   if (nc % 64 == 0 && ceil_div64(M, 128) * (nc / 64) >= 256)
     return launch_igemm_b16<128, 64, 64, 32>(p, stream, stats_px, bs_px);
+  // data gradients of the 1/32-resolution stage (at most one 64 x 64 tile per CU) with the bf16
+  // weight plane: the gather form on 64-wide K steps (WIDE), four K groups
+  static const bool wide_off = [] { const char* e = getenv("UNET_B16_WIDE_GATHER"); return e && e[0] == '0'; }();
+  if (!wide_off && !stats_px && p.w3 && p.tap_cstride == 0 && nc % 64 == 0 && p.C0 % 64 == 0 &&
+      p.C1 % 64 == 0 && ceil_div64(M, 64) * (nc / 64) <= 256 &&
+      (p.ntaps * ((p.C0 + p.C1) / 64)) % 4 == 0 && p.ntaps * ((p.C0 + p.C1) / 64) >= 8)
+    return launch_igemm_b16<64, 64, 32, 32, 4, 1>(p, stream, nullptr, bs_px);
   if (nc % 64 == 0 && M <= 128 * 256) {
     const int kg = deep_k_groups_b16(p);
     return kg == 4   ? launch_igemm_b16<64, 64, 32, 32, 4>(p, stream, stats_px, bs_px)
