@@ -83,6 +83,7 @@ FWD = [  # (N, H, W, C0, C1, Cout, stride, ksize)
     (8, 16, 16, 512, 0, 512, 1, 3),     # 1/32-resolution layer at bs 8: K-group gather-GEMM (KG 4)
     (8, 32, 32, 512, 0, 512, 2, 3),     # ... its stride-2 sibling (encoder_stages.5.block.0)
     (2, 16, 16, 64, 64, 64, 1, 3),      # two sources through the K-group form (KG 4)
+    (2, 16, 16, 128, 128, 64, 1, 3),    # ... and, with the bf16 weight plane, its 64-wide K steps
     # the stride-2 fused forward on the patch kernel (conv_patch_b16_kernel<.., SD = 2>): one and
     # two 32-channel chunks, image borders on every side, H != W
     (4, 256, 256, 32, 0, 64, 2, 3),
@@ -114,6 +115,18 @@ def test_conv_in_fwd_b16(ua, case):
     # statistics come from the fp32 accumulators, not from the rounded y
     assert (st[0].cpu().double() - mean_ref).abs().max() <= 2e-3 * (y_ref.abs().max() + 1)
     check(st[1].cpu(), rstd_ref, 2e-3, "rstd")
+    if ks == 3:
+        # with the pack's pre-rounded bf16 weight plane (what the network passes): the patch
+        # kernels stage their panels without conversion, the 1/32-resolution gather-GEMM runs on
+        # 64-wide K steps (conv_igemm_bf16_kernel MODE 1, activation on the unpacked 16-byte rows)
+        table = ua.ops.PackTable([w.to(DEV)], True, None)
+        table.run()
+        y3, st3 = ua.ops.conv_in_fwd(src(ua, x0, c0), src(ua, x1, c1) if C1 else None, SLOPE,
+                                     table.wf[0], b.to(DEV), ks, stride, gamma.to(DEV),
+                                     beta.to(DEV), 1e-5, None, b16=True, w3=table.wf3[0])
+        check(from_nhwc(y3), y_ref, 6e-3, "y with the bf16 weight plane")
+        assert (st3[0].cpu().double() - mean_ref).abs().max() <= 2e-3 * (y_ref.abs().max() + 1)
+        check(st3[1].cpu(), rstd_ref, 2e-3, "rstd with the bf16 weight plane")
 
 
 def test_rgb_stem_to_bf16(ua):

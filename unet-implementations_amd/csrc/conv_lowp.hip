@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
   // 16-byte loads of 8 bf16 channels of a tap, weights from the bf16 plane - the data gradients
   // of the 1/32-resolution stage.  MODE 2: DENSE.
   constexpr bool DENSE = MODE == 2, WIDE = MODE != 0;
-  static_assert(!WIDE || (!FUSED && sizeof(TS) == 2), "WIDE / DENSE: bf16 rows, no activation");
+  static_assert(!WIDE || sizeof(TS) == 2, "WIDE / DENSE: bf16 rows");
+  static_assert(!DENSE || !FUSED, "DENSE: no activation");
   constexpr int BK = WIDE ? 64 : 32;
   constexpr int LDA = BK + 8;  // bf16 elements per LDS row
   constexpr int EPS = WIDE ? 8 : 4;   // elements per loader segment
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
   // K steps of this group (the launcher checks % KG)
   const int KS = DENSE ? ((Kd + BK - 1) / BK) / KG : p.ntaps * (Ktot / BK) / KG;
   constexpr int CP = FUSED ? A_PASSES : 1;
-  f32x4 ca[CP], cb[CP];
+  constexpr int CV = WIDE ? 2 : 1;     // coefficient quads per staged segment (8 / 4 channels)
+  f32x4 ca[CP][CV], cb[CP][CV];
   float cs = 1.f;
   unsigned okm = 0;
 
@@ -173,17 +175,21 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
       const int Cc = first ? p.C0 : p.C1;
       if (al) {   // uniform
 #pragma unroll
-        for (int i = 0; i < CP; ++i) {
-          ca[i] = *reinterpret_cast<const f32x4*>(al + (size_t)a_img[i] * Cc + cch);
-          cb[i] = *reinterpret_cast<const f32x4*>(be + (size_t)a_img[i] * Cc + cch);
-        }
+        for (int i = 0; i < CP; ++i)
+#pragma unroll
+          for (int v = 0; v < CV; ++v) {
+            ca[i][v] = *reinterpret_cast<const f32x4*>(al + (size_t)a_img[i] * Cc + cch + 4 * v);
+            cb[i][v] = *reinterpret_cast<const f32x4*>(be + (size_t)a_img[i] * Cc + cch + 4 * v);
+          }
         cs = p.slope;
       } else {    // plain source: z = v, slope 1 = identity
 #pragma unroll
-        for (int i = 0; i < CP; ++i) {
-          ca[i] = f32x4{1.f, 1.f, 1.f, 1.f};
-          cb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < CP; ++i)
+#pragma unroll
+          for (int v = 0; v < CV; ++v) {
+            ca[i][v] = f32x4{1.f, 1.f, 1.f, 1.f};
+            cb[i][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         cs = 1.f;
       }
       okm = 0;
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
       for (int i = 0; i < A_PASSES; ++i) {
         const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
         const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        if (FUSED) okm |= (ok ? 1u : 0u) << i;
         ra[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             rs, (unsigned)((a_nb[i] + iy * p.Win + ix) * Cs + coff) * 2u | (ok ? 0u : 0x80000000u), 0, 0));
       }
@@ -231,14 +238,27 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_bf16_ker
     __bf16* Bb = Bs + buf * B_TILE + lrow * LDA + lseg * EPS;
     if constexpr (WIDE) {   // raw bf16 bits, 16 bytes a lane
 #pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[SET][i];
+      for (int i = 0; i < A_PASSES; ++i) {
+        if constexpr (FUSED) {   // unpack, activate (fp32, as the 32-wide form), round again
+          const i32x4 w = __builtin_bit_cast(i32x4, ra[SET][i]);
+          auto lo = [](int x) { return __builtin_bit_cast(float, x << 16); };
+          auto hi = [](int x) { return __builtin_bit_cast(float, x & (int)0xffff0000); };
+          const bool ok = (okm >> i) & 1u;
+          const f32x4 v0 = act4(f32x4{lo(w[0]), hi(w[0]), lo(w[1]), hi(w[1])}, ca[i][0], cb[i][0], cs, ok);
+          const f32x4 v1 = act4(f32x4{lo(w[2]), hi(w[2]), lo(w[3]), hi(w[3])}, ca[i][1], cb[i][1], cs, ok);
+          *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(v0);
+          *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA + 4) = to_bf16(v1);
+        } else {
+          *reinterpret_cast<f32x4*>(Ab + ROWS * i * LDA) = ra[SET][i];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < B_PASSES; ++j) *reinterpret_cast<f32x4*>(Bb + ROWS * j * LDA) = rb[SET][j];
       return;
     }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      if (FUSED) ra[SET][i] = act4(ra[SET][i], ca[i], cb[i], cs, (okm >> i) & 1u);
+      if (FUSED) ra[SET][i] = act4(ra[SET][i], ca[i][0], cb[i][0], cs, (okm >> i) & 1u);
       *reinterpret_cast<bf16x4*>(Ab + ROWS * i * LDA) = to_bf16(ra[SET][i]);
     }
 #pragma unroll
@@ -687,6 +707,19 @@ int launch_igemm_b16(IgemmParams p, hipStream_t stream, int* stats_px, int* bs_p
   const long long tiles = ceil_div64(M, BM) * (p.Ncols / BN);
   const int HlWl = p.Hl * p.Wl;
   if constexpr (MODE != 0) {
+    if (stats_px) {   // WIDE fused layer forward
+      const bool direct = p.sout == 1 && p.Hl == p.Hout && p.Wl == p.Wout;
+      if (direct && p.stats && HlWl % BM == 0) { *stats_px = BM; p.stats_tiles = HlWl / BM; }
+      else { *stats_px = 0; p.stats = nullptr; }
+      p.bs_partial = nullptr;
+      if constexpr (MODE == 1) {
+        auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, __bf16, __bf16, true, KG, 1>;
+        UNET_SET_DYN_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KG), lds, stream, p);
+      }
+      UNET_CHECK_LAUNCH("conv_igemm_b16");
+      return UNET_OK;
+    }
     if (bs_px && p.bs_partial && HlWl % BM == 0 && M % BM == 0) {
       *bs_px = BM; p.bs_tiles = HlWl / BM * (p.sout * p.sout);
     } else {
@@ -791,10 +824,10 @@ int dispatch_igemm_b16(const IgemmParams& p, hipStream_t stream, int* stats_px, 
   // data gradients of the 1/32-resolution stage (at most one 64 x 64 tile per CU) with the bf16
   // weight plane: the gather form on 64-wide K steps (WIDE), four K groups
   static const bool wide_off = [] { const char* e = getenv("UNET_B16_WIDE_GATHER"); return e && e[0] == '0'; }();
-  if (!wide_off && !stats_px && p.w3 && p.tap_cstride == 0 && nc % 64 == 0 && p.C0 % 64 == 0 &&
+  if (!wide_off && p.w3 && p.tap_cstride == 0 && nc % 64 == 0 && p.C0 % 64 == 0 &&
       p.C1 % 64 == 0 && ceil_div64(M, 64) * (nc / 64) <= 256 &&
       (p.ntaps * ((p.C0 + p.C1) / 64)) % 4 == 0 && p.ntaps * ((p.C0 + p.C1) / 64) >= 8)
-    return launch_igemm_b16<64, 64, 32, 32, 4, 1>(p, stream, nullptr, bs_px);
+    return launch_igemm_b16<64, 64, 32, 32, 4, 1>(p, stream, stats_px, bs_px);
   if (nc % 64 == 0 && M <= 128 * 256) {
     const int kg = deep_k_groups_b16(p);
     return kg == 4   ? launch_igemm_b16<64, 64, 32, 32, 4>(p, stream, stats_px, bs_px)
