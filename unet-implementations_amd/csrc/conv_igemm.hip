@@ -1166,6 +1166,175 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_rows_kernel(const T* __rest
   }
 }
 
+// Walking form of the row stem (round 4): a workgroup walks R rows down its 128-pixel column
+// strip.  The weight fragments live in registers for the whole walk, the input rows in a ring of
+// eight LDS rows, one new row a step instead of three.  Row yy + 3 is fetched (unconditional
+// buffer loads: rows and columns outside the image read zero through the descriptor) during step
+// yy and written to LDS at the end of step yy + 1, behind that step's output stores: the counted
+// wait then covers the loads only and leaves the 16 stores of the step in flight - the memory
+// counter is in order, so a load issued behind the stores of the step before it cannot be waited
+// for without them (the first version of this kernel did: 72 us against 97 for the rows kernel
+// above, which pays a weight gather, three row loads and their latency per 128 pixels).
+// Same MFMA sequence and the same 128-pixel statistics tiles as the rows kernel: identical bits.
+template <typename T, typename TO, int R>
+__global__ __launch_bounds__(256) void conv_stem_fwd_walk_kernel(const T* __restrict__ x,
+                                                                 const float* __restrict__ wf,
+                                                                 const float* __restrict__ bias,
+                                                                 TO* __restrict__ y, int N,
+                                                                 int H, int W, int Cout,
+                                                                 float2* __restrict__ stats,
+                                                                 const StemNorm nm) {
+  static_assert(R % 2 == 0, "two register sets alternate");
+  __shared__ float Rw[8 * STEM_ROW_PITCH];
+  __shared__ float2 red[4 * 32];
+  // output staging, one 32-pixel x 32-channel tile per wave: the accumulator layout gives a lane
+  // 16 scattered 2- or 4-byte values, the tile leaves as 16-byte stores (1 KB contiguous per
+  // instruction at Cout = 32) - 2 / 4 store instructions a step instead of 16.  Row pitch: the
+  // row + 16 bytes (bf16), + 32 (fp32: the rows of the two half-waves, 4 apart, 32 banks apart).
+  constexpr int OROW = 32 * (int)sizeof(TO);
+  constexpr int OPITCH = OROW + (sizeof(TO) == 2 ? 16 : 32);
+  __shared__ __attribute__((aligned(16))) char Os[4 * 32 * OPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int HW = H * W;
+  const int strips = W / STEM_ROW_PIX, groups = H / R;
+  int b = blockIdx.x;
+  const int strip = b % strips; b /= strips;
+  const int grp = b % groups;
+  const int n = b / groups;
+  const int x0 = strip * STEM_ROW_PIX, y0 = grp * R, co0 = blockIdx.y * 32;
+  // B operand of this lane, k = 2 * k2 + lh (k = tap*3 + ci; wf is [tap][co][ci]; k = 27: zero)
+  float breg[14];
+  int kof[14];      // A operand: LDS offset inside its row, and the row (ky) it comes from
+  int kyv[14];
+  const int px = wave * 32 + li;
+#pragma unroll
+  for (int k2 = 0; k2 < 14; ++k2) {
+    const int k = 2 * k2 + lh;
+    breg[k2] = k < 27 ? wf[((k / 3) * Cout + co0 + li) * 3 + (k % 3)] : 0.f;
+    const int kc = k < 27 ? k : 26;          // (its weight is zero: any finite a will do)
+    kyv[k2] = kc / 9;
+    kof[k2] = (kc % 9) + 3 * px;
+  }
+  // loader: a row of the strip is 390 consecutive values from pixel x0 - 1 on; lanes outside
+  // the image (or past the 390) carry the kill bit: beyond num_records, the load returns 0
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(x), 0, (int)((long long)N * HW * 3 * (long long)sizeof(T)), 0x00020000);
+  const int e0 = tid, e1 = tid + 256;
+  const bool has1 = e1 < 390;
+  const unsigned kill0 = (unsigned)(x0 - 1 + e0 / 3) < (unsigned)W ? 0u : 0x80000000u;
+  const unsigned kill1 = (has1 && (unsigned)(x0 - 1 + e1 / 3) < (unsigned)W) ? 0u : 0x80000000u;
+  const int c0 = e0 % 3, c1 = e1 % 3;
+  auto fetch = [&](unsigned off) __attribute__((always_inline)) {
+    if constexpr (sizeof(T) == 4) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, off, 0, 0));
+    } else {
+      return (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsx, off, 0, 0);
+    }
+  };
+  auto load_row = [&](int iy, float& v0, float& v1) __attribute__((always_inline)) {
+    const unsigned rk = (unsigned)iy < (unsigned)H ? 0u : 0x80000000u;      // uniform
+    const unsigned base = (unsigned)(((n * H + iy) * W + x0 - 1) * 3) * (unsigned)sizeof(T);
+    v0 = fetch((base + (unsigned)e0 * (unsigned)sizeof(T)) | kill0 | rk);
+    v1 = fetch((base + (unsigned)e1 * (unsigned)sizeof(T)) | kill1 | rk);
+  };
+  auto put_row = [&](int iy, float v0, float v1) __attribute__((always_inline)) {
+    if constexpr (sizeof(T) == 1) {   // uint8: normalise; the zero padding stays zero
+      const bool in = (unsigned)iy < (unsigned)H;
+      v0 = (in && !kill0) ? (v0 / 255.0f - nm.mean[c0]) / nm.std[c0] : 0.f;
+      v1 = (in && !kill1) ? (v1 / 255.0f - nm.mean[c1]) / nm.std[c1] : 0.f;
+    }
+    float* d = Rw + ((iy + 1) & 7) * STEM_ROW_PITCH;
+    d[e0] = v0;
+    if (has1) d[e1] = v1;
+  };
+#pragma unroll
+  for (int r = -1; r <= 2; ++r) {
+    float v0, v1;
+    load_row(y0 + r, v0, v1);
+    put_row(y0 + r, v0, v1);
+  }
+  __syncthreads();
+  const float bv = bias ? bias[co0 + li] : 0.f;
+  float na[2], nb[2];     // rows in flight: [0] fetched in even steps, [1] in odd ones
+  na[1] = nb[1] = 0.f;    // (nothing to write at the end of step 0: row y0 + 2 is in LDS)
+  auto step = [&](int s, auto parc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value;
+    const int yy = y0 + s;
+    // row yy + 3, needed by step s + 2 (past the walk: a dead load, the wait stays counted)
+    load_row(s + 2 < R ? yy + 3 : -1, na[PAR], nb[PAR]);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < 14; ++k2) {
+      const float a = Rw[((yy + kyv[k2]) & 7) * STEM_ROW_PITCH + kof[k2]];   // row yy - 1 + ky
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[k2], acc, 0, 0, 0);
+    }
+    const size_t m0 = (size_t)n * HW + (size_t)yy * W + x0;
+    {
+      char* ow = Os + wave * 32 * OPITCH;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        *reinterpret_cast<TO*>(ow + row * OPITCH + li * (int)sizeof(TO)) = (TO)(acc[r] + bv);
+      }
+      __builtin_amdgcn_wave_barrier();   // (one wave: its LDS accesses complete in order)
+      constexpr int SEGS = OROW / 16;            // 16-byte segments per pixel: 4 (bf16) / 8 (fp32)
+      constexpr int RPP = 64 / SEGS;             // pixels per store instruction
+      typedef int i32x4s __attribute__((ext_vector_type(4)));
+      const int seg = lane % SEGS, r0 = lane / SEGS;
+      char* yb = reinterpret_cast<char*>(y + (m0 + wave * 32) * Cout + co0) + seg * 16;
+#pragma unroll
+      for (int q = 0; q < 32 / RPP; ++q) {
+        const int row = q * RPP + r0;
+        const i32x4s v = *reinterpret_cast<const i32x4s*>(ow + row * OPITCH + seg * 16);
+        *reinterpret_cast<i32x4s*>(yb + (size_t)row * Cout * sizeof(TO)) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // row yy + 2 (fetched during step s - 1) into its slot: nobody reads that slot before the
+    // barrier below (this step reads rows yy - 1 .. yy + 1, the slot held row yy - 6)
+    __builtin_amdgcn_sched_barrier(0);   // (behind the stores: hipcc hoists it to the top otherwise)
+    if (s > 0 && s + 1 < R) put_row(yy + 2, na[PAR ^ 1], nb[PAR ^ 1]);
+    if (stats) {   // (mean, M2) of this 128-pixel tile per output column
+      const float2 mine = wave_col_stats<1>([&](int, int r) { return acc[r] + bv; });
+      if (lh == 0) red[wave * 32 + li] = mine;
+      float2 out;
+      if (block_col_stats<32, 4>(red, 0, 0, false, float2{0.f, 0.f}, 32.f, out))
+        stats[((size_t)n * (HW / STEM_ROW_PIX) + (size_t)(yy * W + x0) / STEM_ROW_PIX) * Cout + co0 +
+              tid] = out;
+    }
+    __syncthreads();
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  // fully unrolled: across a loop back edge hipcc cannot count the stores between a fetch and
+  // its use and waits for (nearly) everything - the wait this kernel is built to avoid
+#pragma unroll
+  for (int s = 0; s < R; s += 2) {
+    step(s, P0{});
+    step(s + 1, P1{});
+  }
+}
+
+constexpr int STEM_WALK_ROWS = 8;
+template <typename T, typename TO>
+void launch_stem_fwd_rows(const T* x, const float* wf, const float* bias, TO* y, int N, int H, int W,
+                          int Cout, float2* stats, const StemNorm& nm, hipStream_t stream) {
+  static const bool walk_off = [] { const char* e = getenv("UNET_STEM_WALK"); return e && e[0] == '0'; }();
+  if (!walk_off && H % STEM_WALK_ROWS == 0 &&
+      (long long)N * H * W * 3 * (long long)sizeof(T) < (1LL << 31)) {   // (buffer descriptor)
+    dim3 grid((unsigned)((long long)N * (H / STEM_WALK_ROWS) * (W / STEM_ROW_PIX)), Cout / 32);
+    hipLaunchKernelGGL((conv_stem_fwd_walk_kernel<T, TO, STEM_WALK_ROWS>), grid, dim3(256), 0, stream,
+                       x, wf, bias, y, N, H, W, Cout, stats, nm);
+  } else {
+    dim3 grid((unsigned)((long long)N * H * W / STEM_ROW_PIX), Cout / 32);
+    hipLaunchKernelGGL((conv_stem_fwd_rows_kernel<T, TO>), grid, dim3(256), 0, stream, x, wf, bias, y,
+                       N, H, W, Cout, stats, nm);
+  }
+}
+
 void fill_fwd_taps(IgemmParams& p, int stride) {
   p.ntaps = 9;
   p.tapw[0] = p.tapw[1] = p.tapw[2] = 0;
@@ -1193,9 +1362,7 @@ static int conv3x3_fwd_impl(const float* x0, int C0, const float* x1, int C1, co
     UNET_REQUIRE(C1 == 0 && stride == 1, "conv3x3_fwd: RGB stem is stride-1, single source");
     const long long M = (long long)N * H * W;
     if (W % STEM_ROW_PIX == 0) {
-      dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
-      hipLaunchKernelGGL(conv_stem_fwd_rows_kernel<float>, grid, dim3(256), 0, stream, x0, wf, bias,
-                         y, N, H, W, Cout, (float2*)nullptr, StemNorm{});
+      launch_stem_fwd_rows<float, float>(x0, wf, bias, y, N, H, W, Cout, nullptr, StemNorm{}, stream);
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
       hipLaunchKernelGGL(conv_stem_fwd_kernel<float>, grid, dim3(256), 0, stream, x0, wf, bias, y,
@@ -1634,15 +1801,12 @@ static int conv_in_fwd_impl(const unet_act_src* s0, const unet_act_src* s1, floa
     const long long M = (long long)N * H * W;
     __bf16* yh = reinterpret_cast<__bf16*>(y);
     if (W % STEM_ROW_PIX == 0) {
-      dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
       if (b16)
-        hipLaunchKernelGGL((conv_stem_fwd_rows_kernel<float, __bf16>), grid, dim3(256), 0, stream,
-                           s0->x, w, bias, yh, N, H, W, Cout, reinterpret_cast<float2*>(workspace),
-                           StemNorm{});
+        launch_stem_fwd_rows<float, __bf16>(s0->x, w, bias, yh, N, H, W, Cout,
+                                            reinterpret_cast<float2*>(workspace), StemNorm{}, stream);
       else
-        hipLaunchKernelGGL((conv_stem_fwd_rows_kernel<float, float>), grid, dim3(256), 0, stream,
-                           s0->x, w, bias, y, N, H, W, Cout, reinterpret_cast<float2*>(workspace),
-                           StemNorm{});
+        launch_stem_fwd_rows<float, float>(s0->x, w, bias, y, N, H, W, Cout,
+                                           reinterpret_cast<float2*>(workspace), StemNorm{}, stream);
       stats_px = STEM_ROW_PIX;
     } else {
       dim3 grid((unsigned)ceil_div64(M, STEM_PIX), Cout / 32);
@@ -2030,11 +2194,9 @@ extern "C" int unet_stem_u8_fwd(const uint8_t* image_hwc, const float* mean3, co
   }
   StemNorm nm;
   for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.std[c] = std3[c]; }
-  const long long M = (long long)N * H * W;
-  dim3 grid((unsigned)(M / STEM_ROW_PIX), Cout / 32);
-  hipLaunchKernelGGL(conv_stem_fwd_rows_kernel<unsigned char>, grid, dim3(256), 0,
-                     (hipStream_t)stream, image_hwc, wf, bias, y, N, H, W, Cout,
-                     reinterpret_cast<float2*>(workspace), nm);
+  launch_stem_fwd_rows<unsigned char, float>(image_hwc, wf, bias, y, N, H, W, Cout,
+                                             reinterpret_cast<float2*>(workspace), nm,
+                                             (hipStream_t)stream);
   UNET_CHECK_LAUNCH("conv_stem_fwd(u8)");
   *stats_px_out = STEM_ROW_PIX;
   return UNET_OK;
