@@ -11,6 +11,13 @@ namespace {
 using unet_conv::act4;
 
 constexpr int HT = 256;  // pixels per head tile
+// ... of the backward kernel, whose tile lives in registers: 64 pixels = 92 VGPRs, five waves per
+// SIMD.  At 256 pixels (234 VGPRs, two waves) it ran at 2.1 TB/s: 192 -> 136 us on fp32 tensors,
+// 161 -> 108 us on bf16 (tools/bench_head.py; 128 pixels: 178 VGPRs, no gain; 32: 164 / 119 us).
+#ifndef UNET_HEAD_BWD_TILE
+#define UNET_HEAD_BWD_TILE 64
+#endif
+constexpr int HB = UNET_HEAD_BWD_TILE;
 
 // ------------------------------------------------------------------ head forward
 // 8 lanes per pixel, 4 channels per lane: a wave's load instruction reads 8 whole pixels
@@ -73,8 +80,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const TS* __restrict__ a,
 
 // ------------------------------------------------------------------ head backward
 // partial[block][K*32 + K]: dw then db
+#ifndef UNET_HEAD_BWD_OCC
+#define UNET_HEAD_BWD_OCC 1
+#endif
 template <typename TS>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const TS* __restrict__ a,
+__global__ __launch_bounds__(256, UNET_HEAD_BWD_OCC) void head_bwd_kernel(const TS* __restrict__ a,
                                                        const float* __restrict__ dl,
                                                        const float* __restrict__ w,
                                                        TS* __restrict__ da,
@@ -98,13 +108,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const TS* __restrict__ a,
     dwacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     dbacc[k] = 0.f;
   }
-  const bool one_image = HW % HT == 0;   // a tile never straddles images
+  const bool one_image = HW % HB == 0;   // a tile never straddles images
   for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const long long m0 = t * HT;
+    const long long m0 = t * HB;
     // all loads of the tile first (rows past M are clamped and masked: no branch, so the eight
     // pixel loads and 8 x K gradient loads are in flight together)
-    f32x4 av[HT / 32];
-    float dv[HT / 32][4];
+    f32x4 av[HB / 32];
+    float dv[HB / 32][4];
     f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
     if (alpha && one_image) {   // uniform: one coefficient row for the whole tile
       const size_t o = (size_t)(m0 / HW) * 32 + seg * 4;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const TS* __restrict__ a,
       be = *reinterpret_cast<const f32x4*>(beta + o);
     }
 #pragma unroll
-    for (int it = 0; it < HT / 32; ++it) {
+    for (int it = 0; it < HB / 32; ++it) {
       const long long m = m0 + it * 32 + grp;
       const long long mc = m < M ? m : M - 1;
       av[it] = ld4(a + (size_t)mc * 32 + seg * 4);
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const TS* __restrict__ a,
         dv[it][k] = (k < K && m < M) ? dl[((size_t)n * K + k) * HW + pp] : 0.f;
     }
 #pragma unroll
-    for (int it = 0; it < HT / 32; ++it) {
+    for (int it = 0; it < HB / 32; ++it) {
       const long long m = m0 + it * 32 + grp;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -524,7 +534,10 @@ size_t loss_ws_layout(int N, LossWs* out, char* base) {
   return off;
 }
 
-int head_bwd_blocks(long long tiles) { return (int)(tiles < 1024 ? tiles : 1024); }
+#ifndef UNET_HEAD_BWD_BLOCKS
+#define UNET_HEAD_BWD_BLOCKS 1024
+#endif
+int head_bwd_blocks(long long tiles) { return (int)(tiles < UNET_HEAD_BWD_BLOCKS ? tiles : UNET_HEAD_BWD_BLOCKS); }
 
 }  // namespace
 
@@ -570,7 +583,7 @@ extern "C" int unet_head1x1_in_fwd_b16(const unet_act_src* x, float slope, const
 
 extern "C" size_t unet_head1x1_bwd_workspace_bytes(int N, int HW, int C, int K) {
   if (N <= 0 || HW <= 0) return 0;
-  const long long tiles = ceil_div64((long long)N * HW, HT);
+  const long long tiles = ceil_div64((long long)N * HW, HB);
   return (size_t)head_bwd_blocks(tiles) * (K * 32 + K) * sizeof(float);
 }
 
@@ -617,7 +630,7 @@ static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w
     return UNET_E_WORKSPACE;
   }
   const long long M = (long long)N * HW;
-  const long long tiles = ceil_div64(M, HT);
+  const long long tiles = ceil_div64(M, HB);
   const int blocks = head_bwd_blocks(tiles);
   float* partial = reinterpret_cast<float*>(workspace);
   if (b16)
