@@ -44,17 +44,36 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const TS* __restrict__ a,
     bk[k] = (k < K && b) ? b[k] : 0.f;
   }
   const long long m0 = (long long)blockIdx.x * HT;
+  // all loads of the tile first (rows past M are clamped and masked: no branch, the eight pixel
+  // loads are in flight together); one coefficient row and one image index for the whole tile
+  // where a tile never straddles images (no 64-bit division per pixel) - as head_bwd_kernel
+  const bool one_image = HW % HT == 0;
+  const long long n_tile = m0 / HW;
+  f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+  if (alpha && one_image) {
+    const size_t o = (size_t)n_tile * 32 + seg * 4;
+    al = *reinterpret_cast<const f32x4*>(alpha + o);
+    be = *reinterpret_cast<const f32x4*>(beta + o);
+  }
+  f32x4 av[HT / 32];
 #pragma unroll
   for (int it = 0; it < HT / 32; ++it) {          // 32 pixels per pass of the 256 threads
     const long long m = m0 + it * 32 + (tid >> 3);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m < M) {
-      v = ld4(a + (size_t)m * 32 + seg * 4);
-      if (alpha) {
-        const size_t o = (size_t)(m / HW) * 32 + seg * 4;
-        v = act4(v, *reinterpret_cast<const f32x4*>(alpha + o),
-                 *reinterpret_cast<const f32x4*>(beta + o), slope, true);
+    const long long mc = m < M ? m : M - 1;
+    av[it] = ld4(a + (size_t)mc * 32 + seg * 4);
+  }
+#pragma unroll
+  for (int it = 0; it < HT / 32; ++it) {
+    const long long m = m0 + it * 32 + (tid >> 3);
+    const long long mc = m < M ? m : M - 1;
+    const long long n = one_image ? n_tile : mc / HW;
+    f32x4 v = av[it];
+    if (alpha) {   // uniform
+      if (!one_image) {
+        al = *reinterpret_cast<const f32x4*>(alpha + (size_t)n * 32 + seg * 4);
+        be = *reinterpret_cast<const f32x4*>(beta + (size_t)n * 32 + seg * 4);
       }
+      v = act4(v, al, be, slope, true);
     }
     float acc[4];
 #pragma unroll
@@ -70,7 +89,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const TS* __restrict__ a,
       acc[k] = s + bk[k];
     }
     if (seg == 0 && m < M) {
-      const long long n = m / HW, pp = m - n * HW;
+      const long long pp = m - n * HW;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < K) logits[((size_t)n * K + k) * HW + pp] = acc[k];
