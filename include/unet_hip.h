@@ -710,6 +710,20 @@ int unet_head1x1_in_fwd(const unet_act_src* x, float slope, const float* w, cons
 int unet_head1x1_in_bwd(const unet_act_src* x, float slope, const float* dlogits_nchw,
                         const float* w, float* da, float* dw, float* db, void* workspace,
                         size_t workspace_bytes, int N, int HW, int K, unet_stream_t stream);
+/* ... with the reductions of the InstanceNorm + LeakyReLU + dropout backward of the layer whose
+ * raw output x->x is (bs->y == x->x; Our_UNet/models/unet.py:128-134 in front of :427): da is
+ * that layer's final dL/da, so the kernel that writes it also leaves S1 = sum gz and
+ * S2 = sum gz * xhat per workgroup in bs->partial (bs->tiles_out summaries per image; 0 = the
+ * shape does not split evenly - run unet_instnorm_lrelu_drop_bwd as usual).  _b16: x, da and
+ * bs->y are bf16 tensors. */
+int unet_head1x1_in_bwd_bs(const unet_act_src* x, float slope, const float* dlogits_nchw,
+                           const float* w, float* da, float* dw, float* db, void* workspace,
+                           size_t workspace_bytes, int N, int HW, int K, unet_bwd_stats* bs,
+                           unet_stream_t stream);
+int unet_head1x1_in_bwd_bs_b16(const unet_act_src* x, float slope, const float* dlogits_nchw,
+                               const float* w, uint16_t* da, float* dw, float* db,
+                               void* workspace, size_t workspace_bytes, int N, int HW, int K,
+                               unet_bwd_stats* bs, unet_stream_t stream);
 
 #ifdef __cplusplus
 }

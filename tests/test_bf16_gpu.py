@@ -268,6 +268,41 @@ def test_instnorm_bwd_upsample_head_b16(ua):
     check(dw.cpu(), wr.grad, 1e-4, "head dw")
 
 
+@pytest.mark.parametrize("case", [(8, 512, 512), (2, 64, 128)])
+def test_head_backward_emits_next_norm_reductions_b16(ua, case):
+    """unet_head1x1_in_bwd_bs_b16: the head's backward on bf16 tensors also leaves the reductions of
+    the last decoder layer's InstanceNorm backward (from its fp32 values of da, as the convolution
+    epilogues do) - same da bits, summaries usable in place of the reduction pass."""
+    N, H, W = case
+    C, K = 32, 3
+    y = r16(rnd(N, H, W, C, seed=30) * 1.5 + 0.3).to(DEV).to(BF)
+    gamma, beta = (rnd(C, seed=31) * 0.2 + 1.0).to(DEV), (rnd(C, seed=32) * 0.2).to(DEV)
+    yf = y.float()
+    mean = yf.mean(dim=(1, 2))
+    rstd = 1.0 / torch.sqrt(yf.var(dim=(1, 2), unbiased=False) + 1e-5)
+    al = gamma[None] * rstd
+    st = torch.stack([mean, rstd, al, beta[None] - mean * al]).contiguous()
+    x = ua.ops.Act(y, st[2].contiguous(), st[3].contiguous())
+    dl = rnd(N, K, H, W, seed=5).to(DEV)
+    w = (rnd(K, C, seed=6) * 0.2).to(DEV)
+    dw0, db0, dw1, db1 = (torch.empty(K, C, device=DEV), torch.empty(K, device=DEV),
+                          torch.empty(K, C, device=DEV), torch.empty(K, device=DEV))
+    ref = ua.ops.head1x1_in_bwd(x, SLOPE, dl, w, dw0, db0)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, None, SLOPE)
+    g = ua.ops.head1x1_in_bwd(x, SLOPE, dl, w, dw1, db1, nxt=nn)
+    assert g.dtype == BF and torch.equal(g, ref) and nn.tiles > 0
+    check(dw1.cpu(), dw0.cpu(), 1e-5, "head dw")
+    outs = []
+    for partials in ((nn.partial, nn.tiles), None):
+        dg, db, dbias = (torch.empty(C, device=DEV) for _ in range(3))
+        dz = ua.ops.instnorm_lrelu_drop_bwd(g.clone(), y, st[0], st[1], gamma, beta, None, SLOPE,
+                                            dg, db, dbias, partials=partials)
+        outs.append((dz.float(), dg, db))
+    check(outs[0][0], outs[1][0], 8e-3, "dz")
+    check(outs[0][1], outs[1][1], 3e-3, "dgamma")
+    check(outs[0][2], outs[1][2], 3e-3, "dbeta")
+
+
 @pytest.mark.parametrize("case", [(2, 8, 16, 64, 64), (1, 16, 16, 32, 64), (3, 2, 2, 64, 64),
                                   (2, 32, 32, 128, 64), (1, 24, 40, 64, 128),
                                   # 32 x 32 channel tiles (the last decoder stage: 64 -> 32):

@@ -920,6 +920,37 @@ def test_low_resolution_gradient_emits_reductions(ua):
     _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
 
 
+@pytest.mark.parametrize("case", [(8, 512, 512), (2, 256, 128), (1, 64, 64), (3, 8, 8), (1, 8, 12)])
+def test_head_backward_emits_next_norm_reductions(ua, case):
+    """unet_head1x1_in_bwd_bs (round 4): da is the final gradient of the last decoder layer, so the
+    head's backward also sums gz and gz * xhat per workgroup (contiguous tile ranges that divide
+    an image) - the stand-alone reduction pass over (da, y) goes.  Same da bits, and the
+    summaries drive the InstanceNorm backward like the reduction pass does; shapes that do not
+    split evenly report tiles == 0."""
+    N, H, W = case
+    C, K = 32, 3
+    y, st, gamma, beta, mask = _next_norm(ua, N, C, H, W, 30)
+    st = st.clone()
+    st[2] *= mask          # alpha / beta of the forward carry the dropout factors
+    st[3] *= mask
+    x = ua.ops.Act(y, st[2].contiguous(), st[3].contiguous())
+    dl = rnd(N, K, H, W, seed=5).to(DEV)
+    w = (rnd(K, C, seed=6) * 0.2).to(DEV)
+    dw0, db0, dw1, db1 = (torch.empty(K, C, device=DEV), torch.empty(K, device=DEV),
+                          torch.empty(K, C, device=DEV), torch.empty(K, device=DEV))
+    ref = ua.ops.head1x1_in_bwd(x, SLOPE, dl, w, dw0, db0)
+    nn = ua.ops.NextNorm(y, st, gamma, beta, mask, SLOPE)
+    g = ua.ops.head1x1_in_bwd(x, SLOPE, dl, w, dw1, db1, nxt=nn)
+    assert torch.equal(g, ref)
+    check(dw1, dw0, 1e-5, "head dw (contiguous tile ranges)")
+    check(db1, db0, 1e-5, "head db")
+    if (H * W) % 64:       # 96 pixels: no whole number of 64-pixel tiles per image
+        assert nn.tiles == 0
+        return
+    assert nn.tiles > 0
+    _in_bwd_both_ways(ua, g, nn, y, st, gamma, beta, mask)
+
+
 def test_winograd_weight_packing_in_one_launch(ua):
     """unet_pack_wino_weights_batched (PackTable.run: every layer's U = G g G^T in one launch)
     against the per-layer entry point, forward and data-gradient forms, incl. a layer that only

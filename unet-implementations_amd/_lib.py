@@ -174,6 +174,8 @@ SIGNATURES = {
     "unet_conv3x3_up_bwd_data": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "unet_head1x1_in_fwd": (_i, [_ps, _f, _p, _p, _p, _i, _i, _i, _p]),
     "unet_head1x1_in_bwd": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _p]),
+    "unet_head1x1_in_bwd_bs": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _pbs, _p]),
+    "unet_head1x1_in_bwd_bs_b16": (_i, [_ps, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _pbs, _p]),
 }
 
 _lib = None

@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const TS* __restrict__ a,
 }
 
 // ------------------------------------------------------------------ head backward
+// InstanceNorm-backward reductions of the layer in front of the head (unet_bwd_stats)
+struct HeadBs {
+  const float* mean; const float* rstd; const float* gamma; const float* beta; const float* mask;
+  float2* partial;          // nullptr: no reductions
+  int tiles_per_block;
+};
 // partial[block][K*32 + K]: dw then db
 #ifndef UNET_HEAD_BWD_OCC
 #define UNET_HEAD_BWD_OCC 1
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256, UNET_HEAD_BWD_OCC) void head_bwd_kernel(const 
                                                        int HW, int K, long long tiles,
                                                        const float* __restrict__ alpha,
                                                        const float* __restrict__ beta,
-                                                       float slope) {
+                                                       float slope, const HeadBs bs) {
   // 8 lanes per pixel, 4 channels per lane (as head_fwd_kernel): a and da move as whole pixels
   // (1 KB per wave instruction), the K logit gradients of a pixel are broadcast loads; every
   // lane keeps its own dw[k][4 channels] partial sums over the pixels it sees, merged per block
@@ -128,11 +134,32 @@ __global__ __launch_bounds__(256, UNET_HEAD_BWD_OCC) void head_bwd_kernel(const 
     dbacc[k] = 0.f;
   }
   const bool one_image = HW % HB == 0;   // a tile never straddles images
-  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+  // bs.partial != nullptr (round 4; the launcher checks that a workgroup's tiles - a contiguous
+  // range then - lie in ONE image): da is the final gradient of the layer that produced `a`, so
+  // the two reductions of its InstanceNorm + LeakyReLU + dropout backward,
+  //   S1 = sum gz,  S2 = sum gz * xhat,   gz = da * mask * (z > 0 ? 1 : slope),
+  // are formed here from values the kernel already holds (same expressions as the convolution
+  // epilogues, conv_params.h) - no pass over (da, y) by in_bwd_reduce_kernel.
+  const bool with_bs = bs.partial != nullptr;
+  f32x4 cA = {0.f, 0.f, 0.f, 0.f}, cB = cA, cM = cA, cMu = cA, cRs = cA, s1 = cA, s2 = cA;
+  const long long t_first = with_bs ? (long long)blockIdx.x * bs.tiles_per_block : blockIdx.x;
+  const long long t_step = with_bs ? 1 : gridDim.x;
+  const long long t_last = with_bs ? min(t_first + bs.tiles_per_block, tiles) : tiles;
+  if (with_bs) {
+    const size_t o = (size_t)(t_first * HB / HW) * 32 + seg * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(bs.gamma + seg * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bs.beta + seg * 4);
+    cMu = *reinterpret_cast<const f32x4*>(bs.mean + o);
+    cRs = *reinterpret_cast<const f32x4*>(bs.rstd + o);
+    cA = g * cRs;
+    cB = b - cMu * cA;
+    cM = bs.mask ? *reinterpret_cast<const f32x4*>(bs.mask + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  for (long long t = t_first; t < t_last; t += t_step) {
     const long long m0 = t * HB;
     // all loads of the tile first (rows past M are clamped and masked: no branch, so the eight
     // pixel loads and 8 x K gradient loads are in flight together)
-    f32x4 av[HB / 32];
+    f32x4 av[HB / 32], yv[HB / 32];
     float dv[HB / 32][4];
     f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
     if (alpha && one_image) {   // uniform: one coefficient row for the whole tile
@@ -145,6 +172,7 @@ __global__ __launch_bounds__(256, UNET_HEAD_BWD_OCC) void head_bwd_kernel(const 
       const long long m = m0 + it * 32 + grp;
       const long long mc = m < M ? m : M - 1;
       av[it] = ld4(a + (size_t)mc * 32 + seg * 4);
+      yv[it] = av[it];
       const long long n = one_image ? m0 / HW : mc / HW, pp = mc - n * HW;
       if (alpha) {   // uniform: the operand is a raw convolution output, activated on load
         if (!one_image) {
@@ -172,6 +200,15 @@ __global__ __launch_bounds__(256, UNET_HEAD_BWD_OCC) void head_bwd_kernel(const 
           dbacc[k] += dv[it][k];
         }
       if (m < M) st4(da + (size_t)m * 32 + seg * 4, v);
+      if (with_bs) {   // uniform (rows past M carry dv = 0, so v = 0 and gz = 0)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float z = fmaf(yv[it][jj], cA[jj], cB[jj]);
+          const float gz = v[jj] * cM[jj] * (z > 0.f ? 1.f : slope);   // (fp32 v, as the conv epilogues)
+          s1[jj] += gz;
+          s2[jj] = fmaf(gz, (yv[it][jj] - cMu[jj]) * cRs[jj], s2[jj]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -187,6 +224,22 @@ __global__ __launch_bounds__(256, UNET_HEAD_BWD_OCC) void head_bwd_kernel(const 
 #pragma unroll
     for (int g = 0; g < 32; ++g) sm += red[g][col];
     partial[(size_t)blockIdx.x * (K * 32 + K) + tid] = sm;
+  }
+  if (with_bs) {   // uniform: the 32 pixel groups of the workgroup merged in fixed order
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      red[grp][seg * 4 + jj] = s1[jj];
+      red[grp][32 + seg * 4 + jj] = s2[jj];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float sm = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) sm += red[g][tid];
+      // partial[(image * tiles_per_image + tile) * 32 + c] = (S1, S2): workgroup b IS tile b
+      reinterpret_cast<float*>(bs.partial)[((size_t)blockIdx.x * 32 + (tid & 31)) * 2 + (tid >> 5)] = sm;
+    }
   }
 }
 
@@ -609,7 +662,8 @@ extern "C" size_t unet_head1x1_bwd_workspace_bytes(int N, int HW, int C, int K) 
 static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w, float* da,
                             float* dw, float* db, void* workspace, size_t workspace_bytes, int N,
                             int HW, int C, int K, const float* alpha, const float* beta,
-                            float slope, unet_stream_t stream, int b16 = 0);
+                            float slope, unet_stream_t stream, int b16 = 0,
+                            unet_bwd_stats* bs = nullptr);
 
 extern "C" int unet_head1x1_bwd(const float* a, const float* dlogits, const float* w, float* da,
                                 float* dw, float* db, void* workspace, size_t workspace_bytes,
@@ -627,6 +681,28 @@ extern "C" int unet_head1x1_in_bwd(const unet_act_src* x, float slope, const flo
                           x->alpha, x->beta, slope, stream);
 }
 
+// ... with the reductions of the InstanceNorm + LeakyReLU + dropout backward of the layer whose
+// raw output x->x is (bs->y == x->x): da is that layer's final dL/da, so the kernel that writes
+// it also sums gz and gz * xhat per workgroup (bs->tiles_out summaries per image; 0 = the shape
+// does not split evenly: run unet_instnorm_lrelu_drop_bwd as usual)
+extern "C" int unet_head1x1_in_bwd_bs(const unet_act_src* x, float slope, const float* dlogits,
+                                      const float* w, float* da, float* dw, float* db,
+                                      void* workspace, size_t workspace_bytes, int N, int HW,
+                                      int K, unet_bwd_stats* bs, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && (!x->alpha || x->beta), "head1x1_in_bwd_bs: null source");
+  return head1x1_bwd_impl(x->x, dlogits, w, da, dw, db, workspace, workspace_bytes, N, HW, x->C, K,
+                          x->alpha, x->beta, slope, stream, 0, bs);
+}
+
+extern "C" int unet_head1x1_in_bwd_bs_b16(const unet_act_src* x, float slope, const float* dlogits,
+                                          const float* w, uint16_t* da, float* dw, float* db,
+                                          void* workspace, size_t workspace_bytes, int N, int HW,
+                                          int K, unet_bwd_stats* bs, unet_stream_t stream) {
+  UNET_REQUIRE(x && x->x && (!x->alpha || x->beta), "head1x1_in_bwd_bs_b16: null source");
+  return head1x1_bwd_impl(x->x, dlogits, w, reinterpret_cast<float*>(da), dw, db, workspace,
+                          workspace_bytes, N, HW, x->C, K, x->alpha, x->beta, slope, stream, 1, bs);
+}
+
 // x and da are bf16 tensors (mixed-precision pipeline); logits gradient and dw / db stay fp32
 extern "C" int unet_head1x1_in_bwd_b16(const unet_act_src* x, float slope, const float* dlogits,
                                        const float* w, uint16_t* da, float* dw, float* db,
@@ -640,7 +716,7 @@ extern "C" int unet_head1x1_in_bwd_b16(const unet_act_src* x, float slope, const
 static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w, float* da,
                             float* dw, float* db, void* workspace, size_t workspace_bytes, int N,
                             int HW, int C, int K, const float* alpha, const float* beta,
-                            float slope, unet_stream_t stream, int b16) {
+                            float slope, unet_stream_t stream, int b16, unet_bwd_stats* bs) {
   UNET_REQUIRE(a && dlogits && w && da && workspace, "head1x1_bwd: null pointer");
   UNET_REQUIRE(C == 32 && K >= 1 && K <= 4 && N > 0 && HW > 0,
                "head1x1_bwd: needs C == 32, K <= 4 (got C=%d K=%d)", C, K);
@@ -652,13 +728,32 @@ static int head1x1_bwd_impl(const float* a, const float* dlogits, const float* w
   const long long tiles = ceil_div64(M, HB);
   const int blocks = head_bwd_blocks(tiles);
   float* partial = reinterpret_cast<float*>(workspace);
+  // reductions of the InstanceNorm backward of the layer in front (bs): a workgroup then takes a
+  // contiguous range of tiles, which must lie in one image and divide it evenly - one summary
+  // "tile" of tiles_per_block * HB pixels per workgroup
+  HeadBs hb{};
+  if (bs) bs->tiles_out = 0;
+  if (bs && alpha && bs->y == a && bs->mean && bs->rstd && bs->gamma && bs->beta && bs->partial &&
+      M % HB == 0) {
+    const long long tpb = ceil_div64(tiles, blocks);
+    const long long px = tpb * HB;
+    if (tiles % tpb == 0 && tiles / tpb == blocks && HW % px == 0 &&
+        bs->partial_bytes >= (size_t)blocks * 32 * sizeof(float2)) {
+      hb.mean = bs->mean; hb.rstd = bs->rstd; hb.gamma = bs->gamma; hb.beta = bs->beta;
+      hb.mask = bs->mask; hb.partial = reinterpret_cast<float2*>(bs->partial);
+      hb.tiles_per_block = (int)tpb;
+      bs->tiles_out = (int)(HW / px);
+      UNET_REQUIRE(bs->slope == slope, "head1x1_in_bwd_bs: bs->slope differs from slope");
+    }
+  }
   if (b16)
     hipLaunchKernelGGL(head_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const __bf16*>(a), dlogits, w,
-                       reinterpret_cast<__bf16*>(da), partial, M, HW, K, tiles, alpha, beta, slope);
+                       reinterpret_cast<__bf16*>(da), partial, M, HW, K, tiles, alpha, beta, slope,
+                       hb);
   else
     hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a,
-                       dlogits, w, da, partial, M, HW, K, tiles, alpha, beta, slope);
+                       dlogits, w, da, partial, M, HW, K, tiles, alpha, beta, slope, hb);
   UNET_CHECK_LAUNCH("head_bwd");
   hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(K * 32 + K), dim3(256), 0, (hipStream_t)stream,
                      partial, dw, db, blocks, K);

@@ -358,22 +358,27 @@ __global__ __launch_bounds__(32 * FL) void in_bwd_finalize1_kernel(const float2*
                                                                float2* __restrict__ coef,
                                                                float2* __restrict__ sums, int HW,
                                                                int C, int split) {
-  __shared__ float sa[FL][33], sb[FL][33];
+  // The tile summaries are merged in double: S1 and S2 are sums of signed terms (for the first
+  // layers, of 2^18 pixels whose sum is far smaller than their magnitudes), and an fp32 running
+  // sum over up to 4096 tiles was the largest rounding term of dgamma / dbeta (round 4: the
+  // bs-8 = 4 x bs-2 test held encoder_stages.0's dbeta at 0.6-1.2e-4 of its maximum).
+  __shared__ double sa[FL][33], sb[FL][33];
   const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
-  float a = 0.f, b = 0.f;
+  double da_ = 0.0, db_ = 0.0;
   if (c < C)
     for (int s = l; s < split; s += FL) {
       const float2 v = partial[((size_t)n * split + s) * C + c];
-      a += v.x;
-      b += v.y;
+      da_ += (double)v.x;
+      db_ += (double)v.y;
     }
-  sa[l][cl] = a; sb[l][cl] = b;
+  sa[l][cl] = da_; sb[l][cl] = db_;
   __syncthreads();
   if (l == 0 && c < C) {
-    a = 0.f; b = 0.f;
+    da_ = 0.0; db_ = 0.0;
 #pragma unroll
-    for (int k = 0; k < FL; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+    for (int k = 0; k < FL; ++k) { da_ += sa[k][cl]; db_ += sb[k][cl]; }
+    float a = (float)da_, b = (float)db_;
     const float inv = 1.f / (float)HW;
     coef[(size_t)n * C + c] = float2{a * inv, b * inv};
     sums[(size_t)n * C + c] = float2{a, b};
@@ -392,22 +397,27 @@ __global__ __launch_bounds__(32 * FL) void in_bwd_coef_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mask, int HW, int C, int split, int NC) {
-  __shared__ float sa[FL][33], sb[FL][33];
+  // The tile summaries are merged in double: S1 and S2 are sums of signed terms (for the first
+  // layers, of 2^18 pixels whose sum is far smaller than their magnitudes), and an fp32 running
+  // sum over up to 4096 tiles was the largest rounding term of dgamma / dbeta (round 4: the
+  // bs-8 = 4 x bs-2 test held encoder_stages.0's dbeta at 0.6-1.2e-4 of its maximum).
+  __shared__ double sa[FL][33], sb[FL][33];
   const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
-  float a = 0.f, b = 0.f;
+  double da_ = 0.0, db_ = 0.0;
   if (c < C)
     for (int s = l; s < split; s += FL) {
       const float2 v = partial[((size_t)n * split + s) * C + c];
-      a += v.x;
-      b += v.y;
+      da_ += (double)v.x;
+      db_ += (double)v.y;
     }
-  sa[l][cl] = a; sb[l][cl] = b;
+  sa[l][cl] = da_; sb[l][cl] = db_;
   __syncthreads();
   if (l == 0 && c < C) {
-    a = 0.f; b = 0.f;
+    da_ = 0.0; db_ = 0.0;
 #pragma unroll
-    for (int k = 0; k < FL; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+    for (int k = 0; k < FL; ++k) { da_ += sa[k][cl]; db_ += sb[k][cl]; }
+    float a = (float)da_, b = (float)db_;
     const float inv = 1.f / (float)HW;
     const float c1 = a * inv, c2 = b * inv;
     const size_t i = (size_t)n * C + c;

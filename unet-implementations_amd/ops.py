@@ -989,16 +989,26 @@ def head1x1_in_fwd(x, slope, w, b):
     return logits
 
 
-def head1x1_in_bwd(x, slope, dlogits, w, dw, db):
+def head1x1_in_bwd(x, slope, dlogits, w, dw, db, nxt=None):
+    """nxt (NextNorm of the layer whose raw output x.x is): also leave the reductions of that
+    layer's InstanceNorm backward (nxt.tiles == 0: this shape has no such epilogue)."""
     x, rx = _act(x)
     N, H, W, C = x.shape
     K = w.shape[0]
     da = torch.empty_like(x.x)
     ws = _ws(lib().unet_head1x1_bwd_workspace_bytes(N, H * W, C, K), x.x)
-    fn = lib().unet_head1x1_in_bwd_b16 if _is_b16(x.x) else lib().unet_head1x1_in_bwd
+    b16 = _is_b16(x.x)
     t0 = _timer.begin() if _timer is not None else None
-    check(fn(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw), _ptr(db), _ptr(ws),
-             ws.numel(), N, H * W, K, _stream()))
+    if nxt is not None:
+        bs = nxt.c_struct()
+        fn = lib().unet_head1x1_in_bwd_bs_b16 if b16 else lib().unet_head1x1_in_bwd_bs
+        check(fn(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw), _ptr(db), _ptr(ws),
+                 ws.numel(), N, H * W, K, ctypes.byref(bs), _stream()))
+        nxt.tiles = bs.tiles_out
+    else:
+        fn = lib().unet_head1x1_in_bwd_b16 if b16 else lib().unet_head1x1_in_bwd
+        check(fn(rx, slope, _ptr(dlogits), _ptr(w), _ptr(da), _ptr(dw), _ptr(db), _ptr(ws),
+                 ws.numel(), N, H * W, K, _stream()))
     if t0 is not None:
         _timer.end("head_bwd", 0.0, 2, t0,
                    nbytes=da.element_size() * 2 * da.numel() + 4.0 * dlogits.numel())

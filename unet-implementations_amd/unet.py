@@ -847,8 +847,18 @@ class _UNetFunction(torch.autograd.Function):
         x3_bwd = ctx.fused and ctx.bf16 == "bf16x3"
         hw = head.weight.detach().view(head.out_channels, -1)
         if fused:
+            # g is the final gradient of the last decoder layer's output: the head's backward
+            # also leaves the reductions of that layer's InstanceNorm backward (NextNorm)
+            pr_ = saved[-1]
+            pl_ = pr_["layer"]
+            nxt_h = ops.NextNorm(pr_["y"], pr_["st"], pl_.norm.weight.detach(),
+                                 pl_.norm.bias.detach(), pr_["mask"], pl_.slope) \
+                if isinstance(ctx.last, ops.Act) and ctx.last.alpha is not None else None
             g = ops.head1x1_in_bwd(ctx.last, slope, dlogits, hw,
-                                   gv(head.weight).view(head.out_channels, -1), gv(head.bias))
+                                   gv(head.weight).view(head.out_channels, -1), gv(head.bias),
+                                   nxt=nxt_h)
+            if nxt_h is not None and nxt_h.tiles > 0:
+                pr_["nxt"] = nxt_h
         else:
             g = ops.head1x1_bwd(saved[-1]["a"], dlogits, hw,
                                 gv(head.weight).view(head.out_channels, -1), gv(head.bias))
