@@ -8,9 +8,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import unet_implementations_amd as ua
 ops = ua.ops
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+FP32 = "--fp32" in sys.argv          # the same five layers on fp32 tensors (gather form only)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+reps = int(args[0]) if args else 20
 N = 8
-BF = torch.bfloat16
+BF = torch.float32 if FP32 else torch.bfloat16
 # (stage, channels of the low-resolution operand, Cout of the convolution, low resolution)
 LAYERS = [("up1", 512, 512, 16), ("up2", 512, 256, 32), ("up3", 256, 128, 64),
           ("up4", 128, 64, 128), ("up5", 64, 32, 256)]
@@ -31,7 +33,7 @@ for name, C0, Cout, h in LAYERS:
     skip = Cout   # the skip half of the concatenated input (same width as Cout in Our_UNet)
     dy = torch.randn(N, 2 * h, 2 * h, Cout, device="cuda").to(BF)
     w = torch.randn(Cout, C0 + skip, 3, 3, device="cuda") * (2.0 / (9 * Cout)) ** 0.5
-    table = ops.PackTable([w], True, None)
+    table = ops.PackTable([w], not FP32, None)
     table.run()
     wd, wd3 = table.wd[0], table.wd3[0]
     t_t = timeit(lambda: ops.upsample2x_bwd_taps(dy))
@@ -46,8 +48,8 @@ for name, C0, Cout, h in LAYERS:
         nn = ops.NextNorm(yl, st, gx, bx, None, 0.01)
         return ops.conv3x3_up_bwd_data(D, wd, 0, C0, out=out, nxt=nn, wd3=w3)
     t_g = timeit(lambda: run(None))
-    t_d = timeit(lambda: run(wd3))
-    nbytes = 2.0 * (D.numel() + out.numel() + yl.numel())
+    t_d = timeit(lambda: run(None if FP32 else wd3))
+    nbytes = D.element_size() * (D.numel() + out.numel() + yl.numel())
     tot[0] += t_t; tot[1] += t_g; tot[2] += t_d
     print(f"{name:6s} {t_t:8.1f} {t_g:10.1f} {t_d:8.1f} {nbytes / t_d / 1e3:7.0f}", flush=True)
 print(f"{'total':6s} {tot[0]:8.1f} {tot[1]:10.1f} {tot[2]:8.1f}")

@@ -997,6 +997,11 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
     }
     return launch_igemm_fused<128, 32, 32, 32>(p, stream, stats_px);
   }
+  static const int taps64 = [] { const char* e = getenv("UNET_F32_TAPS_TILE"); return e ? atoi(e) : 0; }();
+  if (taps64 && p.tap_cstride != 0 && nc % 64 == 0 && M % 64 == 0 && ceil_div64(M, 64) * (nc / 64) >= 512) {
+    if (taps64 == 64) return launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
+    if (taps64 == 1264 && nc % 64 == 0) return launch_igemm_bs<128, 64, 64, 32>(p, stream, bs_px);
+  }
   if (bs_px) {   // per-class launches of one stride-2 gradient pass bs_tile0 themselves
     if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
       return launch_igemm_bs<128, 128, 64, 64>(p, stream, bs_px);
