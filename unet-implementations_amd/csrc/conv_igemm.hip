@@ -997,11 +997,13 @@ int dispatch_igemm(const IgemmParams& p, hipStream_t stream, int* stats_px, int*
     }
     return launch_igemm_fused<128, 32, 32, 32>(p, stream, stats_px);
   }
-  static const int taps64 = [] { const char* e = getenv("UNET_F32_TAPS_TILE"); return e ? atoi(e) : 0; }();
-  if (taps64 && p.tap_cstride != 0 && nc % 64 == 0 && M % 64 == 0 && ceil_div64(M, 64) * (nc / 64) >= 512) {
-    if (taps64 == 64) return launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
-    if (taps64 == 1264 && nc % 64 == 0) return launch_igemm_bs<128, 64, 64, 32>(p, stream, bs_px);
-  }
+  // low-resolution data gradient of the up-sampled operand ("channel taps": a plain GEMM over
+  // K = 9 Cout): 64 x 64 tiles at four workgroups per CU where the larger tiles leave the chip
+  // half filled or the layer has 64 columns (tools/bench_lowres_b16.py --fp32: 199 -> 188 us at
+  // 8192 x 512 x 2304, 242 -> 226 at 524288 x 64 x 288; the other three shapes +-0)
+  if (p.tap_cstride != 0 && nc % 64 == 0 && M % 64 == 0 && (M / 64) * (nc / 64) >= 512 &&
+      (nc == 64 || ceil_div64(M, 128) * (nc / 128) < 512))
+    return launch_igemm_bs<64, 64, 32, 32>(p, stream, bs_px);
   if (bs_px) {   // per-class launches of one stride-2 gradient pass bs_tile0 themselves
     if (nc % 128 == 0 && ceil_div64(M, 128) * (nc / 128) >= 256)
       return launch_igemm_bs<128, 128, 64, 64>(p, stream, bs_px);
