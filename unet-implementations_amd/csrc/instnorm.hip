@@ -376,7 +376,7 @@ __global__ __launch_bounds__(32 * FL) void in_bwd_finalize1_kernel(const float2*
   __syncthreads();
   if (l == 0 && c < C) {
     da_ = 0.0; db_ = 0.0;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < FL; ++k) { da_ += sa[k][cl]; db_ += sb[k][cl]; }
     float a = (float)da_, b = (float)db_;
     const float inv = 1.f / (float)HW;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(32 * FL) void in_bwd_coef_kernel(
   __syncthreads();
   if (l == 0 && c < C) {
     da_ = 0.0; db_ = 0.0;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < FL; ++k) { da_ += sa[k][cl]; db_ += sb[k][cl]; }
     float a = (float)da_, b = (float)db_;
     const float inv = 1.f / (float)HW;
