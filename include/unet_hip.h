@@ -690,7 +690,9 @@ int unet_conv3x3_up_bwd_data_bs_b16(const uint16_t* D, const float* wd, int Cin_
                                     int Ccols, int accumulate, unet_bwd_stats* bs,
                                     unet_stream_t stream);
 /* ... with the weights also pre-rounded to bf16 (wdb = [9][Cin_total][Cout] bf16, plane 0 of
- * wd3; NULL = as above): the contraction runs as a plain bf16 GEMM over the 9 * Cout contiguous
+ * wd3; NULL = as above; the backward of UpBlock's first convolution with respect to its
+ * up-sampled operand, Our_UNet/models/unet.py:219-231, under autocast,
+ * Our_UNet/src/train.py:638-652): the contraction runs as a plain bf16 GEMM over the 9 * Cout contiguous
  * values of a D row (64-wide K steps, no conversion of the weights).  Same result as the form
  * above up to the summation order of the fp32 accumulators; bs may be NULL. */
 int unet_conv3x3_up_bwd_data_bs_b16_wb(const uint16_t* D, const float* wd, const uint16_t* wdb,
